@@ -1,0 +1,119 @@
+"""Independent checker model (tests only): a dict-trie Aho-Corasick written
+ONLY from the emission rules of SURVEY.md section 0.1 / 8 a4-a5, not from the
+Cedar code path.  It cross-checks the C oracle (oracle/aha_oracle.c) and the
+HIP path on randomized inputs.
+
+Rules (reference src/aha/ac.cr:176-192, 265-278, 105-108):
+  * state after byte i = longest suffix of text[0..i] that is a trie path;
+  * if that state is not a key end: nothing is reported at i;
+  * otherwise report its key, then t = fail(state); while t is a key end:
+    report t's key, t = fail(t); stop at the first non-end t;
+  * a NUL input byte resets the state to root (defined-behaviour contract).
+"""
+
+
+class ModelError(Exception):
+    pass
+
+
+def _b(x):
+    return x.encode("utf-8") if isinstance(x, str) else bytes(x)
+
+
+class ModelAC:
+    def __init__(self, keys):
+        keys = [_b(k) for k in keys]
+        self.keys = keys
+        self.children = [dict()]
+        self.key_of = [-1]
+        self.depth = [0]
+        for idx, k in enumerate(keys):
+            if len(k) == 0:
+                raise ModelError("empty")
+            if 0 in k:
+                raise ModelError("zero")
+            s = 0
+            for b in k:
+                nxt = self.children[s].get(b)
+                if nxt is None:
+                    nxt = len(self.children)
+                    self.children.append(dict())
+                    self.key_of.append(-1)
+                    self.depth.append(self.depth[s] + 1)
+                    self.children[s][b] = nxt
+                s = nxt
+            if self.key_of[s] >= 0:
+                raise ModelError("dup")
+            self.key_of[s] = idx
+        n = len(self.children)
+        self.fail = [0] * n
+        order = []
+        queue = list(self.children[0].values())
+        while queue:
+            nq = []
+            for s in queue:
+                order.append(s)
+                for b, c in self.children[s].items():
+                    f = self.fail[s]
+                    while f and b not in self.children[f]:
+                        f = self.fail[f]
+                    t = self.children[f].get(b, 0)
+                    self.fail[c] = t if t != c else 0
+                    nq.append(c)
+            queue = nq
+
+    def _step(self, s, b):
+        if b == 0:
+            return 0
+        while s and b not in self.children[s]:
+            s = self.fail[s]
+        return self.children[s].get(b, 0)
+
+    def match(self, text, sep=None, chars=None):
+        """sep: None or (size, set_bits).  Returns list of (start,end,value)."""
+        if chars is None:
+            chars = isinstance(text, str)
+        t = _b(text)
+
+        def blocked(ch):
+            if sep is None:
+                return False
+            size, bits = sep
+            return ch < size and ch not in set(bits)
+
+        out = []
+        s = 0
+        for i, b in enumerate(t):
+            s = self._step(s, b)
+            if self.key_of[s] < 0:
+                continue
+            if i + 1 < len(t) and blocked(t[i + 1]):
+                continue
+            u = s
+            while True:
+                k = self.key_of[u]
+                st = i + 1 - len(self.keys[k])
+                if not (st > 0 and blocked(t[st - 1])):
+                    out.append((st, i + 1, k))
+                u = self.fail[u]
+                if self.key_of[u] < 0:
+                    break
+        if chars:
+            cmap = []
+            ci = -1
+            for b in t:
+                if (b & 0xC0) != 0x80:
+                    ci += 1
+                cmap.append(ci)
+            out = [(cmap[a], cmap[e - 1] + 1, v) for (a, e, v) in out]
+        return out
+
+    def textbook(self, text):
+        """All true occurrences (for showing the reference emits a subset)."""
+        t = _b(text)
+        out = []
+        for i in range(len(t)):
+            for k, key in enumerate(self.keys):
+                if i + 1 >= len(key) and t[i + 1 - len(key):i + 1] == key:
+                    out.append((i + 1 - len(key), i + 1, k))
+        return out

@@ -1,0 +1,105 @@
+"""ctypes binding of libaha_hip.so (include/aha_hip.h).
+
+The library is built in-tree (aha_amd/csrc/Makefile, or
+__graft_entry__.build()); there is no pure-Python or CPU fallback: if the
+shared object is missing, importing the product path fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaha_hip.so")
+SYNTH_PATH = os.path.join(_HERE, "libaha_synth.so")
+
+AHA_OK = 0
+AHA_E_INVALID = -1
+AHA_E_EMPTY_KEY = -2
+AHA_E_ZERO_BYTE = -3
+AHA_E_DUP_KEY = -4
+AHA_E_SEP_SIZE = -5
+AHA_E_CAPACITY = -6
+AHA_E_NO_DEVICE = -7
+AHA_E_HIP = -8
+AHA_E_TOO_LONG = -9
+AHA_E_NOT_FOUND = -10
+AHA_E_TOO_LARGE = -11
+
+AHA_OPT_HOST_ONLY = 1
+AHA_OPT_FORCE_WIDE = 2
+
+
+class aha_options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class aha_match_params(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("char_offsets", C.c_int32), ("sep_size", C.c_int32),
+                ("sep_bits", C.c_uint8 * 32)]
+
+
+class aha_ac_info_t(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_keys", C.c_uint32), ("n_states", C.c_uint64),
+                ("n_slots", C.c_uint64), ("image_bytes", C.c_uint64), ("max_key_len", C.c_uint32),
+                ("slot_bytes", C.c_uint32), ("lds_slots", C.c_uint32), ("device", C.c_int32)]
+
+
+class aha_timing(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_kernels", C.c_uint32), ("ms_total", C.c_float),
+                ("ms_count", C.c_float), ("ms_scan", C.c_float), ("ms_write", C.c_float),
+                ("ms_aux", C.c_float), ("n_chunks", C.c_uint64), ("n_hits", C.c_uint64)]
+
+
+# every symbol include/aha_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
+SIGNATURES = {
+    "aha_strerror": (C.c_char_p, [_i32]),
+    "aha_last_error": (C.c_char_p, [_vp]),
+    "aha_abi_version": (_u32, []),
+    "aha_device_count": (_i32, []),
+    "aha_ac_compile": (_i32, [_vp, _vp, _u32, C.POINTER(aha_options), C.POINTER(_vp), C.POINTER(_u32)]),
+    "aha_ac_free": (None, [_vp]),
+    "aha_ac_info": (_i32, [_vp, C.POINTER(aha_ac_info_t)]),
+    "aha_ac_key": (_i32, [_vp, _i32, _vp, _i32]),
+    "aha_ac_id": (_i32, [_vp, _vp, _i32]),
+    "aha_ac_match_bytes": (_i32, [_vp, _vp, _u64, C.POINTER(aha_match_params), _vp, _u64, C.POINTER(_u64)]),
+    "aha_ac_match_batch": (_i32, [_vp, _vp, _vp, _u64, C.POINTER(aha_match_params), _vp, _u64, _vp,
+                                  C.POINTER(_u64)]),
+    "aha_ac_match_batch_device": (_i32, [_vp, _vp, _vp, _u64, _u64, C.POINTER(aha_match_params), _vp, _u64,
+                                         _vp, C.POINTER(_u64), _vp]),
+    "aha_ac_export": (C.c_int64, [_vp, _i32, _vp, _u64]),
+    "aha_ac_set_profiling": (_i32, [_vp, _i32]),
+    "aha_ac_last_timing": (_i32, [_vp, C.POINTER(aha_timing)]),
+}
+
+_lib = None
+_synth = None
+
+
+def lib():
+    """Loads libaha_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C aha_amd/csrc` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def synth():
+    global _synth
+    if _synth is None:
+        L = C.CDLL(SYNTH_PATH)
+        L.aha_synth_keys.restype = C.c_int64
+        L.aha_synth_keys.argtypes = [C.c_int, _u64, _u32, _vp, _u64, _vp, C.POINTER(_u32)]
+        L.aha_synth_corpus.restype = C.c_int64
+        L.aha_synth_corpus.argtypes = [C.c_int, _u64, _vp, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _u64]
+        _synth = L
+    return _synth

@@ -1,0 +1,246 @@
+"""Host-side mirror of the reference's public API for the accelerated path:
+``Aha::AC.compile`` / ``#match`` / ``Aha::Hit`` (src/aha/ac.cr:62-112, 280-295,
+321-364; src/aha/matcher.cr:2-46), backed by libaha_hip.so through the C ABI.
+
+Names, argument meaning and error behaviour follow the reference so that the
+parity tests read like spec/ac_spec.cr:
+
+    matcher = AC.compile(["我", "我是", "是中"])
+    for hit in matcher.match("我是中国人"):
+        hit.end, hit.value
+
+``str`` input is the ``String`` overload (char offsets), ``bytes`` the
+``Bytes`` overload (byte offsets), a list of 1-char strings the ``Array(Char)``
+overload.  There is no CPU fallback: matching needs a HIP device.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _native as N
+
+#: Aha::Hit -- src/aha/matcher.cr:2-11
+Hit = namedtuple("Hit", ["start", "end", "value"])
+
+HIT_DTYPE = np.dtype([("start", "<i4"), ("end", "<i4"), ("value", "<i4")])
+
+
+class AhaError(RuntimeError):
+    """The reference raises plain Strings; ``code`` is the C-ABI status."""
+
+    def __init__(self, code, message=None, key_index=None):
+        self.code = code
+        self.key_index = key_index
+        super().__init__(message or N.lib().aha_strerror(code).decode())
+
+
+class BitArray:
+    """Minimal stand-in for Crystal's BitArray as used by match(seq, sep)."""
+
+    def __init__(self, size):
+        self.size = int(size)
+        self._bits = bytearray((max(self.size, 1) + 7) // 8)
+
+    def __setitem__(self, i, v):
+        if not 0 <= i < self.size:
+            raise IndexError(i)
+        if v:
+            self._bits[i >> 3] |= 1 << (i & 7)
+        else:
+            self._bits[i >> 3] &= ~(1 << (i & 7))
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.size:
+            raise IndexError(i)
+        return bool((self._bits[i >> 3] >> (i & 7)) & 1)
+
+
+def _b(x):
+    if isinstance(x, str):
+        return x.encode("utf-8")
+    return bytes(x)
+
+
+def _pack_keys(keys):
+    ks = [_b(k) for k in keys]
+    offs = np.zeros(len(ks) + 1, dtype=np.uint64)
+    if ks:
+        offs[1:] = np.cumsum([len(k) for k in ks], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(ks), dtype=np.uint8) if ks else np.zeros(0, np.uint8)
+    return blob, offs
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def _params(chars, sep):
+    p = N.aha_match_params()
+    p.struct_size = C.sizeof(N.aha_match_params)
+    p.char_offsets = 1 if chars else 0
+    p.sep_size = 0
+    if sep is not None:
+        p.sep_size = sep.size
+        n = min(len(sep._bits), 32)
+        for i in range(n):
+            p.sep_bits[i] = sep._bits[i]
+    return p
+
+
+class AC:
+    """Aha::AC (= ACX(Int32), src/aha/ac.cr:8-11) on the MI355X."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.lib().aha_ac_free(h)
+
+    # -- Aha::AC.compile(keys) src/aha/ac.cr:62-69 ---------------------------
+    @classmethod
+    def compile(cls, keys, device=-1, host_only=False, force_wide=False):
+        blob, offs = _pack_keys(keys)
+        return cls.compile_packed(blob, offs, device, host_only, force_wide)
+
+    @classmethod
+    def compile_packed(cls, blob, offs, device=-1, host_only=False, force_wide=False):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        opts = N.aha_options()
+        opts.struct_size = C.sizeof(N.aha_options)
+        opts.device = device
+        opts.flags = (N.AHA_OPT_HOST_ONLY if host_only else 0) | (N.AHA_OPT_FORCE_WIDE if force_wide else 0)
+        h = C.c_void_p()
+        ek = C.c_uint32(0)
+        rc = N.lib().aha_ac_compile(_ptr(blob), _ptr(offs), len(offs) - 1, C.byref(opts), C.byref(h),
+                                    C.byref(ek))
+        if rc != N.AHA_OK:
+            msg = None
+            if rc == N.AHA_E_DUP_KEY:  # raise "key:#{key} appear twice." ac.cr:66
+                k = bytes(blob[int(offs[ek.value]):int(offs[ek.value + 1])])
+                msg = f"key:{k.decode('utf-8', 'replace')} appear twice."
+            raise AhaError(rc, msg, ek.value)
+        return cls(h)
+
+    def _check(self, rc):
+        if rc != N.AHA_OK:
+            msg = N.lib().aha_last_error(self._h).decode() or None
+            raise AhaError(rc, msg)
+
+    @property
+    def info(self):
+        i = N.aha_ac_info_t()
+        self._check(N.lib().aha_ac_info(self._h, C.byref(i)))
+        return {f: getattr(i, f) for f, _ in i._fields_ if f != "struct_size"}
+
+    # -- delegate :[] src/aha/ac.cr:41-43 ------------------------------------
+    def __getitem__(self, x):
+        if isinstance(x, (int, np.integer)):
+            buf = C.create_string_buffer(1 << 12)
+            n = N.lib().aha_ac_key(self._h, int(x), buf, len(buf))
+            if n > len(buf):
+                buf = C.create_string_buffer(n)
+                n = N.lib().aha_ac_key(self._h, int(x), buf, len(buf))
+            if n < 0:
+                raise IndexError(x)
+            return buf.raw[:n].decode("utf-8", "replace")
+        k = _b(x)
+        r = N.lib().aha_ac_id(self._h, k, len(k))
+        if r < 0:
+            raise IndexError(x)  # IndexError.new cedar.cr:832
+        return r
+
+    # -- #match ---------------------------------------------------------------
+    def match_array(self, seq, sep=None, chars=None):
+        """All hits of one sequence as a HIT_DTYPE array (reference order)."""
+        if isinstance(seq, (list, tuple)) and (not seq or isinstance(seq[0], str)):
+            # Array(Char) overload (ac.cr:288-295): chars re-encode to UTF-8
+            seq = "".join(seq)
+        if chars is None:
+            chars = isinstance(seq, str)
+        t = np.frombuffer(_b(seq), dtype=np.uint8)
+        p = _params(chars, sep)
+        cap = max(64, t.size // 4)
+        while True:
+            out = np.zeros(cap, dtype=HIT_DTYPE)
+            n = C.c_uint64(0)
+            rc = N.lib().aha_ac_match_bytes(self._h, _ptr(t), t.size, C.byref(p), _ptr(out), cap, C.byref(n))
+            if rc == N.AHA_E_CAPACITY:
+                cap = int(n.value)
+                continue
+            self._check(rc)
+            return out[: n.value]
+
+    def match(self, seq, sep=None, chars=None):
+        """Yields Aha::Hit like the reference's block form (ac.cr:280-286)."""
+        for s, e, v in self.match_array(seq, sep, chars).tolist():
+            yield Hit(s, e, v)
+
+    def match_batch(self, corpus, doc_offsets, sep=None, chars=False, cap=None):
+        """D documents in one call: returns (hits, doc_hit_offsets)."""
+        if isinstance(corpus, (bytes, bytearray)):
+            corpus = np.frombuffer(bytes(corpus), dtype=np.uint8)
+        corpus = np.ascontiguousarray(corpus, dtype=np.uint8)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        D = doc_offsets.size - 1
+        p = _params(chars, sep)
+        dho = np.zeros(D + 1, dtype=np.uint64)
+        if cap is None:
+            cap = max(64, corpus.size // 8)
+        while True:
+            out = np.zeros(cap, dtype=HIT_DTYPE)
+            n = C.c_uint64(0)
+            rc = N.lib().aha_ac_match_batch(self._h, _ptr(corpus), _ptr(doc_offsets), D, C.byref(p), _ptr(out),
+                                            cap, _ptr(dho), C.byref(n))
+            if rc == N.AHA_E_CAPACITY:
+                cap = int(n.value)
+                continue
+            self._check(rc)
+            return out[: n.value], dho
+
+    def match_batch_device(self, corpus, doc_offsets, out, doc_hit_offsets=None, sep=None, chars=False,
+                           stream=None):
+        """Device-resident batch match on torch CUDA tensors (uint8 corpus,
+        int64/uint64 doc offsets, int32 [cap,3] out).  Returns the hit count;
+        raises AhaError(AHA_E_CAPACITY) with .required when out is too small."""
+        import torch
+
+        assert corpus.is_cuda and corpus.dtype == torch.uint8 and corpus.is_contiguous()
+        assert doc_offsets.is_cuda and doc_offsets.dtype in (torch.int64, torch.uint64)
+        assert out.is_cuda and out.dtype == torch.int32 and out.is_contiguous()
+        D = doc_offsets.numel() - 1
+        cap = out.numel() // 3
+        p = _params(chars, sep)
+        n = C.c_uint64(0)
+        s = stream if stream is not None else torch.cuda.current_stream(corpus.device).cuda_stream
+        dho = doc_hit_offsets.data_ptr() if doc_hit_offsets is not None else None
+        rc = N.lib().aha_ac_match_batch_device(self._h, corpus.data_ptr(), doc_offsets.data_ptr(), D,
+                                               corpus.numel(), C.byref(p), out.data_ptr(), cap, dho,
+                                               C.byref(n), C.c_void_p(s))
+        if rc == N.AHA_E_CAPACITY:
+            e = AhaError(rc)
+            e.required = int(n.value)
+            raise e
+        self._check(rc)
+        return int(n.value)
+
+    def export(self, which, dtype):
+        """One array of the automaton image (data; host-logic tests, debugging)."""
+        n = N.lib().aha_ac_export(self._h, which, None, 0)
+        if n < 0:
+            raise AhaError(int(n))
+        buf = np.zeros(int(n) // np.dtype(dtype).itemsize, dtype=dtype)
+        if n:
+            N.lib().aha_ac_export(self._h, which, _ptr(buf), int(n))
+        return buf
+
+    def set_profiling(self, enabled=True):
+        self._check(N.lib().aha_ac_set_profiling(self._h, 1 if enabled else 0))
+
+    def last_timing(self):
+        t = N.aha_timing()
+        self._check(N.lib().aha_ac_last_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in t._fields_ if f != "struct_size"}

@@ -1,0 +1,493 @@
+// capi.cpp -- the C ABI of libaha_hip.so (include/aha_hip.h): host-side
+// orchestration of compile (CPU) and match (HIP kernels).  There is NO CPU
+// matching fallback in this library: without a usable HIP device every match
+// entry point fails with AHA_E_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "automaton.hpp"
+#include "image.hpp"
+
+using namespace aha;
+
+struct aha_ac {
+  Automaton aut;
+  Image img;  // host copy of the device image (export / debugging)
+  uint32_t n_slots = 0;
+  uint32_t slot_bytes = 0;
+  bool compact = false;
+  uint64_t image_bytes = 0;
+  int device = -1;
+  DevAut dev{};
+  std::vector<void *> dev_allocs;
+  // scratch (grow-only, guarded by mu)
+  std::mutex mu;
+  uint32_t *d_counts = nullptr, *d_leads = nullptr;
+  uint64_t *d_blk_hits = nullptr, *d_blk_leads = nullptr, *d_docg = nullptr, *d_totals = nullptr;
+  uint64_t cap_chunks = 0, cap_blocks = 0, cap_docs = 0;
+  uint64_t *h_totals = nullptr;  // pinned
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[6] = {};
+  bool ev_ready = false;
+  aha_timing last{};
+  uint32_t chunk = 256;
+  std::string err;
+};
+
+namespace {
+
+#define HIPCHK(ac, call)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      (ac)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+      return AHA_E_HIP;                                                               \
+    }                                                                                 \
+  } while (0)
+
+template <typename T>
+int32_t upload(aha_ac *ac, const std::vector<T> &v, const T **out) {
+  void *d = nullptr;
+  size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+  HIPCHK(ac, hipMalloc(&d, bytes));
+  ac->dev_allocs.push_back(d);
+  if (!v.empty()) HIPCHK(ac, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  ac->image_bytes += v.size() * sizeof(T);
+  *out = reinterpret_cast<const T *>(d);
+  return AHA_OK;
+}
+
+int32_t upload_image(aha_ac *ac, const Image &img) {
+  const Automaton &a = ac->aut;
+  DevAut &d = ac->dev;
+  d.root = img.root_base;
+  d.n_slots = img.n_slots;
+  d.max_len = a.max_key_len;
+  d.compact = img.compact ? 1u : 0u;
+  int32_t rc;
+  if (img.compact) {
+    const uint32_t *p = nullptr;
+    if ((rc = upload(ac, img.narrow, &p))) return rc;
+    d.slots = p;
+    if ((rc = upload(ac, img.end_key, &d.end_key))) return rc;
+  } else {
+    const uint64_t *p = nullptr;
+    if ((rc = upload(ac, img.wide, &p))) return rc;
+    d.slots = p;
+    d.end_key = nullptr;
+  }
+  std::vector<uint2> ln(a.n_keys);
+  for (uint32_t k = 0; k < a.n_keys; k++) ln[k] = uint2{a.key_len[k], (uint32_t)a.key_next[k]};
+  if ((rc = upload(ac, ln, &d.key_ln))) return rc;
+  if ((rc = upload(ac, a.key_cnt, &d.key_cnt))) return rc;
+  if ((rc = upload(ac, a.key_kc, &d.key_kc))) return rc;
+  return AHA_OK;
+}
+
+int32_t ensure_scratch(aha_ac *ac, uint64_t n_chunks, uint64_t n_blocks, uint64_t n_docs) {
+  if (n_chunks > ac->cap_chunks) {
+    if (ac->d_counts) (void)hipFree(ac->d_counts);
+    if (ac->d_leads) (void)hipFree(ac->d_leads);
+    ac->d_counts = ac->d_leads = nullptr;
+    ac->cap_chunks = 0;
+    uint64_t n = n_chunks + n_chunks / 8 + 1024;
+    HIPCHK(ac, hipMalloc((void **)&ac->d_counts, n * sizeof(uint32_t)));
+    HIPCHK(ac, hipMalloc((void **)&ac->d_leads, n * sizeof(uint32_t)));
+    ac->cap_chunks = n;
+  }
+  if (n_blocks > ac->cap_blocks) {
+    if (ac->d_blk_hits) (void)hipFree(ac->d_blk_hits);
+    if (ac->d_blk_leads) (void)hipFree(ac->d_blk_leads);
+    ac->d_blk_hits = ac->d_blk_leads = nullptr;
+    ac->cap_blocks = 0;
+    uint64_t n = n_blocks + n_blocks / 8 + 64;
+    HIPCHK(ac, hipMalloc((void **)&ac->d_blk_hits, n * sizeof(uint64_t)));
+    HIPCHK(ac, hipMalloc((void **)&ac->d_blk_leads, n * sizeof(uint64_t)));
+    ac->cap_blocks = n;
+  }
+  if (n_docs + 1 > ac->cap_docs) {
+    if (ac->d_docg) (void)hipFree(ac->d_docg);
+    ac->d_docg = nullptr;
+    ac->cap_docs = 0;
+    uint64_t n = n_docs + 1 + n_docs / 8 + 64;
+    HIPCHK(ac, hipMalloc((void **)&ac->d_docg, n * sizeof(uint64_t)));
+    ac->cap_docs = n;
+  }
+  if (!ac->d_totals) {
+    HIPCHK(ac, hipMalloc((void **)&ac->d_totals, 2 * sizeof(uint64_t)));
+    HIPCHK(ac, hipHostMalloc((void **)&ac->h_totals, 2 * sizeof(uint64_t), hipHostMallocDefault));
+  }
+  return AHA_OK;
+}
+
+int32_t fill_params(aha_ac *ac, const aha_match_params *p, MatchArgs &M) {
+  M.chars = 0;
+  M.sep = 0;
+  memset(M.sep_block, 0, sizeof(M.sep_block));
+  if (!p) return AHA_OK;
+  M.chars = p->char_offsets ? 1 : 0;
+  if (p->sep_size > 256) {  // raise "sep BitArray size > 256 is not supported" ac.cr:322
+    ac->err = "sep BitArray size > 256 is not supported";
+    return AHA_E_SEP_SIZE;
+  }
+  if (p->sep_size > 0) {
+    M.sep = 1;
+    // blocked(c) <=> c < sep.size && !sep[c]   (ac.cr:326, 333)
+    for (int c = 0; c < p->sep_size; c++)
+      if (!((p->sep_bits[c >> 3] >> (c & 7)) & 1)) M.sep_block[c >> 5] |= 1u << (c & 31);
+  }
+  return AHA_OK;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool active = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+      active = hipSetDevice(dev) == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (active) (void)hipSetDevice(prev);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *aha_strerror(int32_t code) {
+  switch (code) {
+    case AHA_OK: return "ok";
+    case AHA_E_INVALID: return "invalid argument";
+    case AHA_E_EMPTY_KEY: return "Cannot insert empty key";
+    case AHA_E_ZERO_BYTE: return "key[pos] is zero";
+    case AHA_E_DUP_KEY: return "key appear twice.";
+    case AHA_E_SEP_SIZE: return "sep BitArray size > 256 is not supported";
+    case AHA_E_CAPACITY: return "output buffer too small";
+    case AHA_E_NO_DEVICE: return "no usable HIP device (libaha_hip has no CPU fallback)";
+    case AHA_E_HIP: return "HIP runtime error";
+    case AHA_E_TOO_LONG: return "sequence longer than Int32 offsets allow";
+    case AHA_E_NOT_FOUND: return "not found";
+    case AHA_E_TOO_LARGE: return "automaton too large for the device image";
+  }
+  return "unknown error";
+}
+
+const char *aha_last_error(const aha_ac *ac) { return ac ? ac->err.c_str() : ""; }
+uint32_t aha_abi_version(void) { return AHA_ABI_VERSION; }
+
+int32_t aha_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, uint32_t n_keys,
+                       const aha_options *opts, aha_ac **out, uint32_t *err_key) {
+  if (!out || !key_offsets || (n_keys && !key_bytes && key_offsets[n_keys] != key_offsets[0]))
+    return AHA_E_INVALID;
+  *out = nullptr;
+  uint32_t flags = opts ? opts->flags : 0;
+  int device = opts ? opts->device : -1;
+  aha_ac *ac = new aha_ac();
+  BuildError be;
+  static const uint8_t dummy = 0;
+  if (!build_automaton(key_bytes ? key_bytes : &dummy, key_offsets, n_keys, ac->aut, be)) {
+    if (err_key) *err_key = be.key_index;
+    delete ac;
+    return be.code;
+  }
+  Placement pl;
+  place_states(ac->aut, pl);
+  Image &img = ac->img;
+  if (!encode_image(ac->aut, pl, (flags & AHA_OPT_FORCE_WIDE) != 0, img)) {
+    delete ac;
+    return AHA_E_TOO_LARGE;
+  }
+  ac->n_slots = img.n_slots;
+  ac->compact = img.compact;
+  ac->slot_bytes = img.compact ? 4 : 8;
+  if (!(flags & AHA_OPT_HOST_ONLY)) {
+    int n = aha_device_count();
+    if (n <= 0) {
+      delete ac;
+      return AHA_E_NO_DEVICE;
+    }
+    if (device < 0) {
+      if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n) {
+      delete ac;
+      return AHA_E_INVALID;
+    }
+    ac->device = device;
+    DeviceGuard g(device);
+    int32_t rc = upload_image(ac, img);
+    if (rc != AHA_OK) {
+      fprintf(stderr, "aha_ac_compile: %s\n", ac->err.c_str());
+      aha_ac_free(ac);
+      return rc;
+    }
+  }
+  *out = ac;
+  return AHA_OK;
+}
+
+void aha_ac_free(aha_ac *ac) {
+  if (!ac) return;
+  if (ac->device >= 0) {
+    DeviceGuard g(ac->device);
+    for (void *p : ac->dev_allocs) (void)hipFree(p);
+    void *scratch[] = {ac->d_counts, ac->d_leads, ac->d_blk_hits, ac->d_blk_leads, ac->d_docg, ac->d_totals};
+    for (void *p : scratch)
+      if (p) (void)hipFree(p);
+    if (ac->h_totals) (void)hipHostFree(ac->h_totals);
+    if (ac->ev_ready)
+      for (auto &e : ac->ev) (void)hipEventDestroy(e);
+  }
+  delete ac;
+}
+
+int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
+  if (!ac || !info) return AHA_E_INVALID;
+  memset(info, 0, sizeof(*info));
+  info->struct_size = sizeof(*info);
+  info->n_keys = ac->aut.n_keys;
+  info->n_states = ac->aut.n_states;
+  info->n_slots = ac->n_slots;
+  info->image_bytes = ac->image_bytes;
+  info->max_key_len = ac->aut.max_key_len;
+  info->slot_bytes = ac->slot_bytes;
+  info->lds_slots = 0;
+  info->device = ac->device;
+  return AHA_OK;
+}
+
+int32_t aha_ac_key(const aha_ac *ac, int32_t id, uint8_t *buf, int32_t cap) {
+  if (!ac) return AHA_E_INVALID;
+  if (id < 0 || (uint32_t)id >= ac->aut.n_keys) return AHA_E_NOT_FOUND;
+  uint64_t o = ac->aut.offs[id], n = ac->aut.offs[id + 1] - o;
+  if (buf && cap > 0) memcpy(buf, ac->aut.blob.data() + o, std::min<uint64_t>(n, (uint64_t)cap));
+  return (int32_t)n;
+}
+
+int32_t aha_ac_id(const aha_ac *ac, const uint8_t *key, int32_t len) {
+  if (!ac || (!key && len > 0)) return AHA_E_INVALID;
+  int32_t k = ac->aut.find_key(key, len);
+  return k < 0 ? AHA_E_NOT_FOUND : k;
+}
+
+int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_bytes) {
+  if (!ac) return AHA_E_INVALID;
+  const void *src = nullptr;
+  uint64_t bytes = 0;
+  std::vector<uint32_t> tmp;
+  const Automaton &a = ac->aut;
+  switch (which) {
+    case AHA_IMG_SLOTS:
+      if (ac->img.compact) {
+        src = ac->img.narrow.data();
+        bytes = ac->img.narrow.size() * 4;
+      } else {
+        src = ac->img.wide.data();
+        bytes = ac->img.wide.size() * 8;
+      }
+      break;
+    case AHA_IMG_END_KEY:
+      src = ac->img.end_key.data();
+      bytes = ac->img.end_key.size() * 4;
+      break;
+    case AHA_IMG_KEY_LN:
+      tmp.resize((size_t)a.n_keys * 2);
+      for (uint32_t k = 0; k < a.n_keys; k++) {
+        tmp[2 * k] = a.key_len[k];
+        tmp[2 * k + 1] = (uint32_t)a.key_next[k];
+      }
+      src = tmp.data();
+      bytes = tmp.size() * 4;
+      break;
+    case AHA_IMG_KEY_CNT:
+      src = a.key_cnt.data();
+      bytes = a.key_cnt.size() * 4;
+      break;
+    case AHA_IMG_KEY_KC:
+      src = a.key_kc.data();
+      bytes = a.key_kc.size() * 4;
+      break;
+    default:
+      return AHA_E_INVALID;
+  }
+  if (buf && cap_bytes >= bytes && bytes) memcpy(buf, src, bytes);
+  return (int64_t)bytes;
+}
+
+int32_t aha_ac_set_profiling(aha_ac *ac, int32_t enabled) {
+  if (!ac) return AHA_E_INVALID;
+  if (ac->device < 0) return AHA_E_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ac->mu);
+  if (enabled && !ac->ev_ready) {
+    DeviceGuard g(ac->device);
+    for (auto &e : ac->ev) HIPCHK(ac, hipEventCreate(&e));
+    ac->ev_ready = true;
+  }
+  ac->profiling = enabled != 0;
+  return AHA_OK;
+}
+
+int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t) {
+  if (!ac || !t) return AHA_E_INVALID;
+  *t = ac->last;
+  t->struct_size = sizeof(*t);
+  return AHA_OK;
+}
+
+int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
+                                  const uint64_t *d_doc_offsets, uint64_t n_docs,
+                                  uint64_t n_bytes, const aha_match_params *params,
+                                  aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets,
+                                  uint64_t *n_hits, void *stream) {
+  if (!ac || !n_hits || !d_doc_offsets) return AHA_E_INVALID;
+  if (ac->device < 0) {
+    ac->err = aha_strerror(AHA_E_NO_DEVICE);
+    return AHA_E_NO_DEVICE;
+  }
+  if (cap && !d_out) return AHA_E_INVALID;
+  std::lock_guard<std::mutex> lk(ac->mu);
+  DeviceGuard g(ac->device);
+  hipStream_t s = (hipStream_t)stream;
+  MatchArgs M{};
+  int32_t rc = fill_params(ac, params, M);
+  if (rc) return rc;
+  *n_hits = 0;
+  if (n_bytes == 0) {
+    if (d_doc_hit_offsets)
+      HIPCHK(ac, hipMemsetAsync(d_doc_hit_offsets, 0, (n_docs + 1) * sizeof(uint64_t), s));
+    HIPCHK(ac, hipStreamSynchronize(s));
+    return AHA_OK;
+  }
+  if (!d_corpus) return AHA_E_INVALID;
+  M.text = d_corpus;
+  M.doc_off = d_doc_offsets;
+  M.n_docs = n_docs;
+  M.n_bytes = n_bytes;
+  M.chunk = ac->chunk;
+  // warm-up is Lmax-1 bytes per chunk: keep it a small fraction of the chunk
+  while (M.chunk < 8ull * ac->aut.max_key_len && M.chunk < (1u << 20)) M.chunk *= 2;
+  M.n_chunks = (n_bytes + M.chunk - 1) / M.chunk;
+  const uint64_t n_blocks = (M.n_chunks + kBlock - 1) / kBlock;
+  if ((rc = ensure_scratch(ac, M.n_chunks, n_blocks, n_docs))) return rc;
+  M.counts = ac->d_counts;
+  M.leads = ac->d_leads;
+  M.blk_hits = ac->d_blk_hits;
+  M.blk_leads = ac->d_blk_leads;
+  M.docg = ac->d_docg;
+  M.totals = ac->d_totals;
+  M.out = d_out;
+  M.cap = cap;
+  M.doc_hit_off = d_doc_hit_offsets;
+
+  const bool prof = ac->profiling && ac->ev_ready;
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
+  launch_count(ac->dev, M, s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
+  launch_scan_blocks(M, n_blocks, s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
+  if (M.chars) launch_docg(M, s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[3], s));
+  launch_write(ac->dev, M, s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[4], s));
+  HIPCHK(ac, hipGetLastError());
+  HIPCHK(ac, hipMemcpyAsync(ac->h_totals, ac->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(ac, hipStreamSynchronize(s));
+  *n_hits = ac->h_totals[0];
+  if (prof) {
+    aha_timing &t = ac->last;
+    memset(&t, 0, sizeof(t));
+    t.struct_size = sizeof(t);
+    t.n_kernels = M.chars ? 4 : 3;
+    (void)hipEventElapsedTime(&t.ms_total, ac->ev[0], ac->ev[4]);
+    (void)hipEventElapsedTime(&t.ms_count, ac->ev[0], ac->ev[1]);
+    (void)hipEventElapsedTime(&t.ms_scan, ac->ev[1], ac->ev[2]);
+    (void)hipEventElapsedTime(&t.ms_aux, ac->ev[2], ac->ev[3]);
+    (void)hipEventElapsedTime(&t.ms_write, ac->ev[3], ac->ev[4]);
+    t.n_chunks = M.n_chunks;
+    t.n_hits = *n_hits;
+  }
+  if (*n_hits > cap) {
+    ac->err = "output buffer too small";
+    return AHA_E_CAPACITY;
+  }
+  return AHA_OK;
+}
+
+int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets,
+                           uint64_t n_docs, const aha_match_params *params, aha_hit *out,
+                           uint64_t cap, uint64_t *doc_hit_offsets, uint64_t *n_hits) {
+  if (!ac || !doc_offsets || !n_hits) return AHA_E_INVALID;
+  if (ac->device < 0) {
+    ac->err = aha_strerror(AHA_E_NO_DEVICE);
+    return AHA_E_NO_DEVICE;
+  }
+  if (doc_offsets[0] != 0) return AHA_E_INVALID;
+  for (uint64_t d = 0; d < n_docs; d++) {
+    if (doc_offsets[d + 1] < doc_offsets[d]) return AHA_E_INVALID;
+    if (doc_offsets[d + 1] - doc_offsets[d] >= 0x7FFFFFFFull) return AHA_E_TOO_LONG;
+  }
+  const uint64_t n_bytes = doc_offsets[n_docs];
+  if (n_bytes && !corpus) return AHA_E_INVALID;
+  if (cap && !out) return AHA_E_INVALID;
+  DeviceGuard g(ac->device);
+  uint8_t *d_corpus = nullptr;
+  uint64_t *d_doc = nullptr, *d_dho = nullptr;
+  aha_hit *d_out = nullptr;
+  int32_t rc = AHA_OK;
+  auto cleanup = [&]() {
+    if (d_corpus) (void)hipFree(d_corpus);
+    if (d_doc) (void)hipFree(d_doc);
+    if (d_dho) (void)hipFree(d_dho);
+    if (d_out) (void)hipFree(d_out);
+  };
+#define HIPCHK2(call)                                                  \
+  do {                                                                 \
+    hipError_t e_ = (call);                                            \
+    if (e_ != hipSuccess) {                                            \
+      ac->err = std::string(#call) + ": " + hipGetErrorString(e_);     \
+      cleanup();                                                       \
+      return AHA_E_HIP;                                                \
+    }                                                                  \
+  } while (0)
+  HIPCHK2(hipMalloc((void **)&d_corpus, n_bytes + 64));
+  HIPCHK2(hipMalloc((void **)&d_doc, (n_docs + 1) * sizeof(uint64_t)));
+  HIPCHK2(hipMalloc((void **)&d_dho, (n_docs + 1) * sizeof(uint64_t)));
+  if (cap) HIPCHK2(hipMalloc((void **)&d_out, cap * sizeof(aha_hit)));
+  if (n_bytes) HIPCHK2(hipMemcpy(d_corpus, corpus, n_bytes, hipMemcpyHostToDevice));
+  HIPCHK2(hipMemcpy(d_doc, doc_offsets, (n_docs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  rc = aha_ac_match_batch_device(ac, d_corpus, d_doc, n_docs, n_bytes, params, d_out, cap, d_dho,
+                                 n_hits, nullptr);
+  if (rc == AHA_OK || rc == AHA_E_CAPACITY) {
+    uint64_t n = std::min<uint64_t>(*n_hits, cap);
+    if (n) HIPCHK2(hipMemcpy(out, d_out, n * sizeof(aha_hit), hipMemcpyDeviceToHost));
+    if (doc_hit_offsets)
+      HIPCHK2(hipMemcpy(doc_hit_offsets, d_dho, (n_docs + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  cleanup();
+#undef HIPCHK2
+  return rc;
+}
+
+int32_t aha_ac_match_bytes(aha_ac *ac, const uint8_t *text, uint64_t n,
+                           const aha_match_params *params, aha_hit *out, uint64_t cap,
+                           uint64_t *n_hits) {
+  uint64_t offs[2] = {0, n};
+  return aha_ac_match_batch(ac, text, offs, 1, params, out, cap, nullptr, n_hits);
+}
+
+}  // extern "C"

@@ -1,0 +1,360 @@
+// kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for Aha::AC#match.
+//
+// Path replaced (reference, file:line):
+//   ACX#match_(Bytes)   src/aha/ac.cr:176-192   goto/fail traversal
+//   CedarX#child        src/aha/cedar.cr:441-447 base/check probe
+//   ACX#fetch           src/aha/ac.cr:265-278   output-chain emission
+//   MatchString#match   src/aha/matcher.cr:34-39 byte -> char offset remap
+//   ACX#match(seq,sep)  src/aha/ac.cr:321-340   separator-filtered emission
+//
+// Parallelisation: the corpus is cut into fixed-size chunks at absolute byte
+// positions.  A chunk's traversal starts at root (Lmax-1) bytes before the
+// chunk (clamped to the start of the enclosing document); after that warm-up
+// its state equals the sequential automaton's state exactly (the AC state is
+// the longest suffix that is a trie path, depth <= Lmax), so the reference's
+// non-textbook emission rule is reproduced bit for bit.  Hits are produced in
+// the reference's order by count -> scan -> ordered write.
+#include <hip/hip_runtime.h>
+
+#include "automaton.hpp"
+#include "image.hpp"
+
+namespace aha {
+
+// ---------------------------------------------------------------- automaton
+// One probe of the XOR double array.  B = base of the current state (its
+// identity), b != 0.  Returns true when the byte was consumed.
+template <bool COMPACT>
+struct Probe;
+
+template <>
+struct Probe<false> {
+  // returns: 0 = miss, 1 = hit, 2 = hit on an end state (key set)
+  static __device__ __forceinline__ int go(const DevAut &A, uint32_t &B, uint32_t b, uint32_t &key) {
+    const uint2 *slots = reinterpret_cast<const uint2 *>(A.slots);
+    uint2 e = slots[B ^ b];
+    if ((e.y & 0xFFu) == b) {
+      B = e.x & W_BASE_MASK;
+      if (e.x & W_END) {
+        key = e.y >> 8;
+        return 2;
+      }
+      return 1;
+    }
+    return 0;
+  }
+  static __device__ __forceinline__ uint32_t fail(const DevAut &A, uint32_t B) {
+    return reinterpret_cast<const uint2 *>(A.slots)[B].x & W_BASE_MASK;
+  }
+};
+
+template <>
+struct Probe<true> {
+  static __device__ __forceinline__ int go(const DevAut &A, uint32_t &B, uint32_t b, uint32_t &key) {
+    const uint32_t *slots = reinterpret_cast<const uint32_t *>(A.slots);
+    uint32_t e = slots[B ^ b];
+    if ((e & 0xFFu) == b) {
+      B = (e >> C_BASE_SHIFT) & C_BASE_MASK;
+      if (e & C_END) {
+        key = (uint32_t)A.end_key[B];
+        return 2;
+      }
+      return 1;
+    }
+    return 0;
+  }
+  static __device__ __forceinline__ uint32_t fail(const DevAut &A, uint32_t B) {
+    return (reinterpret_cast<const uint32_t *>(A.slots)[B] >> C_BASE_SHIFT) & C_BASE_MASK;
+  }
+};
+
+// delta(B, b): goto/fail loop of match_ (ac.cr:179-190).  Returns true when
+// the new state ends a key (is_end?, cedar.cr:657-660 <=> output.value >= 0).
+template <bool COMPACT>
+__device__ __forceinline__ bool aut_step(const DevAut &A, uint32_t &B, uint32_t b, uint32_t &key) {
+  if (b == 0) {  // NUL contract: state := root, nothing reported
+    B = A.root;
+    return false;
+  }
+  for (;;) {
+    int r = Probe<COMPACT>::go(A, B, b, key);
+    if (r) return r == 2;
+    if (B == A.root) return false;
+    B = Probe<COMPACT>::fail(A, B);
+  }
+}
+
+__device__ __forceinline__ bool sep_blocked(const MatchArgs &M, uint32_t c) {
+  return (M.sep_block[c >> 5] >> (c & 31)) & 1u;
+}
+
+// first d in [0, D] with doc_off[d] >= a
+__device__ __forceinline__ uint64_t first_boundary(const uint64_t *doc_off, uint64_t D, uint64_t a) {
+  uint64_t lo = 0, hi = D;  // doc_off[D] = N >= a
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (doc_off[mid] < a)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------ block helpers
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// exclusive scan over the block's kBlock threads; total returned via *total
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *smem /*[kBlock/64]*/, T *total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  T inc = wave_incl_scan(v);
+  if (lane == 63) smem[w] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kBlock / 64; i++) {
+    T s = smem[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return base + inc - v;
+}
+
+// ------------------------------------------------------------- count kernel
+// Pass 1: per-chunk number of hits (and UTF-8 lead bytes in chars mode).
+template <bool COMPACT>
+__global__ __launch_bounds__(kBlock) void k_count(DevAut A, MatchArgs M) {
+  __shared__ uint64_t sm[kBlock / 64];
+  const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  uint32_t hits = 0, leads = 0;
+  if (c < M.n_chunks) {
+    const uint64_t N = M.n_bytes, D = M.n_docs;
+    const uint64_t a = c * M.chunk;
+    const uint64_t e = min(a + M.chunk, N);
+    uint64_t dn = first_boundary(M.doc_off, D, a);
+    uint64_t nb = M.doc_off[dn];
+    uint64_t doc_start = a;
+    uint32_t B = A.root, key = 0;
+    if (nb != a) {
+      doc_start = M.doc_off[dn - 1];
+      uint64_t back = min<uint64_t>(a - doc_start, (uint64_t)(A.max_len ? A.max_len - 1 : 0));
+      for (uint64_t p = a - back; p < a; p++) aut_step<COMPACT>(A, B, M.text[p], key);
+    }
+    for (uint64_t p = a; p < e; p++) {
+      if (p == nb) {
+        do {
+          dn++;
+          nb = dn <= D ? M.doc_off[dn] : ~0ull;
+        } while (nb == p);
+        B = A.root;
+        doc_start = p;
+      }
+      const uint32_t b = M.text[p];
+      if (M.chars) leads += (b & 0xC0u) != 0x80u;
+      if (aut_step<COMPACT>(A, B, b, key)) {
+        if (!M.sep) {
+          hits += A.key_cnt[key];
+        } else {
+          // match(seq, sep): right neighbour of the end position (ac.cr:324-329)
+          if (p + 1 < nb && sep_blocked(M, M.text[p + 1])) continue;
+          int32_t k = (int32_t)key;
+          do {
+            uint2 ln = A.key_ln[k];
+            uint64_t s = p + 1 - ln.x;  // absolute start
+            // left neighbour of the hit (ac.cr:331-336)
+            if (!(s > doc_start && sep_blocked(M, M.text[s - 1]))) hits++;
+            k = (int32_t)ln.y;
+          } while (k >= 0);
+        }
+      }
+    }
+    M.counts[c] = hits;
+    if (M.chars) M.leads[c] = leads;
+  }
+  // block sums for the scan
+  uint64_t tot;
+  block_excl_scan<uint64_t>(hits, sm, &tot);
+  if (threadIdx.x == 0) M.blk_hits[blockIdx.x] = tot;
+  if (M.chars) {
+    block_excl_scan<uint64_t>(leads, sm, &tot);
+    if (threadIdx.x == 0) M.blk_leads[blockIdx.x] = tot;
+  }
+}
+
+// -------------------------------------------------------------- scan kernel
+// Exclusive scan of the per-block sums, in place; one workgroup walks the
+// array tile by tile with a running carry.  totals[0] = hits, totals[1] = leads.
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint64_t *blk_hits, uint64_t *blk_leads,
+                                                      uint64_t n, uint64_t *totals) {
+  __shared__ uint64_t sm[16];
+  uint64_t *arrs[2] = {blk_hits, blk_leads};
+  for (int which = 0; which < 2; which++) {
+    uint64_t *arr = arrs[which];
+    if (!arr) continue;
+    uint64_t carry = 0;
+    for (uint64_t t0 = 0; t0 < n; t0 += 1024) {
+      uint64_t i = t0 + threadIdx.x;
+      uint64_t v = i < n ? arr[i] : 0;
+      // block scan over 1024 threads = 16 waves
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      uint64_t inc = wave_incl_scan(v);
+      if (lane == 63) sm[w] = inc;
+      __syncthreads();
+      uint64_t base = 0, tot = 0;
+      for (int k = 0; k < 16; k++) {
+        uint64_t s = sm[k];
+        if (k < w) base += s;
+        tot += s;
+      }
+      if (i < n) arr[i] = carry + base + inc - v;
+      __syncthreads();  // sm is rewritten by the next tile
+      carry += tot;
+    }
+    if (threadIdx.x == 0) totals[which] = carry;
+  }
+}
+
+// -------------------------------------------------------------- docg kernel
+// chars mode: absolute lead-byte count at the start of every document, so the
+// write pass can turn absolute counts into per-document char offsets
+// (char_map, matcher.cr:14-22, without the 4-bytes-per-input-byte array).
+__global__ void k_docg(MatchArgs M) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d > M.n_docs) return;
+  const uint64_t q = M.doc_off[d];
+  if (q >= M.n_bytes) {
+    M.docg[d] = M.totals[1];
+    return;
+  }
+  const uint64_t c = q / M.chunk;
+  uint64_t g = M.blk_leads[c / kBlock];
+  for (uint64_t cc = (c / kBlock) * kBlock; cc < c; cc++) g += M.leads[cc];
+  for (uint64_t p = c * M.chunk; p < q; p++) g += (M.text[p] & 0xC0u) != 0x80u;
+  M.docg[d] = g;
+}
+
+// -------------------------------------------------------------- write kernel
+// Pass 2: same traversal, hits written at their final position.
+template <bool COMPACT>
+__global__ __launch_bounds__(kBlock) void k_write(DevAut A, MatchArgs M) {
+  __shared__ uint64_t sm[kBlock / 64];
+  const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = c < M.n_chunks;
+  uint64_t idx = M.blk_hits[blockIdx.x] +
+                 block_excl_scan<uint64_t>(live ? M.counts[c] : 0u, sm, nullptr);
+  uint64_t lead_abs = 0;
+  if (M.chars)
+    lead_abs = M.blk_leads[blockIdx.x] +
+               block_excl_scan<uint64_t>(live ? M.leads[c] : 0u, sm, nullptr);
+  if (!live) return;
+
+  const uint64_t N = M.n_bytes, D = M.n_docs;
+  const uint64_t a = c * M.chunk;
+  const uint64_t e = min(a + M.chunk, N);
+  uint64_t dn = first_boundary(M.doc_off, D, a);
+  uint64_t nb = M.doc_off[dn];
+  uint64_t doc_start = a;
+  uint64_t doc_lead0 = 0;
+  uint32_t B = A.root, key = 0;
+  if (nb != a) {
+    doc_start = M.doc_off[dn - 1];
+    if (M.chars) doc_lead0 = M.docg[dn - 1];
+    uint64_t back = min<uint64_t>(a - doc_start, (uint64_t)(A.max_len ? A.max_len - 1 : 0));
+    for (uint64_t p = a - back; p < a; p++) aut_step<COMPACT>(A, B, M.text[p], key);
+  }
+  for (uint64_t p = a; p < e; p++) {
+    if (p == nb) {
+      do {
+        if (M.doc_hit_off) M.doc_hit_off[dn] = idx;
+        dn++;
+        nb = dn <= D ? M.doc_off[dn] : ~0ull;
+      } while (nb == p);
+      B = A.root;
+      doc_start = p;
+      doc_lead0 = lead_abs;
+    }
+    const uint32_t b = M.text[p];
+    if (M.chars) lead_abs += (b & 0xC0u) != 0x80u;
+    if (aut_step<COMPACT>(A, B, b, key)) {
+      if (M.sep && p + 1 < nb && sep_blocked(M, M.text[p + 1])) continue;
+      const int32_t end_b = (int32_t)(p - doc_start) + 1;
+      int32_t k = (int32_t)key;
+      do {
+        uint2 ln = A.key_ln[k];
+        const int32_t start_b = end_b - (int32_t)ln.x;
+        if (!(M.sep && start_b > 0 && sep_blocked(M, M.text[doc_start + start_b - 1]))) {
+          if (idx < M.cap) {
+            aha_hit h;
+            if (M.chars) {
+              // end_char = #lead bytes in doc[0,end); start_char = end_char - kc - 1
+              const int32_t end_c = (int32_t)(lead_abs - doc_lead0);
+              h.start = end_c - (int32_t)A.key_kc[k] - 1;
+              h.end = end_c;
+            } else {
+              h.start = start_b;
+              h.end = end_b;
+            }
+            h.value = k;
+            M.out[idx] = h;
+          }
+          idx++;
+        }
+        k = (int32_t)ln.y;
+      } while (k >= 0);
+    }
+  }
+  if (e == N && M.doc_hit_off) {
+    // documents that start at N (empty tail documents) and the final total
+    while (dn <= D) {
+      M.doc_hit_off[dn] = idx;
+      dn++;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- launchers
+static inline uint32_t blocks_for(uint64_t n_chunks) {
+  return (uint32_t)((n_chunks + kBlock - 1) / kBlock);
+}
+
+void launch_count(const DevAut &A, const MatchArgs &M, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t g = blocks_for(M.n_chunks);
+  if (A.compact)
+    hipLaunchKernelGGL(k_count<true>, dim3(g), dim3(kBlock), 0, s, A, M);
+  else
+    hipLaunchKernelGGL(k_count<false>, dim3(g), dim3(kBlock), 0, s, A, M);
+}
+
+void launch_scan_blocks(const MatchArgs &M, uint64_t n_blocks, void *stream) {
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, (hipStream_t)stream, M.blk_hits,
+                     M.chars ? M.blk_leads : nullptr, n_blocks, M.totals);
+}
+
+void launch_docg(const MatchArgs &M, void *stream) {
+  uint64_t n = M.n_docs + 1;
+  hipLaunchKernelGGL(k_docg, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M);
+}
+
+void launch_write(const DevAut &A, const MatchArgs &M, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t g = blocks_for(M.n_chunks);
+  if (A.compact)
+    hipLaunchKernelGGL(k_write<true>, dim3(g), dim3(kBlock), 0, s, A, M);
+  else
+    hipLaunchKernelGGL(k_write<false>, dim3(g), dim3(kBlock), 0, s, A, M);
+}
+
+}  // namespace aha

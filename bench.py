@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native Aha::AC#match path.
+
+Metric (BASELINE.json): input GB/s scanned + M-hits/s, 100k-pattern
+Aho-Corasick over a 1 GiB UTF-8 corpus (config 3: "100k patterns, 1 GiB
+synthetic UTF-8 corpus, 1xMI355X").  A "step" is one pass of the hot path
+(aha_ac_match_batch_device: corpus and automaton resident in HBM -> ordered
+hit triples + per-document offsets final in HBM) over one batch.
+
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scans
+its own 1 GiB corpus (config 4: seed + rank; weak scaling, documents never
+span ranks) and the hit buffers are exchanged with an all-gatherv over
+RCCL/xGMI (aha_amd/distributed.py).  value = bytes scanned by all ranks / max
+over ranks of the timed region.
+
+One JSON line is printed by rank 0; it carries `roofline` (dominant kernel,
+HIP-event timed inside the library on the launch stream) and `cpu_baseline`
+(the C oracle -- a restatement of the reference's CPU path -- timed on this
+box's host cores on a bounded sample, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5], help="BASELINE.json config (3 = headline)")
+    ap.add_argument("--bytes", type=int, default=None, help="override corpus bytes per GPU")
+    ap.add_argument("--keys", type=int, default=None, help="override number of keys")
+    ap.add_argument("--chars", action="store_true", help="String overload (char offsets)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
+    ap.add_argument("--gather", default="allgatherv", choices=["allgatherv", "none"],
+                    help="N>1: exchange hit buffers over RCCL inside the timed step")
+    ap.add_argument("--force-wide", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(blob, offs, corpus, doc, gpu_hits, gpu_dho, seconds, log):
+    """Times the oracle (C restatement of ac.cr:176-192,265-286 over reference-layout
+    arrays) on a prefix of the documents; also checks the GPU hits on that prefix."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc  # checker / reported baseline only
+
+    t0 = time.time()
+    o = orc.AC.compile_packed(blob, offs)
+    t_compile = time.time() - t0
+    D = doc.size - 1
+    done_docs, done_bytes, t_match, n_hits = 0, 0, 0.0, 0
+    exact = True
+    step = max(1, D // 64)
+    while done_docs < D and t_match < seconds:
+        d1 = min(D, done_docs + step)
+        sub = doc[done_docs:d1 + 1] - doc[done_docs]
+        seg = corpus[int(doc[done_docs]):int(doc[d1])]
+        t0 = time.time()
+        oh, od = o.match_batch(seg, sub, cap=max(1024, seg.size // 4))
+        t_match += time.time() - t0
+        if gpu_hits is not None:
+            a, b = int(gpu_dho[done_docs]), int(gpu_dho[d1])
+            exact = exact and (b - a == len(oh)) and gpu_hits[a:b].tobytes() == oh.tobytes()
+            exact = exact and np.array_equal(gpu_dho[done_docs:d1 + 1] - gpu_dho[done_docs], od)
+        n_hits += len(oh)
+        done_bytes += seg.size
+        done_docs = d1
+    log(f"cpu baseline: {done_bytes / 1e6:.1f} MB in {t_match:.2f}s, {n_hits} hits, compile {t_compile:.2f}s")
+    return {
+        "value": round(done_bytes / t_match / 1e9, 4),
+        "unit": "GB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {done_docs} of {D} documents ({done_bytes} bytes) of the same corpus, 1 thread, "
+                  f"C restatement of the reference CPU path (oracle/aha_oracle.c), Bytes overload",
+        "m_hits_per_s": round(n_hits / t_match / 1e6, 3),
+        "parity_on_sample": "bit-exact" if exact else "MISMATCH",
+    }, exact
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    from aha_amd import AC, AhaError, synth
+    from aha_amd import _native as N
+
+    cfg = args.config
+    t0 = time.time()
+    blob, offs, nf = synth.keys(cfg, K=args.keys)
+    K = offs.size - 1
+    n_bytes = args.bytes if args.bytes else synth.DEFAULT_BYTES[cfg]
+    corpus, doc = synth.corpus(cfg, blob, offs, nf, n_bytes=n_bytes, rank=rank)
+    D = doc.size - 1
+    log(f"generated cfg{cfg}: {K} keys, {n_bytes} bytes, {D} docs in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    ac = AC.compile_packed(blob, offs, device=local_rank, force_wide=args.force_wide)
+    info = ac.info
+    log(f"compiled in {time.time() - t0:.2f}s: {info}")
+    ac.set_profiling(True)
+
+    t0 = time.time()
+    d_corpus = torch.from_numpy(corpus).to(dev)
+    d_doc = torch.from_numpy(doc.astype(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    t_upload = time.time() - t0
+    d_dho = torch.zeros(D + 1, dtype=torch.int64, device=dev)
+    # size the hit buffer with one untimed call
+    try:
+        n_hits = ac.match_batch_device(d_corpus, d_doc, torch.zeros((1, 3), dtype=torch.int32, device=dev), d_dho,
+                                       chars=args.chars)
+    except AhaError as e:
+        if e.code != N.AHA_E_CAPACITY:
+            raise
+        n_hits = e.required
+    d_out = torch.zeros((n_hits + 1024, 3), dtype=torch.int32, device=dev)
+    log(f"{n_hits} hits per pass ({n_hits / n_bytes:.4f} per byte); upload {t_upload:.2f}s "
+        f"({n_bytes / t_upload / 1e9:.1f} GB/s PCIe-inclusive)")
+
+    gather = None
+    if world > 1 and args.gather == "allgatherv":
+        from aha_amd.distributed import HitGatherer
+
+        gather = HitGatherer(dist, dev)
+
+    def step():
+        n = ac.match_batch_device(d_corpus, d_doc, d_out, d_dho, chars=args.chars)
+        if gather is not None:
+            gather.all_gatherv(d_out, n)
+        return n
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kern = {"ms_total": [], "ms_count": [], "ms_scan": [], "ms_write": [], "ms_aux": []}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        t = ac.last_timing()
+        for k in kern:
+            kern[k].append(t[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot_bytes = torch.tensor([float(n_bytes)], dtype=torch.float64, device=dev)
+    tot_hits = torch.tensor([float(n_hits)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot_bytes)
+        dist.all_reduce(tot_hits)
+    elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    gbs = float(tot_bytes.item()) * args.steps / elapsed / 1e9
+    mhits = float(tot_hits.item()) * args.steps / elapsed / 1e6
+
+    # roofline of the dominant kernel (HIP events inside the library, launch stream)
+    avg = {k: float(np.mean(v)) for k, v in kern.items()}
+    dom = "write" if avg["ms_write"] >= avg["ms_count"] else "count"
+    A = info["image_bytes"]
+    if dom == "write":  # reads the corpus + automaton, writes the ordered hits and doc offsets
+        alg_bytes = n_bytes + 12 * n_hits + 8 * (D + 1) + 8 * (D + 1) + A
+    else:  # count pass: corpus + automaton in, per-chunk counts out
+        alg_bytes = n_bytes + 8 * (D + 1) + A
+    dom_ms = avg[f"ms_{dom}"]
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "alg_bytes_per_launch": int(alg_bytes), "avg_ms": round(dom_ms, 4),
+        "whole_path_frac": round((n_bytes + 12 * n_hits + 16 * (D + 1) + A) / (avg["ms_total"] * 1e-3) / 1e9
+                                 / HBM_PEAK_GBS, 4),
+        "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
+    }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        hits_h = d_out[:n_hits].cpu().numpy().view(np.dtype([("start", "<i4"), ("end", "<i4"), ("value", "<i4")])).reshape(-1)
+        dho_h = d_dho.cpu().numpy().astype(np.uint64)
+        if args.chars:
+            hits_h = None
+        cpu, exact = cpu_baseline(blob, offs, corpus, doc, hits_h, dho_h, args.cpu_seconds, log)
+        if not exact:
+            log("PARITY MISMATCH against the oracle on the sampled documents")
+
+    if rank == 0:
+        line = {
+            "metric": "input GB/s scanned + M-hits/s, 100k-pattern AC over 1 GiB UTF-8 corpus",
+            "value": round(gbs, 3), "unit": "GB/s", "m_hits_per_s": round(mhits, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"cfg{cfg if world == 1 else 4}: {K} patterns, {n_bytes} B synthetic "
+                                   f"{'UTF-8' if cfg != 2 else 'ASCII'} corpus per GPU, {D} docs",
+                       "keys": K, "bytes_per_gpu": n_bytes, "docs_per_gpu": D, "hits_per_gpu": n_hits,
+                       "slots": info["n_slots"], "slot_bytes": info["slot_bytes"], "max_key_len": info["max_key_len"],
+                       "offsets": "chars" if args.chars else "bytes",
+                       "parallelism": f"doc-sharded x{world}" + (f" + {args.gather}" if world > 1 else "")},
+            "roofline": roofline,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line, ensure_ascii=False), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+/*
+ * aha_hip.h -- C ABI of libaha_hip.so: MI355X-native Aha::AC#match.
+ *
+ * Drop-in boundary for ONE path of chenkovsky/aha: batch Aho-Corasick
+ * traversal (Aha::AC.compile / #match / Aha::Hit).  The reference has no FFI
+ * of its own (pure Crystal); these entry points are what a Crystal
+ * `lib LibAhaHip` binding calls (bindings/crystal/aha_hip.cr).
+ * Citations are file:line relative to the reference repository root.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no exceptions across the
+ * boundary.  Every function returns an int32 status (AHA_OK = 0, <0 error)
+ * unless stated.  The caller owns every buffer it passes; the library never
+ * retains caller pointers past return.  A handle is immutable after compile;
+ * concurrent match calls on one handle are serialised internally.
+ */
+#ifndef AHA_HIP_H
+#define AHA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AHA_ABI_VERSION 1
+
+/* Aha::Hit -- src/aha/matcher.cr:2-11.  Half-open [start,end) offsets
+ * relative to the start of the sequence (document); value = key index in
+ * compile order (src/aha/ac.cr:64-67). */
+typedef struct {
+  int32_t start, end, value;
+} aha_hit;
+
+typedef struct aha_ac aha_ac;
+
+enum {
+  AHA_OK = 0,
+  AHA_E_INVALID = -1,     /* bad argument */
+  AHA_E_EMPTY_KEY = -2,   /* raise "Cannot insert empty key"        src/aha/cedar.cr:756 */
+  AHA_E_ZERO_BYTE = -3,   /* raise "key[pos] is zero"               src/aha/cedar.cr:235 */
+  AHA_E_DUP_KEY = -4,     /* raise "key:... appear twice."          src/aha/ac.cr:66     */
+  AHA_E_SEP_SIZE = -5,    /* raise "sep BitArray size > 256 ..."    src/aha/ac.cr:322    */
+  AHA_E_CAPACITY = -6,    /* out buffer too small; *n_hits = required count */
+  AHA_E_NO_DEVICE = -7,   /* no usable HIP device: the product path has NO CPU fallback */
+  AHA_E_HIP = -8,         /* a HIP runtime call failed; see aha_last_error */
+  AHA_E_TOO_LONG = -9,    /* a sequence is >= 2^31 bytes (Int32 offsets, src/aha/matcher.cr:3-5) */
+  AHA_E_NOT_FOUND = -10,  /* key / id lookup miss (IndexError in the reference, src/aha/cedar.cr:830-834) */
+  AHA_E_TOO_LARGE = -11   /* automaton exceeds the device image limits */
+};
+
+/* Compile-time options.  Zero-initialise and set struct_size. */
+typedef struct {
+  uint32_t struct_size;
+  int32_t device;        /* HIP device ordinal; -1 = current device */
+  uint32_t flags;        /* AHA_OPT_* */
+  uint32_t reserved;
+} aha_options;
+
+#define AHA_OPT_HOST_ONLY 1u /* build the automaton image but do not touch the GPU (tests of host logic) */
+#define AHA_OPT_FORCE_WIDE 2u /* always use the 8-byte slot format (default: compact 4-byte when it fits) */
+
+/* Per-call options mirroring the reference's overloads:
+ *   char_offsets = 0: match(seq : Bytes)        src/aha/ac.cr:280-286  (byte offsets)
+ *   char_offsets = 1: match(seq : String)       src/aha/matcher.cr:34-39 (char offsets; valid UTF-8)
+ *   sep_size > 0    : match(seq, sep : BitArray) src/aha/ac.cr:321-340, matcher.cr:41-46;
+ *                     sep_bits is the BitArray, LSB-first, sep_size <= 256. */
+typedef struct {
+  uint32_t struct_size;
+  int32_t char_offsets;
+  int32_t sep_size;
+  uint8_t sep_bits[32];
+} aha_match_params;
+
+typedef struct {
+  uint32_t struct_size;
+  uint32_t n_keys;          /* K */
+  uint64_t n_states;        /* trie nodes incl. root */
+  uint64_t n_slots;         /* double-array slots in the device image */
+  uint64_t image_bytes;     /* bytes resident in HBM for the automaton */
+  uint32_t max_key_len;     /* Lmax, bytes */
+  uint32_t slot_bytes;      /* 4 (compact) or 8 (wide) */
+  uint32_t lds_slots;       /* slots of the image cached in LDS by the match kernel */
+  int32_t device;           /* device the image lives on, -1 if host only */
+} aha_ac_info_t;
+
+/* Timing of the most recent device match on this handle (HIP events recorded
+ * on the launch stream).  Only filled when profiling is enabled. */
+typedef struct {
+  uint32_t struct_size;
+  uint32_t n_kernels;
+  float ms_total;           /* first launch -> hits and offsets final in HBM */
+  float ms_count;           /* traversal pass 1 (count) */
+  float ms_scan;            /* scans of per-chunk counts */
+  float ms_write;           /* traversal pass 2 (ordered write) */
+  float ms_aux;             /* char-offset prefix pass etc. */
+  uint64_t n_chunks;
+  uint64_t n_hits;
+} aha_timing;
+
+const char *aha_strerror(int32_t code);
+/* Message of the last error on this handle (thread-unsafe snapshot). */
+const char *aha_last_error(const aha_ac *ac);
+uint32_t aha_abi_version(void);
+/* Number of visible HIP devices (0 when there is none / no driver). */
+int32_t aha_device_count(void);
+
+/* Aha::AC.compile(keys) -- src/aha/ac.cr:62-112.  Keys are one blob plus K+1
+ * offsets.  On AHA_E_EMPTY_KEY / ZERO_BYTE / DUP_KEY *err_key (optional) is
+ * the index of the offending key (the index at which the reference raises). */
+int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, uint32_t n_keys,
+                       const aha_options *opts, aha_ac **out, uint32_t *err_key);
+void aha_ac_free(aha_ac *ac);
+int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info);
+
+/* AC#[](sid : Int) : String and AC#[](key) : Int -- delegated to the trie in
+ * the reference (src/aha/ac.cr:41-43, src/aha/cedar.cr:747-749, 817-834).
+ * aha_ac_key returns the key length (copies min(len,cap) bytes) or <0. */
+int32_t aha_ac_key(const aha_ac *ac, int32_t id, uint8_t *buf, int32_t cap);
+int32_t aha_ac_id(const aha_ac *ac, const uint8_t *key, int32_t len);
+
+/* AC#match on ONE sequence held in host memory (uploads, matches on the GPU,
+ * downloads).  Hits come back in the reference's order: ascending end
+ * position, and per position own key first, then the output chain
+ * (src/aha/ac.cr:176-192, 265-278).  params may be NULL (plain byte match). */
+int32_t aha_ac_match_bytes(aha_ac *ac, const uint8_t *text, uint64_t n,
+                           const aha_match_params *params, aha_hit *out, uint64_t cap,
+                           uint64_t *n_hits);
+
+/* Batch entry (new; the reference is one-sequence-per-call): D documents,
+ * document d = corpus[doc_offsets[d] .. doc_offsets[d+1]); doc_offsets[0]
+ * must be 0.  Equivalent to D independent #match calls concatenated;
+ * doc_hit_offsets (D+1 entries, optional) delimits each document's hits. */
+int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets,
+                           uint64_t n_docs, const aha_match_params *params, aha_hit *out,
+                           uint64_t cap, uint64_t *doc_hit_offsets, uint64_t *n_hits);
+
+/* Device-resident variant: every pointer prefixed d_ is HBM on the handle's
+ * device; nothing crosses PCIe except the 8-byte hit count.  `stream` is a
+ * hipStream_t (NULL = default stream).  Blocks until the hits are final.
+ * On AHA_E_CAPACITY the first `cap` hits and all offsets are still valid. */
+int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
+                                  const uint64_t *d_doc_offsets, uint64_t n_docs,
+                                  uint64_t n_bytes, const aha_match_params *params,
+                                  aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets,
+                                  uint64_t *n_hits, void *stream);
+
+/* Copies one array of the automaton image (as uploaded to HBM) into buf;
+ * returns its size in bytes (call with cap_bytes = 0 to size the buffer).
+ * Data only -- used by host-logic tests and debugging tools. */
+enum {
+  AHA_IMG_SLOTS = 0,   /* uint32[n_slots] (compact) or uint64[n_slots] (wide) */
+  AHA_IMG_END_KEY = 1, /* int32[n_slots], compact only */
+  AHA_IMG_KEY_LN = 2,  /* {uint32 len, int32 next}[K] */
+  AHA_IMG_KEY_CNT = 3, /* uint32[K] */
+  AHA_IMG_KEY_KC = 4   /* uint32[K] */
+};
+int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_bytes);
+
+/* Enable/disable HIP-event timing of device matches on this handle. */
+int32_t aha_ac_set_profiling(aha_ac *ac, int32_t enabled);
+int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AHA_HIP_H */

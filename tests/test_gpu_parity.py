@@ -1,0 +1,212 @@
+"""GPU parity tests: the HIP path (through the C ABI of libaha_hip.so) against
+the CPU oracle on the same inputs -- bit-exact hit triples in the same order.
+Reads like spec/ac_spec.cr; run with `pytest -m gpu` on an MI355X."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pyoracle as orc
+from aha_amd import AC, AhaError, BitArray, Hit, synth
+from aha_amd import _native as N
+from pymodel import ModelAC
+from test_oracle_vs_model import as_list, rand_keys
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+KATS = json.load(open(os.path.join(G, "reference_kats.json"), encoding="utf-8"))
+
+
+def gpu_list(h):
+    return [tuple(int(v) for v in x) for x in h.tolist()]
+
+
+# ---- the reference's own specs, run against the HIP path --------------------
+
+def test_spec_ac():  # spec/ac_spec.cr:5-12
+    matcher = AC.compile(["我", "我是", "是中"])
+    matched = [(hit.end, hit.value) for hit in matcher.match("我是中国人")]
+    assert matched == [(1, 0), (2, 1), (3, 2)]
+
+
+def test_spec_ac_with_sep():  # spec/ac_spec.cr:25-34
+    matcher = AC.compile(["a", "aa"])
+    sep = BitArray(256)
+    sep[ord(" ")] = True
+    matched = [(hit.end, hit.value) for hit in matcher.match("a aaa", sep)]
+    assert matched == [(1, 0)]
+
+
+def test_spec_ac_char_array():  # spec/ac_spec.cr:36-43
+    matcher = AC.compile(["我", "我是", "是中"])
+    matched = [(hit.end, hit.value) for hit in matcher.match(list("我是中国人"))]
+    assert matched == [(1, 0), (2, 1), (3, 2)]
+
+
+@pytest.mark.parametrize("kat", KATS["ac_match"], ids=lambda k: k["cite"][:24] + k["api"])
+def test_reference_kats(kat):
+    ac = AC.compile(kat["keys"])
+    sep = None
+    if kat["sep"]:
+        sep = BitArray(kat["sep"]["size"])
+        for b in kat["sep"]["set"]:
+            sep[b] = True
+    seq = list(kat["text"]) if kat["api"] == "chars" else kat["text"]
+    assert [[h.end, h.value] for h in ac.match(seq, sep)] == kat["expect_end_value"]
+
+
+def test_byte_level_triples():
+    ac = AC.compile(["我", "我是", "是中"])
+    assert list(ac.match("我是中国人".encode())) == [Hit(0, 3, 0), Hit(0, 6, 1), Hit(3, 9, 2)]
+    assert list(ac.match("我是中国人")) == [Hit(0, 1, 0), Hit(0, 2, 1), Hit(1, 3, 2)]
+
+
+# ---- derived semantics, both slot formats ----------------------
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_subset_semantics(wide):
+    assert list(AC.compile(["c", "abcd"], force_wide=wide).match(b"abc")) == []
+    assert gpu_list(AC.compile(["a", "aa"], force_wide=wide).match_array(b"aa")) == [(0, 1, 0), (0, 2, 1), (1, 2, 0)]
+    assert gpu_list(AC.compile(["xabc", "abc", "bcz", "c"], force_wide=wide).match_array(b"xabc")) == [(0, 4, 0), (1, 4, 1)]
+
+
+def test_nul_and_empty():
+    ac = AC.compile(["ab", "abc", "b"])
+    assert gpu_list(ac.match_array(b"ab\x00abc\x00b")) == [(0, 2, 0), (1, 2, 2), (3, 5, 0), (4, 5, 2), (3, 6, 1), (7, 8, 2)]
+    assert len(ac.match_array(b"")) == 0
+    hits, dho = ac.match_batch(b"", [0, 0, 0])
+    assert len(hits) == 0 and dho.tolist() == [0, 0, 0]
+
+
+def test_sep_size_error():
+    ac = AC.compile(["a"])
+    with pytest.raises(AhaError) as e:
+        list(ac.match(b"a", BitArray(257)))
+    assert e.value.code == N.AHA_E_SEP_SIZE
+    assert str(e.value) == "sep BitArray size > 256 is not supported"
+
+
+# ---- randomized parity vs the oracle ---------------------------------------
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("seed", range(6))
+def test_random_small_alphabet(seed, wide):
+    rng = random.Random(seed)
+    alphabet = [b"ab", b"abc", b"abcd\xe4\xb8"][seed % 3]
+    keys = rand_keys(rng, rng.randint(1, 60), alphabet, 1, 8)
+    # several chunks long: matches straddle chunk boundaries all the time
+    text = bytes(rng.choice(alphabet + (b"\x00" if seed % 2 else b"")) for _ in range(5000))
+    g = AC.compile(keys, force_wide=wide)
+    o = orc.AC.compile(keys)
+    assert gpu_list(g.match_array(text)) == as_list(o.match(text))
+    assert gpu_list(g.match_array(text)) == ModelAC(keys).match(text)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_batch_ragged_docs(seed):
+    rng = random.Random(100 + seed)
+    keys = rand_keys(rng, 200, b"abcde", 1, 9)
+    g = AC.compile(keys)
+    o = orc.AC.compile(keys)
+    docs = [bytes(rng.choice(b"abcde") for _ in range(rng.choice([0, 0, 1, 3, 50, 255, 256, 257, 1000, 5000])))
+            for _ in range(60)]
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+    corpus = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    gh, gd = g.match_batch(corpus, offs)
+    oh, od = o.match_batch(corpus, offs)
+    assert np.array_equal(gd, od)
+    assert gh.tobytes() == oh.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_utf8_chars_and_sep(seed):
+    rng = random.Random(200 + seed)
+    cps = [chr(c) for c in list(range(0x4E00, 0x4E30)) + list(range(97, 105)) + list(range(0x430, 0x438))] + [" "]
+    keys, seen = [], set()
+    while len(keys) < 150:
+        k = "".join(rng.choice(cps[:-1]) for _ in range(rng.randint(1, 4)))
+        if k not in seen:
+            seen.add(k)
+            keys.append(k)
+    text = "".join(rng.choice(cps) for _ in range(4000))
+    g = AC.compile(keys)
+    o = orc.AC.compile(keys)
+    assert gpu_list(g.match_array(text)) == as_list(o.match(text))
+    assert gpu_list(g.match_array(text.encode())) == as_list(o.match(text.encode()))
+    sep = BitArray(256)
+    sep[32] = True
+    assert gpu_list(g.match_array(text, sep)) == as_list(o.match(text, sep=(256, [32])))
+    sep = BitArray(100)
+    sep[32] = True
+    sep[97] = True
+    assert gpu_list(g.match_array(text.encode(), sep)) == as_list(o.match(text.encode(), sep=(100, [32, 97])))
+    # chars + batch: per-document char offsets
+    docs = [text[i:i + 333] for i in range(0, len(text), 333)]
+    enc = [d.encode() for d in docs]
+    offs = np.cumsum([0] + [len(d) for d in enc]).astype(np.uint64)
+    gh, gd = g.match_batch(np.frombuffer(b"".join(enc), dtype=np.uint8), offs, chars=True)
+    oh, od = o.match_batch(np.frombuffer(b"".join(enc), dtype=np.uint8), offs, chars=True)
+    assert np.array_equal(gd, od) and gh.tobytes() == oh.tobytes()
+
+
+def test_long_keys_grow_the_chunk():
+    rng = random.Random(7)
+    keys = [bytes(rng.choice(b"ab") for _ in range(n)) for n in (700, 300, 5, 2, 1)]
+    keys = list(dict.fromkeys(keys))
+    text = bytes(rng.choice(b"ab") for _ in range(3000)) + keys[0] + keys[1] + bytes(rng.choice(b"ab") for _ in range(3000))
+    assert gpu_list(AC.compile(keys).match_array(text)) == as_list(orc.AC.compile(keys).match(text))
+
+
+def test_capacity_error_reports_required():
+    import ctypes as C
+
+    ac = AC.compile(["a"])
+    t = np.frombuffer(b"a" * 1000, dtype=np.uint8)
+    out = np.zeros(10, dtype=orc.HIT_DTYPE)
+    n = C.c_uint64(0)
+    rc = N.lib().aha_ac_match_bytes(ac._h, t.ctypes.data, t.size, None, out.ctypes.data, 10, C.byref(n))
+    assert rc == N.AHA_E_CAPACITY and n.value == 1000
+    assert gpu_list(out) == [(i, i + 1, 0) for i in range(10)]
+
+
+# ---- the BASELINE configs at oracle-sized scale ------------------------------
+
+@pytest.mark.parametrize("cfg,K,nbytes,docb", [(2, 1000, 1 << 22, 1 << 16), (3, 100_000, 1 << 23, 1 << 18),
+                                                (5, 96_000, 1 << 21, 1 << 17)])
+def test_config_parity(cfg, K, nbytes, docb):
+    blob, offs, nf = synth.keys(cfg, K=K)
+    corpus, doc = synth.corpus(cfg, blob, offs, nf, n_bytes=nbytes, doc_bytes=docb)
+    g = AC.compile_packed(blob, offs)
+    o = orc.AC.compile_packed(blob, offs)
+    gh, gd = g.match_batch(corpus, doc)
+    oh, od = o.match_batch(corpus, doc, cap=len(gh) + 16)
+    assert len(gh) == len(oh) and np.array_equal(gd, od)
+    assert gh.tobytes() == oh.tobytes()
+    if cfg == 3:  # String overload on the headline shape
+        gh, gd = g.match_batch(corpus, doc, chars=True)
+        oh, od = o.match_batch(corpus, doc, chars=True, cap=len(gh) + 16)
+        assert gh.tobytes() == oh.tobytes() and np.array_equal(gd, od)
+
+
+def test_device_resident_entry_point():
+    import torch
+
+    blob, offs, nf = synth.keys(3, K=20_000)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 22, doc_bytes=1 << 16)
+    g = AC.compile_packed(blob, offs)
+    o = orc.AC.compile_packed(blob, offs)
+    oh, od = o.match_batch(corpus, doc)
+    dc = torch.from_numpy(corpus).cuda()
+    dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+    out = torch.zeros((len(oh) + 8, 3), dtype=torch.int32, device="cuda")
+    dho = torch.zeros(doc.size, dtype=torch.int64, device="cuda")
+    n = g.match_batch_device(dc, dd, out, dho)
+    assert n == len(oh)
+    assert out[:n].cpu().numpy().tobytes() == oh.tobytes()
+    assert np.array_equal(dho.cpu().numpy().astype(np.uint64), od)
+    small = torch.zeros((5, 3), dtype=torch.int32, device="cuda")
+    with pytest.raises(AhaError) as e:
+        g.match_batch_device(dc, dd, small)
+    assert e.value.code == N.AHA_E_CAPACITY and e.value.required == len(oh)

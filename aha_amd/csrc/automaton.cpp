@@ -321,7 +321,8 @@ bool encode_image(const Automaton &a, const Placement &p, bool force_wide, Image
     img.wide.assign(p.n_slots, 0);
     for (uint32_t s = 0; s < S; s++) {
       uint32_t b = p.base[s];
-      img.wide[b] = (uint64_t)p.base[a.fail[s]];  // header: label 0, lo = fail base
+      // header: label 0, lo = fail base | W_FAILROOT when the fail state's own fail is root
+      img.wide[b] = (uint64_t)(p.base[a.fail[s]] | (a.fail[a.fail[s]] == 0 ? W_FAILROOT : 0u));
       for (uint32_t j = 0; j < a.n_child[s]; j++) {
         uint32_t c = a.first_child[s] + j;
         uint8_t lab = a.in_label[c];
@@ -340,7 +341,8 @@ bool encode_image(const Automaton &a, const Placement &p, bool force_wide, Image
     img.end_key.assign(p.n_slots, -1);
     for (uint32_t s = 0; s < S; s++) {
       uint32_t b = p.base[s];
-      img.narrow[b] = p.base[a.fail[s]] << C_BASE_SHIFT;  // header: label 0
+      // header: label 0, fail base, C_FAILROOT when the fail state's own fail is root
+      img.narrow[b] = (p.base[a.fail[s]] << C_BASE_SHIFT) | (a.fail[a.fail[s]] == 0 ? C_FAILROOT : 0u);
       if (a.key_of[s] >= 0) img.end_key[b] = a.key_of[s];
       for (uint32_t j = 0; j < a.n_child[s]; j++) {
         uint32_t c = a.first_child[s] + j;

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -38,6 +39,16 @@ struct aha_ac {
   bool ev_ready = false;
   aha_timing last{};
   uint32_t chunk = 256;
+  // single-traversal engine (scan_v2.hip)
+  bool v2_ok = false;
+  uint32_t v2_lds_slots = 0;
+  uint32_t v2_grid = 0;
+  struct Buf {
+    void *p = nullptr;
+    size_t bytes = 0;
+  };
+  Buf v2buf[16];
+  unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
   std::string err;
 };
 
@@ -146,6 +157,128 @@ int32_t fill_params(aha_ac *ac, const aha_match_params *p, MatchArgs &M) {
   return AHA_OK;
 }
 
+// ---- single-traversal engine: sizing, scratch, orchestration ----------------
+constexpr size_t kLdsPerCU = 160 * 1024;
+
+void v2_setup(aha_ac *ac) {
+  const char *eng = getenv("AHA_ENGINE");
+  if (eng && strcmp(eng, "v1") == 0) return;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ac->device) != hipSuccess || cus <= 0)
+    return;
+  const size_t in_bytes = (size_t)(kV2Threads / 64) * 64 * kV2Piece;
+  const size_t slot = ac->compact ? 4 : 8;
+  size_t budget = (kLdsPerCU - in_bytes) / slot;
+  uint32_t T = (uint32_t)std::min<size_t>(budget, ac->n_slots);
+  T &= ~3u;  // copied into LDS as 16-byte vectors
+  if (v2_prepare(ac->compact, v2_lds_bytes(T, ac->compact)) != 0) return;
+  ac->v2_lds_slots = T;
+  ac->v2_grid = (uint32_t)cus;
+  ac->v2_ok = true;
+}
+
+int32_t v2_reserve(aha_ac *ac, int i, size_t bytes) {
+  aha_ac::Buf &b = ac->v2buf[i];
+  if (b.bytes >= bytes) return AHA_OK;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+  size_t want = bytes + bytes / 8 + 256;
+  HIPCHK(ac, hipMalloc(&b.p, want));
+  b.bytes = want;
+  return AHA_OK;
+}
+
+// returns AHA_OK, an error, or +1 when the caller must fall back to the two-pass engine
+int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
+  const uint64_t N = M1.n_bytes;
+  const uint32_t Lmax = ac->aut.max_key_len;
+  uint64_t s_min = std::max<uint64_t>(64, ((8ull * Lmax + 63) / 64) * 64);
+  if (s_min > kV2MaxS) return 1;
+  if (reinterpret_cast<uintptr_t>(M1.text) % 16 != 0) return 1;
+  uint64_t lanes = (uint64_t)ac->v2_grid * kV2Threads;
+  uint64_t S = ((N + lanes - 1) / lanes + 63) / 64 * 64;
+  S = std::min<uint64_t>(std::max<uint64_t>(S, s_min), kV2MaxS);
+  V2Args M{};
+  M.text = M1.text;
+  M.doc_off = M1.doc_off;
+  M.n_docs = M1.n_docs;
+  M.n_bytes = N;
+  M.S = (uint32_t)S;
+  M.n_chunks = (N + S - 1) / S;
+  if (M.n_chunks > 0xFFFFFFFFull) return 1;
+  M.lds_slots = ac->v2_lds_slots;
+  M.chars = M1.chars;
+  M.sep = M1.sep;
+  memcpy(M.sep_block, M1.sep_block, sizeof(M.sep_block));
+  M.out = M1.out;
+  M.cap = M1.cap;
+  M.doc_hit_off = M1.doc_hit_off;
+  const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
+  M.ev_cap = ((M1.cap + waves * kV2Slab + kV2Slab) / kV2Slab) * kV2Slab;
+  const uint64_t n_slabs = M.ev_cap / kV2Slab + 2;
+  const uint64_t n_blk = std::max<uint64_t>((M.n_chunks + 255) / 256, (M.ev_cap + 255) / 256) + 2;
+  int32_t rc;
+  size_t sizes[16] = {M.ev_cap * 16,      M.ev_cap * 16,      M.ev_cap * 4,     n_slabs * 4,
+                      M.n_chunks * 4,     (M.n_docs + 1) * 4, M.n_chunks * 8,   n_blk * 8,
+                      n_blk * 8,          5 * 8,              M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
+                      M.chars ? M.n_chunks * 4 : 0, M.chars ? M.n_chunks * 4 : 0, M.chars ? (M.n_docs + 1) * 4 : 0,
+                      M.chars ? M.n_chunks * 8 : 0};
+  for (int i = 0; i < 16; i++)
+    if (sizes[i] && (rc = v2_reserve(ac, i, sizes[i]))) return rc;
+  M.ev = (uint4 *)ac->v2buf[0].p;
+  M.sorted_ev = (uint4 *)ac->v2buf[1].p;
+  M.sorted_cnt = (uint32_t *)ac->v2buf[2].p;
+  M.slab_used = (uint32_t *)ac->v2buf[3].p;
+  M.ev_cnt = (uint32_t *)ac->v2buf[4].p;
+  M.doc_ev_rank = (uint32_t *)ac->v2buf[5].p;
+  M.ev_base = (uint64_t *)ac->v2buf[6].p;
+  M.blk_a = (uint64_t *)ac->v2buf[7].p;
+  M.blk_b = (uint64_t *)ac->v2buf[8].p;
+  M.cursor = (unsigned long long *)ac->v2buf[9].p;
+  M.totals = (uint64_t *)ac->v2buf[9].p + 2;
+  M.ev_aux = (uint32_t *)ac->v2buf[10].p;
+  M.sorted_aux = (uint32_t *)ac->v2buf[11].p;
+  M.lead_cnt = (uint32_t *)ac->v2buf[12].p;
+  M.chunk_doc0 = (uint32_t *)ac->v2buf[13].p;
+  M.doc_lead_rank = (uint32_t *)ac->v2buf[14].p;
+  M.lead_base = (uint64_t *)ac->v2buf[15].p;
+  if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+
+  const bool prof = ac->profiling && ac->ev_ready;
+  HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 5 * 8, s));
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
+  v2_launch_traverse(ac->dev, M, ac->v2_grid, s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
+  v2_launch_chunk_scan(M, s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
+  v2_launch_sort(ac->dev, M, M.ev_cap, s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[3], s));
+  v2_launch_expand(ac->dev, M, M.ev_cap, s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[4], s));
+  HIPCHK(ac, hipGetLastError());
+  HIPCHK(ac, hipMemcpyAsync(ac->h_v2, ac->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(ac, hipStreamSynchronize(s));
+  if (ac->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
+  *n_hits = ac->h_v2[2];
+  if (prof) {
+    aha_timing &t = ac->last;
+    memset(&t, 0, sizeof(t));
+    t.struct_size = sizeof(t);
+    t.engine = 2;
+    t.chunk_bytes = M.S;
+    t.n_kernels = 9;
+    (void)hipEventElapsedTime(&t.ms_total, ac->ev[0], ac->ev[4]);
+    (void)hipEventElapsedTime(&t.ms_count, ac->ev[0], ac->ev[1]);
+    (void)hipEventElapsedTime(&t.ms_scan, ac->ev[1], ac->ev[2]);
+    (void)hipEventElapsedTime(&t.ms_aux, ac->ev[2], ac->ev[3]);
+    (void)hipEventElapsedTime(&t.ms_write, ac->ev[3], ac->ev[4]);
+    t.n_chunks = M.n_chunks;
+    t.n_hits = *n_hits;
+  }
+  return AHA_OK;
+}
+
 struct DeviceGuard {
   int prev = -1;
   bool active = false;
@@ -236,6 +369,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
       aha_ac_free(ac);
       return rc;
     }
+    v2_setup(ac);
   }
   *out = ac;
   return AHA_OK;
@@ -250,6 +384,9 @@ void aha_ac_free(aha_ac *ac) {
     for (void *p : scratch)
       if (p) (void)hipFree(p);
     if (ac->h_totals) (void)hipHostFree(ac->h_totals);
+    for (auto &b : ac->v2buf)
+      if (b.p) (void)hipFree(b.p);
+    if (ac->h_v2) (void)hipHostFree(ac->h_v2);
     if (ac->ev_ready)
       for (auto &e : ac->ev) (void)hipEventDestroy(e);
   }
@@ -266,7 +403,7 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->image_bytes = ac->image_bytes;
   info->max_key_len = ac->aut.max_key_len;
   info->slot_bytes = ac->slot_bytes;
-  info->lds_slots = 0;
+  info->lds_slots = ac->v2_lds_slots;
   info->device = ac->device;
   return AHA_OK;
 }
@@ -378,6 +515,21 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
   M.doc_off = d_doc_offsets;
   M.n_docs = n_docs;
   M.n_bytes = n_bytes;
+  M.out = d_out;
+  M.cap = cap;
+  M.doc_hit_off = d_doc_hit_offsets;
+  if (ac->v2_ok) {
+    rc = match_v2(ac, M, s, n_hits);
+    if (rc < 0) return rc;
+    if (rc == AHA_OK) {
+      if (*n_hits > cap) {
+        ac->err = "output buffer too small";
+        return AHA_E_CAPACITY;
+      }
+      return AHA_OK;
+    }
+    *n_hits = 0;  // rc == 1: fall through to the two-pass engine
+  }
   M.chunk = ac->chunk;
   // warm-up is Lmax-1 bytes per chunk: keep it a small fraction of the chunk
   while (M.chunk < 8ull * ac->aut.max_key_len && M.chunk < (1u << 20)) M.chunk *= 2;
@@ -420,6 +572,8 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
     (void)hipEventElapsedTime(&t.ms_write, ac->ev[3], ac->ev[4]);
     t.n_chunks = M.n_chunks;
     t.n_hits = *n_hits;
+    t.engine = 1;
+    t.chunk_bytes = M.chunk;
   }
   if (*n_hits > cap) {
     ac->err = "output buffer too small";

@@ -1,0 +1,127 @@
+// devcommon.hpp -- device helpers shared by kernels.hip (two-pass engine) and
+// scan_v2.hip (single-traversal engine).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "automaton.hpp"
+#include "image.hpp"
+
+namespace aha {
+
+// ---------------------------------------------------------------- automaton
+// One probe of the XOR double array.  B = base of the current state (its
+// identity), b != 0.  Returns true when the byte was consumed.
+template <bool COMPACT>
+struct Probe;
+
+template <>
+struct Probe<false> {
+  // returns: 0 = miss, 1 = hit, 2 = hit on an end state (key set)
+  static __device__ __forceinline__ int go(const DevAut &A, uint32_t &B, uint32_t b, uint32_t &key) {
+    const uint2 *slots = reinterpret_cast<const uint2 *>(A.slots);
+    uint2 e = slots[B ^ b];
+    if ((e.y & 0xFFu) == b) {
+      B = e.x & W_BASE_MASK;
+      if (e.x & W_END) {
+        key = e.y >> 8;
+        return 2;
+      }
+      return 1;
+    }
+    return 0;
+  }
+  static __device__ __forceinline__ uint32_t fail(const DevAut &A, uint32_t B) {
+    return reinterpret_cast<const uint2 *>(A.slots)[B].x & W_BASE_MASK;
+  }
+};
+
+template <>
+struct Probe<true> {
+  static __device__ __forceinline__ int go(const DevAut &A, uint32_t &B, uint32_t b, uint32_t &key) {
+    const uint32_t *slots = reinterpret_cast<const uint32_t *>(A.slots);
+    uint32_t e = slots[B ^ b];
+    if ((e & 0xFFu) == b) {
+      B = (e >> C_BASE_SHIFT) & C_BASE_MASK;
+      if (e & C_END) {
+        key = (uint32_t)A.end_key[B];
+        return 2;
+      }
+      return 1;
+    }
+    return 0;
+  }
+  static __device__ __forceinline__ uint32_t fail(const DevAut &A, uint32_t B) {
+    return (reinterpret_cast<const uint32_t *>(A.slots)[B] >> C_BASE_SHIFT) & C_BASE_MASK;
+  }
+};
+
+// delta(B, b): goto/fail loop of match_ (ac.cr:179-190).  Returns true when
+// the new state ends a key (is_end?, cedar.cr:657-660 <=> output.value >= 0).
+template <bool COMPACT>
+__device__ __forceinline__ bool aut_step(const DevAut &A, uint32_t &B, uint32_t b, uint32_t &key) {
+  if (b == 0) {  // NUL contract: state := root, nothing reported
+    B = A.root;
+    return false;
+  }
+  for (;;) {
+    int r = Probe<COMPACT>::go(A, B, b, key);
+    if (r) return r == 2;
+    if (B == A.root) return false;
+    B = Probe<COMPACT>::fail(A, B);
+  }
+}
+
+__device__ __forceinline__ bool sep_blocked(const MatchArgs &M, uint32_t c) {
+  return (M.sep_block[c >> 5] >> (c & 31)) & 1u;
+}
+
+__device__ __forceinline__ bool sep_blocked_bits(const uint32_t *bits, uint32_t c) {
+  return (bits[c >> 5] >> (c & 31)) & 1u;
+}
+
+// first d in [0, D] with doc_off[d] >= a
+__device__ __forceinline__ uint64_t first_boundary(const uint64_t *doc_off, uint64_t D, uint64_t a) {
+  uint64_t lo = 0, hi = D;  // doc_off[D] = N >= a
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (doc_off[mid] < a)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------ block helpers
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// exclusive scan over the block's kBlock threads; total returned via *total
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *smem /*[kBlock/64]*/, T *total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  T inc = wave_incl_scan(v);
+  if (lane == 63) smem[w] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kBlock / 64; i++) {
+    T s = smem[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return base + inc - v;
+}
+
+
+}  // namespace aha

@@ -45,6 +45,59 @@ struct MatchArgs {
 
 constexpr int kBlock = 256;  // threads per block in the traversal kernels
 
+// ---- single-traversal engine (scan_v2.hip) ---------------------------------
+constexpr int kV2Threads = 1024;      // one persistent workgroup per CU
+constexpr int kV2Piece = 64;          // input bytes staged per lane per round
+constexpr uint32_t kV2Slab = 512;     // event records a wave reserves per atomic
+constexpr uint32_t kV2MaxS = 32768;   // super-chunk bytes per lane (rel/seq fit 15/16 bits)
+
+// One record per position whose state ends a key (fetch is expanded later):
+//   x = chunk id, y = seq << 16 | last_byte_of_doc << 15 | rel (pos - chunk start),
+//   z = end offset inside the document (bytes), w = key id (wide) / state base (compact)
+struct V2Args {
+  const uint8_t *text;
+  const uint64_t *doc_off;
+  uint64_t n_docs;
+  uint64_t n_bytes;
+  uint64_t n_chunks;
+  uint32_t S;                // super-chunk bytes per lane, multiple of 64
+  uint32_t lds_slots;        // automaton slots cached in LDS (prefix of the image)
+  int32_t chars;
+  int32_t sep;
+  uint32_t sep_block[8];
+  // traversal outputs
+  uint4 *ev;                 // [ev_cap] event records in arrival order
+  uint32_t *ev_aux;          // [ev_cap] chars mode: lead count << 1 | exact
+  uint64_t ev_cap;
+  unsigned long long *cursor;  // [0] next free record, [1] overflow flag
+  uint32_t *slab_used;       // [ev_cap / kV2Slab + 1] valid records per slab
+  uint32_t *ev_cnt;          // [n_chunks] events per chunk
+  uint32_t *lead_cnt;        // [n_chunks] chars: lead bytes per chunk
+  uint32_t *chunk_doc0;      // [n_chunks] chars: document containing the chunk start
+  uint32_t *doc_ev_rank;     // [D+1] events of the chunk before the document start
+  uint32_t *doc_lead_rank;   // [D+1] chars: lead bytes of the chunk before the document start
+  // post passes
+  uint64_t *ev_base;         // [n_chunks] exclusive scan of ev_cnt
+  uint64_t *lead_base;       // [n_chunks] exclusive scan of lead_cnt
+  uint64_t *blk_a;           // block sums / bases scratch
+  uint64_t *blk_b;
+  uint4 *sorted_ev;          // [ev_cap] {key, end_b, chunk, y} in final order
+  uint32_t *sorted_aux;      // [ev_cap]
+  uint32_t *sorted_cnt;      // [ev_cap] hits per event
+  uint64_t *totals;          // [0] hits [1] leads [2] events
+  aha_hit *out;
+  uint64_t cap;
+  uint64_t *doc_hit_off;
+};
+
+size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
+int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
+void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream);
+// scans ev_cnt (and lead_cnt) into ev_base / lead_base; totals[2] = events, totals[1] = leads
+void v2_launch_chunk_scan(const V2Args &M, void *stream);
+void v2_launch_sort(const DevAut &A, const V2Args &M, uint64_t n_records, void *stream);
+void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events, void *stream);
+
 struct LaunchCfg {
   void *stream;
 };

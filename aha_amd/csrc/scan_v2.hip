@@ -1,0 +1,481 @@
+// scan_v2.hip -- single-traversal match engine for gfx950 (MI355X).
+//
+// Replaces the same reference path as kernels.hip (src/aha/ac.cr:176-192
+// match_, :265-278 fetch, src/aha/cedar.cr:441-447 child, matcher.cr:34-39)
+// but walks the corpus ONCE:
+//
+//   k2_traverse   one persistent 1024-thread workgroup per CU.  The first
+//                 lds_slots slots of the BFS-ordered double array (the hot,
+//                 shallow states) are copied into LDS once per workgroup;
+//                 deeper states are probed in HBM/L2.  Each lane owns one
+//                 contiguous super-chunk of S bytes and streams it through a
+//                 wave-private LDS window (64 B per lane per round, loaded as
+//                 4 x 16 B).  Lanes advance independently: one table probe per
+//                 loop trip (goto hit, or a fail step).  A position whose state
+//                 ends a key is NOT expanded here: the wave compacts such
+//                 "events" with ballot + mbcnt and appends 16-byte records to
+//                 a slab it reserved with one atomic -- no key-table loads and
+//                 no ordering work in the hot loop.
+//   k2_sort       scatters the records into final (position) order using the
+//                 exclusive scan of per-chunk event counts, resolves the key
+//                 and its output-chain length.
+//   k2_expand     walks each event's output chain (ac.cr:265-278) and writes
+//                 the Hit triples at their final index; k2_doc_offsets writes
+//                 the per-document hit offsets.
+//
+// Exactness: a lane starts (Lmax-1) bytes before its chunk (clamped to the
+// document start) at root, so its state is the sequential automaton's state
+// for every position it reports (see kernels.hip header).
+#include <hip/hip_runtime.h>
+
+#include "automaton.hpp"
+#include "devcommon.hpp"
+#include "image.hpp"
+
+namespace aha {
+
+namespace {
+
+constexpr int kWaveIn = 64 * kV2Piece;  // LDS input bytes per wave
+constexpr uint32_t kLastFlag = 0x8000u;
+
+template <bool COMPACT>
+struct Slot;
+template <>
+struct Slot<true> {
+  using type = uint32_t;
+  static __device__ __forceinline__ bool match(type e, uint32_t b) { return (e & 0xFFu) == b; }
+  static __device__ __forceinline__ uint32_t base(type e) { return (e >> C_BASE_SHIFT) & C_BASE_MASK; }
+  static __device__ __forceinline__ bool end(type e) { return (e & C_END) != 0; }
+  static __device__ __forceinline__ uint32_t failroot(type e) { return e & C_FAILROOT; }
+  // payload of an event: the new state's base (key resolved later through end_key)
+  static __device__ __forceinline__ uint32_t payload(type e) { return base(e); }
+};
+template <>
+struct Slot<false> {
+  using type = uint2;
+  static __device__ __forceinline__ bool match(type e, uint32_t b) { return (e.y & 0xFFu) == b; }
+  static __device__ __forceinline__ uint32_t base(type e) { return e.x & W_BASE_MASK; }
+  static __device__ __forceinline__ bool end(type e) { return (e.x & W_END) != 0; }
+  static __device__ __forceinline__ uint32_t failroot(type e) { return e.x & W_FAILROOT; }
+  static __device__ __forceinline__ uint32_t payload(type e) { return e.y >> 8; }  // key id
+};
+
+// ------------------------------------------------------------------ traverse
+template <bool COMPACT>
+__global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  using S_ = Slot<COMPACT>;
+  using slot_t = typename S_::type;
+  slot_t *lt = reinterpret_cast<slot_t *>(smem);
+  const slot_t *gt = reinterpret_cast<const slot_t *>(A.slots);
+  const uint32_t T = M.lds_slots;
+  uint8_t *in_base = smem + (size_t)T * sizeof(slot_t);
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(gt);
+    uint4 *dst = reinterpret_cast<uint4 *>(lt);
+    const uint32_t nvec = (uint32_t)((size_t)T * sizeof(slot_t) / 16);
+    for (uint32_t i = threadIdx.x; i < nvec; i += kV2Threads) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t *inl = in_base + wave * kWaveIn + lane * 16;  // this lane's 16-byte column
+  const uint32_t root = A.root;
+  const int64_t N = (int64_t)M.n_bytes;
+  const uint64_t D = M.n_docs;
+  const int64_t S = (int64_t)M.S;
+  const int rounds = (int)(M.S / kV2Piece);
+  const int warm = A.max_len > 1 ? (int)A.max_len - 1 : 0;
+  const int R = (warm + kV2Piece - 1) / kV2Piece;  // warm-up rounds before the chunk
+
+  // wave-private slab of event records (values are wave-uniform)
+  uint64_t slab_pos = 0;
+  uint32_t slab_left = 0, slab_used_n = 0;
+  uint64_t slab_id = ~0ull;
+
+  const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t chunk = tile * kV2Threads + threadIdx.x;
+    const bool live = chunk < M.n_chunks;
+    const int64_t a = (int64_t)chunk * S;
+    const int64_t e = live ? min(a + S, N) : a;
+    uint64_t dn = 0;
+    int64_t nb = INT64_MAX, doc_start = a, pos = e;
+    uint32_t B = root, fr = 0, seq = 0;
+    uint32_t lc = 0, lc_exact = 0, lead_total = 0;
+    if (live) {
+      dn = first_boundary(M.doc_off, D, (uint64_t)a);
+      nb = (int64_t)M.doc_off[dn];
+      pos = a;
+      if (nb != a) {
+        doc_start = (int64_t)M.doc_off[dn - 1];
+        pos = a - min<int64_t>(a - doc_start, warm);
+        if (M.chars) M.chunk_doc0[chunk] = (uint32_t)(dn - 1);
+      } else if (M.chars) {
+        M.chunk_doc0[chunk] = (uint32_t)dn;
+      }
+    }
+
+    for (int r = -R; r < rounds; r++) {
+      const int64_t pb = a + (int64_t)r * kV2Piece;
+      const int64_t pend = min(pb + kV2Piece, e);
+      const bool need = live && pos < pend;
+      if (!__any(need)) continue;
+      if (need) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int64_t g = pb + k * 16;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (g >= 0 && g + 16 <= N) {
+            v = *reinterpret_cast<const uint4 *>(M.text + g);
+          } else if (g >= 0 && g < N) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int j = 0; j < 16 && g + j < N; j++) w[j >> 2] |= (uint32_t)M.text[g + j] << ((j & 3) * 8);
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+          *reinterpret_cast<uint4 *>(inl + k * 1024) = v;
+        }
+      }
+      // ---- hot loop: one probe per trip, lanes advance independently -------
+      for (;;) {
+        const bool act = live && pos < pend;
+        if (!__any(act)) break;
+        bool ev = false;
+        uint32_t ev_w = 0, ev_z = 0, ev_y = 0, ev_aux = 0;
+        if (act) {
+          if (pos == nb) {  // a document starts here: reset (match state is per sequence, ac.cr:177)
+            do {
+              M.doc_ev_rank[dn] = seq;
+              if (M.chars) M.doc_lead_rank[dn] = lead_total;
+              dn++;
+              nb = dn <= D ? (int64_t)M.doc_off[dn] : INT64_MAX;
+            } while (nb == pos);
+            B = root;
+            fr = 0;
+            doc_start = pos;
+            lc = 0;
+            lc_exact = 1;
+          }
+          const uint32_t o = (uint32_t)(pos - pb);
+          const uint32_t b = inl[(o >> 4) * 1024 + (o & 15)];
+          bool consumed = false;
+          if (b == 0) {  // NUL contract: state := root, nothing reported
+            B = root;
+            fr = 0;
+            consumed = true;
+          } else {
+            const uint32_t idx = B ^ b;
+            slot_t en;
+            if (idx < T)
+              en = lt[idx];
+            else
+              en = gt[idx];
+            if (S_::match(en, b)) {  // goto (cedar.cr:441-447)
+              B = S_::base(en);
+              fr = S_::failroot(en);
+              consumed = true;
+              if (S_::end(en) && pos >= a) {  // is_end? -> fetch later (ac.cr:183-185)
+                ev = true;
+                ev_w = S_::payload(en);
+              }
+            } else if (B == root) {
+              consumed = true;  // break if nid == 0 (ac.cr:188)
+            } else if (fr) {
+              B = root;  // nid = fails[nid] with fail == root (ac.cr:189)
+              fr = 0;
+            } else {
+              slot_t h;
+              if (B < T)
+                h = lt[B];
+              else
+                h = gt[B];
+              B = S_::base(h);
+              fr = S_::failroot(h);
+            }
+          }
+          if (consumed) {
+            if (M.chars && pos >= a) {
+              const uint32_t isl = (b & 0xC0u) != 0x80u;
+              lc += isl;
+              lead_total += isl;
+            }
+            if (ev) {
+              const uint32_t last = (pos + 1 == nb) ? kLastFlag : 0u;
+              ev_y = (seq << 16) | last | (uint32_t)(pos - a);
+              ev_z = (uint32_t)(pos - doc_start) + 1u;
+              ev_aux = (lc << 1) | lc_exact;
+              seq++;
+            }
+            pos++;
+          }
+        }
+        // ---- wave-level compaction of events (ballot + prefix count) --------
+        const unsigned long long mask = __ballot(ev);
+        if (mask) {
+          const uint32_t n = (uint32_t)__popcll(mask);
+          if (slab_left < n) {
+            if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(M.cursor, (unsigned long long)kV2Slab);
+            base = __shfl(base, 0, 64);
+            slab_pos = base;
+            slab_left = kV2Slab;
+            slab_used_n = 0;
+            slab_id = base / kV2Slab;
+            if (base + kV2Slab > M.ev_cap) {  // temp exhausted: the host falls back
+              if (lane == 0) M.cursor[1] = 1ull;
+              slab_id = ~0ull;
+            }
+          }
+          if (ev && slab_id != ~0ull) {
+            const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            M.ev[slab_pos + my] = make_uint4((uint32_t)chunk, ev_y, ev_z, ev_w);
+            if (M.chars) M.ev_aux[slab_pos + my] = ev_aux;
+          }
+          slab_pos += n;
+          slab_left -= n;
+          slab_used_n += n;
+        }
+      }
+    }
+    if (live) {
+      M.ev_cnt[chunk] = seq;
+      if (M.chars) M.lead_cnt[chunk] = lead_total;
+      if (e == N) {  // documents that start at N (empty tail documents, and d = D)
+        while (dn <= D) {
+          M.doc_ev_rank[dn] = seq;
+          if (M.chars) M.doc_lead_rank[dn] = lead_total;
+          dn++;
+        }
+      }
+    }
+  }
+  if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
+}
+
+// ---------------------------------------------------------------- scans
+__global__ __launch_bounds__(256) void k2_blocksum(const uint32_t *in, const uint64_t *n_ptr, uint64_t n_fixed,
+                                                    uint64_t *blk) {
+  __shared__ uint64_t sm[4];
+  const uint64_t n = n_ptr ? *n_ptr : n_fixed;
+  const uint64_t nblk = (n + 255) / 256;
+  for (uint64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const uint64_t i = b * 256 + threadIdx.x;
+    uint64_t tot;
+    block_excl_scan<uint64_t>(i < n ? in[i] : 0u, sm, &tot);
+    if (threadIdx.x == 0) blk[b] = tot;
+  }
+}
+
+// exclusive scan of blk[0..ceil(n/256)) in place by one workgroup; *total = sum
+__global__ __launch_bounds__(1024) void k2_scan_blocks(uint64_t *arr, const uint64_t *n_ptr, uint64_t n_fixed,
+                                                       uint64_t *total) {
+  __shared__ uint64_t sm[16];
+  const uint64_t n_items = n_ptr ? *n_ptr : n_fixed;
+  const uint64_t n = (n_items + 255) / 256;
+  uint64_t carry = 0;
+  for (uint64_t t0 = 0; t0 < n; t0 += 1024) {
+    const uint64_t i = t0 + threadIdx.x;
+    const uint64_t v = i < n ? arr[i] : 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t inc = wave_incl_scan(v);
+    if (lane == 63) sm[w] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (int k = 0; k < 16; k++) {
+      const uint64_t s = sm[k];
+      if (k < w) base += s;
+      tot += s;
+    }
+    if (i < n) arr[i] = carry + base + inc - v;
+    __syncthreads();
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k2_scan_apply(const uint32_t *in, uint64_t n, const uint64_t *blk,
+                                                      uint64_t *out) {
+  __shared__ uint64_t sm[4];
+  const uint64_t nblk = (n + 255) / 256;
+  for (uint64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const uint64_t i = b * 256 + threadIdx.x;
+    const uint64_t ex = block_excl_scan<uint64_t>(i < n ? in[i] : 0u, sm, nullptr);
+    if (i < n) out[i] = blk[b] + ex;
+  }
+}
+
+// -------------------------------------------------------- event -> hit chain
+// Walks the output chain of `key` for an event at absolute position abs_pos
+// (end offset end_b inside its document) and calls f(k, len) for every hit the
+// reference yields, in its order (fetch, ac.cr:265-278; with the separator
+// tests of match(seq, sep), ac.cr:324-336).
+template <class F>
+__device__ __forceinline__ void for_each_hit(const DevAut &A, const V2Args &M, uint32_t key, uint64_t abs_pos,
+                                             uint32_t end_b, bool last, F &&f) {
+  if (M.sep && !last && sep_blocked_bits(M.sep_block, M.text[abs_pos + 1])) return;
+  int32_t k = (int32_t)key;
+  do {
+    const uint2 ln = A.key_ln[k];
+    const bool blocked = M.sep && end_b > ln.x && sep_blocked_bits(M.sep_block, M.text[abs_pos - ln.x]);
+    if (!blocked) f(k, ln.x);
+    k = (int32_t)ln.y;
+  } while (k >= 0);
+}
+
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void k2_sort(DevAut A, V2Args M) {
+  if (M.cursor[1]) return;  // temp overflow: results are discarded by the host
+  const uint64_t n = min<uint64_t>(M.cursor[0], M.ev_cap);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    if ((uint32_t)(i % kV2Slab) >= M.slab_used[i / kV2Slab]) continue;
+    const uint4 rec = M.ev[i];
+    const uint64_t p = M.ev_base[rec.x] + (rec.y >> 16);
+    const uint32_t key = COMPACT ? (uint32_t)A.end_key[rec.w] : rec.w;
+    uint32_t cnt;
+    if (!M.sep) {
+      cnt = A.key_cnt[key];
+    } else {
+      cnt = 0;
+      const uint64_t abs_pos = (uint64_t)rec.x * M.S + (rec.y & 0x7FFFu);
+      for_each_hit(A, M, key, abs_pos, rec.z, (rec.y & kLastFlag) != 0, [&](int32_t, uint32_t) { cnt++; });
+    }
+    M.sorted_ev[p] = make_uint4(key, rec.z, rec.x, rec.y);
+    M.sorted_cnt[p] = cnt;
+    if (M.chars) M.sorted_aux[p] = M.ev_aux[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void k2_expand(DevAut A, V2Args M) {
+  __shared__ uint64_t sm[4];
+  if (M.cursor[1]) return;
+  const uint64_t n = M.totals[2];
+  const uint64_t nblk = (n + 255) / 256;
+  for (uint64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const uint64_t p = b * 256 + threadIdx.x;
+    const bool live = p < n;
+    uint64_t idx = M.blk_a[b] + block_excl_scan<uint64_t>(live ? M.sorted_cnt[p] : 0u, sm, nullptr);
+    if (!live) continue;
+    const uint4 rec = M.sorted_ev[p];  // {key, end_b, chunk, y}
+    const uint64_t abs_pos = (uint64_t)rec.z * M.S + (rec.w & 0x7FFFu);
+    int32_t end_c = 0;
+    if (M.chars) {
+      const uint32_t aux = M.sorted_aux[p];
+      end_c = (int32_t)(aux >> 1);
+      if (!(aux & 1u)) {
+        // the document began before this chunk: add the lead bytes between
+        // the document start and the chunk start
+        const uint32_t d0 = M.chunk_doc0[rec.z];
+        const uint64_t dchunk = M.doc_off[d0] / M.S;
+        const uint64_t docg = M.lead_base[dchunk] + M.doc_lead_rank[d0];
+        end_c += (int32_t)(M.lead_base[rec.z] - docg);
+      }
+    }
+    for_each_hit(A, M, rec.x, abs_pos, rec.y, (rec.w & kLastFlag) != 0, [&](int32_t k, uint32_t len) {
+      if (idx < M.cap) {
+        aha_hit h;
+        if (M.chars) {  // Hit(char_of_byte[start], char_of_byte[end-1]+1) matcher.cr:37
+          h.start = end_c - (int32_t)A.key_kc[k] - 1;
+          h.end = end_c;
+        } else {  // Hit(idx-len+1, idx+1) ac.cr:271-273
+          h.start = (int32_t)rec.y - (int32_t)len;
+          h.end = (int32_t)rec.y;
+        }
+        h.value = k;
+        M.out[idx] = h;
+      }
+      idx++;
+    });
+  }
+}
+
+// doc_hit_off[d] = index of the first hit at or after the document's start
+__global__ __launch_bounds__(256) void k2_doc_offsets(V2Args M) {
+  if (M.cursor[1] || !M.doc_hit_off) return;
+  const uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (d > M.n_docs) return;
+  const uint64_t q = M.doc_off[d];
+  const uint64_t n_ev = M.totals[2], n_hits = M.totals[0];
+  uint64_t r = n_hits;
+  if (q < M.n_bytes) {
+    const uint64_t p = M.ev_base[q / M.S] + M.doc_ev_rank[d];
+    if (p < n_ev) {
+      const uint64_t b = p / 256;
+      r = M.blk_a[b];
+      for (uint64_t j = b * 256; j < p; j++) r += M.sorted_cnt[j];
+    }
+  }
+  M.doc_hit_off[d] = r;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- launchers
+size_t v2_lds_bytes(uint32_t lds_slots, bool compact) {
+  return (size_t)lds_slots * (compact ? 4 : 8) + (size_t)(kV2Threads / 64) * kWaveIn;
+}
+
+int v2_prepare(bool compact, size_t lds_bytes) {
+  const void *f = compact ? (const void *)k2_traverse<true> : (const void *)k2_traverse<false>;
+  return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = v2_lds_bytes(M.lds_slots, A.compact != 0);
+  if (A.compact)
+    hipLaunchKernelGGL(k2_traverse<true>, dim3(grid), dim3(kV2Threads), lds, s, A, M);
+  else
+    hipLaunchKernelGGL(k2_traverse<false>, dim3(grid), dim3(kV2Threads), lds, s, A, M);
+}
+
+static inline uint32_t grid_for(uint64_t n_items, uint32_t per_block, uint32_t max_blocks) {
+  uint64_t g = (n_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  return (uint32_t)(g > max_blocks ? max_blocks : g);
+}
+
+void v2_launch_chunk_scan(const V2Args &M, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t g = grid_for(M.n_chunks, 256, 4096);
+  hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.ev_cnt, (const uint64_t *)nullptr, M.n_chunks,
+                     M.blk_a);
+  hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_a, (const uint64_t *)nullptr, M.n_chunks,
+                     M.totals + 2);
+  hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.ev_cnt, M.n_chunks, M.blk_a, M.ev_base);
+  if (M.chars) {
+    hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.lead_cnt, (const uint64_t *)nullptr, M.n_chunks,
+                       M.blk_b);
+    hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_b, (const uint64_t *)nullptr, M.n_chunks,
+                       M.totals + 1);
+    hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.lead_cnt, M.n_chunks, M.blk_b, M.lead_base);
+  }
+}
+
+void v2_launch_sort(const DevAut &A, const V2Args &M, uint64_t n_records_hint, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t g = grid_for(n_records_hint, 256, 8192);
+  if (A.compact)
+    hipLaunchKernelGGL(k2_sort<true>, dim3(g), dim3(256), 0, s, A, M);
+  else
+    hipLaunchKernelGGL(k2_sort<false>, dim3(g), dim3(256), 0, s, A, M);
+}
+
+void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events_hint, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t g = grid_for(n_events_hint, 256, 8192);
+  // hits per event -> block sums -> bases (device-side counts: no host sync)
+  hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.sorted_cnt, (const uint64_t *)(M.totals + 2),
+                     (uint64_t)0, M.blk_a);
+  hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_a, (const uint64_t *)(M.totals + 2),
+                     (uint64_t)0, M.totals + 0);
+  hipLaunchKernelGGL(k2_expand, dim3(g), dim3(256), 0, s, A, M);
+  if (M.doc_hit_off) {
+    const uint64_t nd = M.n_docs + 1;
+    hipLaunchKernelGGL(k2_doc_offsets, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, M);
+  }
+}
+
+}  // namespace aha

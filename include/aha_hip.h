@@ -90,12 +90,14 @@ typedef struct {
   uint32_t struct_size;
   uint32_t n_kernels;
   float ms_total;           /* first launch -> hits and offsets final in HBM */
-  float ms_count;           /* traversal pass 1 (count) */
+  float ms_count;           /* engine 2: the traversal kernel; engine 1: traversal pass 1 (count) */
   float ms_scan;            /* scans of per-chunk counts */
-  float ms_write;           /* traversal pass 2 (ordered write) */
-  float ms_aux;             /* char-offset prefix pass etc. */
+  float ms_write;           /* engine 2: chain expansion + doc offsets; engine 1: traversal pass 2 */
+  float ms_aux;             /* engine 2: event sort; engine 1: char-offset prefix pass */
   uint64_t n_chunks;
   uint64_t n_hits;
+  uint32_t engine;          /* 2 = single-traversal engine, 1 = two-pass engine */
+  uint32_t chunk_bytes;     /* bytes per lane chunk */
 } aha_timing;
 
 const char *aha_strerror(int32_t code);

@@ -15,6 +15,15 @@ from pymodel import ModelAC
 from test_oracle_vs_model import as_list, rand_keys
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["v2", "v1"], autouse=True)
+def engine(request, monkeypatch):
+    """Every parity test runs on both engines: the single-traversal engine
+    (scan_v2.hip, default) and the two-pass engine it falls back to
+    (kernels.hip; AHA_ENGINE is read when a handle is compiled)."""
+    monkeypatch.setenv("AHA_ENGINE", request.param)
+    return request.param
 G = os.path.join(os.path.dirname(__file__), "golden")
 KATS = json.load(open(os.path.join(G, "reference_kats.json"), encoding="utf-8"))
 
@@ -188,6 +197,14 @@ def test_config_parity(cfg, K, nbytes, docb):
         gh, gd = g.match_batch(corpus, doc, chars=True)
         oh, od = o.match_batch(corpus, doc, chars=True, cap=len(gh) + 16)
         assert gh.tobytes() == oh.tobytes() and np.array_equal(gd, od)
+
+
+def test_engine_selected(engine):
+    ac = AC.compile(["ab", "b"])
+    ac.set_profiling(True)
+    assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
+    assert ac.last_timing()["engine"] == (2 if engine == "v2" else 1)
+    assert (ac.info["lds_slots"] > 0) == (engine == "v2")
 
 
 def test_device_resident_entry_point():

@@ -256,9 +256,12 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
 }
 
 // ---------------------------------------------------------------- scans
+// `abort_flag` (nullable): when set (event temp exhausted) the device-side
+// count in *n_ptr may exceed the scratch sizes, so the pass must not run.
 __global__ __launch_bounds__(256) void k2_blocksum(const uint32_t *in, const uint64_t *n_ptr, uint64_t n_fixed,
-                                                    uint64_t *blk) {
+                                                    uint64_t *blk, const unsigned long long *abort_flag) {
   __shared__ uint64_t sm[4];
+  if (abort_flag && *abort_flag) return;
   const uint64_t n = n_ptr ? *n_ptr : n_fixed;
   const uint64_t nblk = (n + 255) / 256;
   for (uint64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
@@ -271,8 +274,9 @@ __global__ __launch_bounds__(256) void k2_blocksum(const uint32_t *in, const uin
 
 // exclusive scan of blk[0..ceil(n/256)) in place by one workgroup; *total = sum
 __global__ __launch_bounds__(1024) void k2_scan_blocks(uint64_t *arr, const uint64_t *n_ptr, uint64_t n_fixed,
-                                                       uint64_t *total) {
+                                                       uint64_t *total, const unsigned long long *abort_flag) {
   __shared__ uint64_t sm[16];
+  if (abort_flag && *abort_flag) return;
   const uint64_t n_items = n_ptr ? *n_ptr : n_fixed;
   const uint64_t n = (n_items + 255) / 256;
   uint64_t carry = 0;
@@ -441,15 +445,15 @@ void v2_launch_chunk_scan(const V2Args &M, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t g = grid_for(M.n_chunks, 256, 4096);
   hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.ev_cnt, (const uint64_t *)nullptr, M.n_chunks,
-                     M.blk_a);
+                     M.blk_a, (const unsigned long long *)nullptr);
   hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_a, (const uint64_t *)nullptr, M.n_chunks,
-                     M.totals + 2);
+                     M.totals + 2, (const unsigned long long *)nullptr);
   hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.ev_cnt, M.n_chunks, M.blk_a, M.ev_base);
   if (M.chars) {
     hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.lead_cnt, (const uint64_t *)nullptr, M.n_chunks,
-                       M.blk_b);
+                       M.blk_b, (const unsigned long long *)nullptr);
     hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_b, (const uint64_t *)nullptr, M.n_chunks,
-                       M.totals + 1);
+                       M.totals + 1, (const unsigned long long *)nullptr);
     hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.lead_cnt, M.n_chunks, M.blk_b, M.lead_base);
   }
 }
@@ -468,9 +472,9 @@ void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events_hint, 
   const uint32_t g = grid_for(n_events_hint, 256, 8192);
   // hits per event -> block sums -> bases (device-side counts: no host sync)
   hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.sorted_cnt, (const uint64_t *)(M.totals + 2),
-                     (uint64_t)0, M.blk_a);
+                     (uint64_t)0, M.blk_a, (const unsigned long long *)(M.cursor + 1));
   hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_a, (const uint64_t *)(M.totals + 2),
-                     (uint64_t)0, M.totals + 0);
+                     (uint64_t)0, M.totals + 0, (const unsigned long long *)(M.cursor + 1));
   hipLaunchKernelGGL(k2_expand, dim3(g), dim3(256), 0, s, A, M);
   if (M.doc_hit_off) {
     const uint64_t nd = M.n_docs + 1;

@@ -180,6 +180,21 @@ def test_capacity_error_reports_required():
     assert gpu_list(out) == [(i, i + 1, 0) for i in range(10)]
 
 
+def test_capacity_error_when_event_temp_overflows():
+    # more events than the single-traversal engine's temp (sized from cap) can
+    # hold: it must hand over to the two-pass engine and still report the count
+    import ctypes as C
+
+    ac = AC.compile(["a", "aa"])
+    n_bytes = 3_000_000
+    t = np.full(n_bytes, ord("a"), dtype=np.uint8)
+    out = np.zeros(4, dtype=orc.HIT_DTYPE)
+    n = C.c_uint64(0)
+    rc = N.lib().aha_ac_match_bytes(ac._h, t.ctypes.data, t.size, None, out.ctypes.data, 4, C.byref(n))
+    assert rc == N.AHA_E_CAPACITY and n.value == 2 * n_bytes - 1
+    assert gpu_list(out) == [(0, 1, 0), (0, 2, 1), (1, 2, 0), (1, 3, 1)]
+
+
 # ---- the BASELINE configs at oracle-sized scale ------------------------------
 
 @pytest.mark.parametrize("cfg,K,nbytes,docb", [(2, 1000, 1 << 22, 1 << 16), (3, 100_000, 1 << 23, 1 << 18),

@@ -1,0 +1,126 @@
+"""Multi-GPU sharding of Aha::AC#match (SURVEY.md section 8 e).
+
+The path shards naturally: the match state resets per sequence
+(src/aha/ac.cr:177) and the automaton is read-only, so documents are
+independent units.  One process per GPU (torch.distributed, backend "nccl" =
+RCCL over xGMI on ROCm; "gloo" in the CPU tests):
+
+  * partition_docs   -- contiguous document ranges balanced by cumulative
+                        bytes; contiguity makes global hit order = rank order,
+                        so no merge is needed;
+  * HitGatherer      -- all-gatherv of the variable-length hit buffers:
+                        all_gather of the per-rank counts, then ONE grouped
+                        all-pairs isend/irecv exchange (ncclGroupStart ..
+                        Send/Recv .. GroupEnd under RCCL).  On MI355X's fully
+                        connected xGMI mesh every rank then drives its 7 links
+                        at once (time ~ 12*max_r H_r / 153 GB/s), where a ring
+                        all-gather would be per-link bound.
+
+The automaton is replicated: every rank compiles the same keys (~0.2 s for
+100k keys), which is cheaper than broadcasting and needs no collective.
+"""
+import numpy as np
+import torch
+
+
+def partition_docs(doc_offsets, world):
+    """Splits D documents into `world` contiguous ranges balanced by bytes.
+    Returns a list of (d_lo, d_hi) with d_lo <= d_hi, covering [0, D]."""
+    doc_offsets = np.asarray(doc_offsets, dtype=np.uint64)
+    D = doc_offsets.size - 1
+    total = int(doc_offsets[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r // world
+        d = int(np.searchsorted(doc_offsets, target, side="left"))
+        # nearest document boundary to the byte target
+        if d > 0 and d <= D and abs(int(doc_offsets[d - 1]) - target) < abs(int(doc_offsets[min(d, D)]) - target):
+            d -= 1
+        d = min(max(d, cuts[-1]), D)
+        cuts.append(d)
+    cuts.append(D)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def local_shard(corpus, doc_offsets, rank, world):
+    """This rank's documents: (corpus view, rebased doc offsets, first doc index)."""
+    lo, hi = partition_docs(doc_offsets, world)[rank]
+    doc_offsets = np.asarray(doc_offsets, dtype=np.uint64)
+    b0, b1 = int(doc_offsets[lo]), int(doc_offsets[hi])
+    return corpus[b0:b1], (doc_offsets[lo:hi + 1] - doc_offsets[lo]).astype(np.uint64), lo
+
+
+class HitGatherer:
+    """all-gatherv of hit triples ([n,3] int32 tensors) across ranks."""
+
+    def __init__(self, dist, device, group=None):
+        self.dist = dist
+        self.device = device
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self._counts = torch.zeros(self.world, dtype=torch.int64, device=device)
+        self._mine = torch.zeros(1, dtype=torch.int64, device=device)
+        self._buf = None
+
+    def all_gatherv(self, hits, n):
+        """hits: [cap,3] int32 on self.device, first n rows valid.  Returns
+        (gathered [sum_n,3] view, counts list); rank r's hits start at
+        sum(counts[:r]) -- global order = rank order (contiguous doc ranges)."""
+        dist = self.dist
+        self._mine[0] = n
+        dist.all_gather_into_tensor(self._counts, self._mine, group=self.group)
+        counts = [int(c) for c in self._counts.tolist()]
+        total = sum(counts)
+        if self._buf is None or self._buf.shape[0] < total:
+            self._buf = torch.empty((total + total // 8 + 16, 3), dtype=torch.int32, device=self.device)
+        out = self._buf
+        base = [0]
+        for c in counts:
+            base.append(base[-1] + c)
+        ops = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            if n:
+                ops.append(dist.P2POp(dist.isend, hits[:n], peer, group=self.group))
+            if counts[peer]:
+                ops.append(dist.P2POp(dist.irecv, out[base[peer]:base[peer + 1]], peer, group=self.group))
+        if n:
+            out[base[self.rank]:base[self.rank + 1]].copy_(hits[:n])
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out[:total], counts
+
+    def gather_doc_hit_offsets(self, dho, counts):
+        """Per-document hit offsets of all ranks, rebased to the global hit
+        index (dho: [D_r+1] int64 on device).  Returns a [D+1] tensor."""
+        dist = self.dist
+        n_local = torch.tensor([dho.numel() - 1], dtype=torch.int64, device=self.device)
+        all_n = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(all_n, n_local, group=self.group)
+        ns = [int(x) for x in all_n.tolist()]
+        base_hits = [0]
+        for c in counts:
+            base_hits.append(base_hits[-1] + c)
+        out = torch.empty(sum(ns) + 1, dtype=torch.int64, device=self.device)
+        doc_base = [0]
+        for x in ns:
+            doc_base.append(doc_base[-1] + x)
+        mine = (dho[:-1] + base_hits[self.rank]).contiguous()
+        ops = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            if ns[self.rank]:
+                ops.append(dist.P2POp(dist.isend, mine, peer, group=self.group))
+            if ns[peer]:
+                ops.append(dist.P2POp(dist.irecv, out[doc_base[peer]:doc_base[peer + 1]], peer, group=self.group))
+        if ns[self.rank]:
+            out[doc_base[self.rank]:doc_base[self.rank + 1]].copy_(mine)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        out[-1] = base_hits[-1]
+        return out

@@ -1,0 +1,85 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU sharding logic: contiguous
+document partition + all-gatherv of hit buffers reproduces the single-process
+result.  The per-rank matcher here is the CPU oracle (checker only) because
+there is no GPU in this environment; on the GPU box bench.py --gpus N runs the
+same HitGatherer over RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, keys_blob, keys_offs, corpus, doc, out_q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import pyoracle as orc
+    from aha_amd.distributed import HitGatherer, local_shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o = orc.AC.compile_packed(keys_blob, keys_offs)
+        sub, sub_doc, lo = local_shard(corpus, doc, rank, world)
+        hits, dho = o.match_batch(sub, sub_doc)
+        t = torch.from_numpy(hits.view(np.int32).reshape(-1, 3).copy()) if len(hits) else torch.zeros((0, 3), dtype=torch.int32)
+        g = HitGatherer(dist, torch.device("cpu"))
+        allh, counts = g.all_gatherv(t, len(hits))
+        alld = g.gather_doc_hit_offsets(torch.from_numpy(dho.astype(np.int64)), counts)
+        out_q.put((rank, allh.numpy().copy(), alld.numpy().copy(), counts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allgatherv_matches_single_process(world):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc
+    from aha_amd import synth
+
+    blob, offs, nf = synth.keys(3, K=3000)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 18, doc_bytes=1 << 13)
+    # a few empty documents, including at the ends
+    doc = np.concatenate([[0], doc[:5], [doc[4]], doc[5:], [doc[-1]]]).astype(np.uint64)
+    o = orc.AC.compile_packed(blob, offs)
+    ref_hits, ref_dho = o.match_batch(corpus, doc)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, blob, offs, corpus, doc, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = ref_hits.view(np.int32).reshape(-1, 3)
+    for rank, allh, alld, counts in res:
+        assert sum(counts) == len(ref_hits)
+        assert np.array_equal(allh, ref), f"rank {rank}: gathered hits differ"
+        assert np.array_equal(alld.astype(np.uint64), ref_dho), f"rank {rank}: doc offsets differ"
+
+
+def test_partition_is_contiguous_and_balanced():
+    from aha_amd.distributed import partition_docs
+
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(0, 5000, size=1000)
+    doc = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    for world in (1, 2, 4, 8):
+        parts = partition_docs(doc, world)
+        assert parts[0][0] == 0 and parts[-1][1] == 1000
+        for (a, b), (c, d) in zip(parts, parts[1:]):
+            assert b == c and a <= b
+        loads = [int(doc[b] - doc[a]) for a, b in parts]
+        assert max(loads) - min(loads) <= 2 * 5000
+    # degenerate: fewer documents than ranks
+    parts = partition_docs(np.array([0, 10], dtype=np.uint64), 4)
+    assert parts[0][0] == 0 and parts[-1][1] == 1 and sum(b - a for a, b in parts) == 1

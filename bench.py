@@ -192,18 +192,30 @@ def main():
 
     # roofline of the dominant kernel (HIP events inside the library, launch stream)
     avg = {k: float(np.mean(v)) for k, v in kern.items()}
-    dom = "write" if avg["ms_write"] >= avg["ms_count"] else "count"
+    engine = ac.last_timing()["engine"]
     A = info["image_bytes"]
-    if dom == "write":  # reads the corpus + automaton, writes the ordered hits and doc offsets
-        alg_bytes = n_bytes + 12 * n_hits + 8 * (D + 1) + 8 * (D + 1) + A
-    else:  # count pass: corpus + automaton in, per-chunk counts out
+    if engine == 2:
+        # k2_traverse: corpus + doc offsets + automaton image in; its event records are scratch
+        dom, dom_ms = "k2_traverse", avg["ms_count"]
         alg_bytes = n_bytes + 8 * (D + 1) + A
-    dom_ms = avg[f"ms_{dom}"]
+    elif avg["ms_write"] >= avg["ms_count"]:  # two-pass engine: ordered-write pass
+        dom, dom_ms = "k_write", avg["ms_write"]
+        alg_bytes = n_bytes + 12 * n_hits + 16 * (D + 1) + A
+    else:
+        dom, dom_ms = "k_count", avg["ms_count"]
+        alg_bytes = n_bytes + 8 * (D + 1) + A
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    try:  # PMC HBM bytes per launch, measured in separate rocprofv3 --pmc passes (profiles/)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+        if pmc.get("config") == cfg and pmc.get("bytes_per_gpu") == n_bytes:
+            traffic = pmc["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        pass
     roofline = {
-        "bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "alg_bytes_per_launch": int(alg_bytes), "avg_ms": round(dom_ms, 4),
+        "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "alg_bytes_per_launch": int(alg_bytes), "avg_ms": round(dom_ms, 4), "engine": engine,
         "whole_path_frac": round((n_bytes + 12 * n_hits + 16 * (D + 1) + A) / (avg["ms_total"] * 1e-3) / 1e9
                                  / HBM_PEAK_GBS, 4),
         "kernels_ms": {k: round(v, 4) for k, v in avg.items()},

@@ -1,0 +1,147 @@
+// aha/ac.hpp -- C++ host-side mirror of the reference's Crystal API for the
+// accelerated path, on top of the C ABI (include/aha_hip.h):
+//
+//   Aha::AC.compile(keys)                    src/aha/ac.cr:62-69
+//   AC#match(seq : Bytes) { |hit| }          src/aha/ac.cr:280-286
+//   AC#match(seq : String) { |hit| }         src/aha/matcher.cr:34-39  (char offsets)
+//   AC#match(seq, sep : BitArray) { |hit| }  src/aha/ac.cr:321-340, matcher.cr:41-46
+//   AC#[](id) / AC#[](key)                   src/aha/ac.cr:41-43
+//   Aha::Hit#start/#end/#value               src/aha/matcher.cr:2-11
+//
+// Errors are thrown as aha::Error carrying the reference's message text.
+// Header-only; link with -laha_hip.  No CPU fallback: matching needs a GPU.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <vector>
+
+#include "../aha_hip.h"
+
+namespace aha {
+
+using Hit = aha_hit;  // {start, end, value : Int32}
+
+struct Error : std::runtime_error {
+  int32_t code;
+  uint32_t key_index;
+  Error(int32_t c, const std::string &msg, uint32_t k = 0) : std::runtime_error(msg), code(c), key_index(k) {}
+};
+
+// BitArray as used by match(seq, sep)
+class BitArray {
+ public:
+  explicit BitArray(int size) : size_(size), bits_((size_t)(size > 0 ? (size + 7) / 8 : 1), 0) {}
+  int size() const { return size_; }
+  void set(int i, bool v = true) {
+    if (i < 0 || i >= size_) throw std::out_of_range("BitArray index");
+    if (v)
+      bits_[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));
+    else
+      bits_[(size_t)i >> 3] &= (uint8_t)~(1u << (i & 7));
+  }
+  const std::vector<uint8_t> &bytes() const { return bits_; }
+
+ private:
+  int size_;
+  std::vector<uint8_t> bits_;
+};
+
+class AC {
+ public:
+  AC(const AC &) = delete;
+  AC &operator=(const AC &) = delete;
+  AC(AC &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  ~AC() { aha_ac_free(h_); }
+
+  // Aha::AC.compile(keys)
+  static AC compile(const std::vector<std::string> &keys, int device = -1) {
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> offs(keys.size() + 1, 0);
+    for (size_t i = 0; i < keys.size(); i++) {
+      blob.insert(blob.end(), keys[i].begin(), keys[i].end());
+      offs[i + 1] = blob.size();
+    }
+    aha_options o{};
+    o.struct_size = sizeof(o);
+    o.device = device;
+    aha_ac *h = nullptr;
+    uint32_t bad = 0;
+    int32_t rc = aha_ac_compile(blob.data(), offs.data(), (uint32_t)keys.size(), &o, &h, &bad);
+    if (rc == AHA_E_DUP_KEY) throw Error(rc, "key:" + keys[bad] + " appear twice.", bad);  // ac.cr:66
+    if (rc != AHA_OK) throw Error(rc, aha_strerror(rc), bad);
+    return AC(h);
+  }
+
+  // AC#match(seq : Bytes) -- byte offsets; hits in the reference's order
+  template <class F>
+  void match(std::string_view seq, F &&block) const {
+    run(seq, nullptr, false, std::forward<F>(block));
+  }
+  // AC#match(seq : String) -- char offsets (valid UTF-8)
+  template <class F>
+  void match_string(std::string_view seq, F &&block) const {
+    run(seq, nullptr, true, std::forward<F>(block));
+  }
+  // AC#match(seq, sep)
+  template <class F>
+  void match(std::string_view seq, const BitArray &sep, F &&block, bool chars = false) const {
+    run(seq, &sep, chars, std::forward<F>(block));
+  }
+  std::vector<Hit> match(std::string_view seq, bool chars = false) const {
+    std::vector<Hit> v;
+    run(seq, nullptr, chars, [&](const Hit &h) { v.push_back(h); });
+    return v;
+  }
+
+  // AC#[](sid : Int) : String ;  AC#[](key) : Int (IndexError when absent)
+  std::string operator[](int32_t id) const {
+    int32_t n = aha_ac_key(h_, id, nullptr, 0);
+    if (n < 0) throw Error(n, "Index out of bounds");
+    std::string s((size_t)n, '\0');
+    aha_ac_key(h_, id, reinterpret_cast<uint8_t *>(&s[0]), n);
+    return s;
+  }
+  int32_t operator[](std::string_view key) const {
+    int32_t r = aha_ac_id(h_, reinterpret_cast<const uint8_t *>(key.data()), (int32_t)key.size());
+    if (r < 0) throw Error(r, "Index out of bounds");
+    return r;
+  }
+  aha_ac *handle() const { return h_; }
+
+ private:
+  explicit AC(aha_ac *h) : h_(h) {}
+  template <class F>
+  void run(std::string_view seq, const BitArray *sep, bool chars, F &&block) const {
+    aha_match_params p{};
+    p.struct_size = sizeof(p);
+    p.char_offsets = chars ? 1 : 0;
+    if (sep) {
+      p.sep_size = sep->size();
+      std::memcpy(p.sep_bits, sep->bytes().data(), sep->bytes().size() < 32 ? sep->bytes().size() : 32);
+    }
+    std::vector<Hit> out(seq.size() / 4 + 64);
+    uint64_t n = 0;
+    for (;;) {
+      int32_t rc = aha_ac_match_bytes(h_, reinterpret_cast<const uint8_t *>(seq.data()), seq.size(), &p,
+                                      out.data(), out.size(), &n);
+      if (rc == AHA_E_CAPACITY) {
+        out.resize(n);
+        continue;
+      }
+      if (rc != AHA_OK) {
+        const char *m = aha_last_error(h_);
+        throw Error(rc, (m && *m) ? m : aha_strerror(rc));
+      }
+      break;
+    }
+    for (uint64_t i = 0; i < n; i++) block(out[i]);
+  }
+  aha_ac *h_;
+};
+
+}  // namespace aha

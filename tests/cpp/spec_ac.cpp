@@ -1,0 +1,61 @@
+// C++ twin of the reference's spec/ac_spec.cr, run against libaha_hip.so
+// through include/aha/ac.hpp (built and executed by tests/test_cpp_wrapper.py
+// on the GPU box).
+#include <cstdio>
+#include <utility>
+#include <vector>
+
+#include "aha/ac.hpp"
+
+using Pair = std::pair<int, int>;
+static int fails = 0;
+static void expect(const char *name, const std::vector<Pair> &got, const std::vector<Pair> &want) {
+  if (got != want) {
+    fails++;
+    std::printf("FAIL %s: got", name);
+    for (auto &p : got) std::printf(" {%d,%d}", p.first, p.second);
+    std::printf("\n");
+  } else {
+    std::printf("ok   %s\n", name);
+  }
+}
+
+int main() {
+  {  // it "ac"  spec/ac_spec.cr:5-12
+    auto matcher = aha::AC::compile({"我", "我是", "是中"});
+    std::vector<Pair> matched;
+    matcher.match_string("我是中国人", [&](const aha::Hit &hit) { matched.push_back({hit.end, hit.value}); });
+    expect("ac", matched, {{1, 0}, {2, 1}, {3, 2}});
+    // byte-level triples (Bytes overload)
+    std::vector<Pair> b;
+    matcher.match("我是中国人", [&](const aha::Hit &hit) { b.push_back({hit.start, hit.end}); });
+    expect("ac bytes", b, {{0, 3}, {0, 6}, {3, 9}});
+    if (matcher[1] != "我是" || matcher["是中"] != 2) {
+      fails++;
+      std::printf("FAIL []\n");
+    }
+  }
+  {  // it "ac with sep"  spec/ac_spec.cr:25-34
+    auto matcher = aha::AC::compile({"a", "aa"});
+    aha::BitArray sep(256);
+    sep.set(' ');
+    std::vector<Pair> matched;
+    matcher.match("a aaa", sep, [&](const aha::Hit &hit) { matched.push_back({hit.end, hit.value}); }, true);
+    expect("ac with sep", matched, {{1, 0}});
+  }
+  {  // error behaviour: raise "key:... appear twice."  ac.cr:66
+    try {
+      aha::AC::compile({"ab", "cd", "ab"});
+      fails++;
+      std::printf("FAIL dup: no exception\n");
+    } catch (const aha::Error &e) {
+      if (std::string(e.what()) != "key:ab appear twice." || e.key_index != 2) {
+        fails++;
+        std::printf("FAIL dup message: %s\n", e.what());
+      } else {
+        std::printf("ok   dup key\n");
+      }
+    }
+  }
+  return fails ? 1 : 0;
+}

@@ -12,6 +12,12 @@
 #include <string>
 #include <vector>
 
+#if defined(__HIPCC__)
+#define AHA_HD __host__ __device__
+#else
+#define AHA_HD
+#endif
+
 namespace aha {
 
 // Abstract automaton, states numbered in BFS order (0 = root).  The children
@@ -27,6 +33,7 @@ struct Automaton {
   std::vector<uint32_t> parent;       // [n_states]
   std::vector<uint32_t> fail;         // [n_states]
   std::vector<int32_t> key_of;        // [n_states]   key ending here, or -1
+  std::vector<uint32_t> depth;        // [n_states]   bytes from the root
 
   // per key (emission tables; index = key id = Hit#value)
   std::vector<uint32_t> key_len;    // bytes                      (ac.cr:89-93 key_lens)
@@ -60,9 +67,15 @@ bool build_automaton(const uint8_t *blob, const uint64_t *offs, uint32_t n_keys,
 // (its header; label 0 is never a goto because keys hold no NUL byte,
 // cedar.cr:235) and slot base[s]^label for each child.  Because bases are
 // unique, "slot.label == label" is a complete ownership check.
+// Placement is depth-segmented for the shallow levels: when the BFS reaches
+// depth d <= kSegDepth a fresh 256-slot block is started and earlier blocks
+// are closed, so  seg_start[d] <= base[s]  <=>  depth(s) >= d  (d <= kSegDepth)
+// and every slot below seg_start[d] belongs to a state of depth < d.
+constexpr uint32_t kSegDepth = 5;
 struct Placement {
   std::vector<uint32_t> base;  // [n_states]
   uint32_t n_slots = 0;        // multiple of 256
+  uint32_t seg_start[kSegDepth + 2] = {0};  // first slot of depth d; [kSegDepth+1] = n_slots sentinel if shallower
 };
 void place_states(const Automaton &a, Placement &p);
 
@@ -96,5 +109,41 @@ struct Image {
 };
 // Returns false if the automaton does not fit the format limits.
 bool encode_image(const Automaton &a, const Placement &p, bool force_wide, Image &img);
+
+// ---- boundary filter (scan_v2.hip, filter mode) ------------------------------
+// States of depth < d0 have their rows in LDS; states of depth d0 are
+// "boundary" states.  For a boundary state u and the next bytes x1 x2 x3 the
+// filter answers "may an excursion below u be observable or long?":
+//   n=1: u.x1 is a path and (it ends a key, or the depth<=d0 state the shallow
+//        automaton would be in at that position ends a key)
+//   n=2: the same for u.x1x2
+//   n=3: u.x1x2x3 is a path
+// `bloom` is a blocked Bloom filter (3 bits in one 32-bit word, no false
+// negatives); `xset` the exact set (open addressing, 0 = empty) used to
+// discard false positives before the exact re-walk.
+AHA_HD inline uint32_t filter_hash(uint32_t B, uint32_t w) {
+  uint32_t h = (B * 0x9E3779B1u) ^ (w * 0x85EBCA6Bu);
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 13;
+  return h;
+}
+AHA_HD inline uint32_t filter_mask(uint32_t h) {
+  uint32_t g = h * 0x297A2D39u;
+  return (1u << (g >> 27)) | (1u << ((g >> 22) & 31u)) | (1u << ((g >> 17) & 31u));
+}
+AHA_HD inline uint32_t filter_word(uint32_t h, uint32_t words) { return (uint32_t)(((uint64_t)h * words) >> 32); }
+AHA_HD inline uint32_t filter_key(uint32_t n, uint32_t x1, uint32_t x2, uint32_t x3) {
+  return (n << 24) | x1 | (x2 << 8) | (x3 << 16);
+}
+struct Filter {
+  uint32_t d0 = 0;
+  uint32_t t_rows = 0;   // slots [0, t_rows): rows + headers of states with depth < d0
+  uint32_t t_bend = 0;   // slots [t_rows, t_bend): boundary (depth d0) states
+  std::vector<uint32_t> bloom;  // [words]
+  std::vector<uint64_t> xset;   // [pow2] key = base << 32 | filter_key
+  uint64_t n_entries = 0;
+};
+void build_filter(const Automaton &a, const Placement &p, uint32_t d0, uint32_t words, Filter &f);
 
 }  // namespace aha

@@ -20,6 +20,7 @@ using namespace aha;
 struct aha_ac {
   Automaton aut;
   Image img;  // host copy of the device image (export / debugging)
+  Filter flt; // filter mode tables (d0 == 0: off)
   uint32_t n_slots = 0;
   uint32_t slot_bytes = 0;
   bool compact = false;
@@ -160,19 +161,53 @@ int32_t fill_params(aha_ac *ac, const aha_match_params *p, MatchArgs &M) {
 // ---- single-traversal engine: sizing, scratch, orchestration ----------------
 constexpr size_t kLdsPerCU = 160 * 1024;
 
+// Host-only plan: how much of the image the traversal kernel keeps in LDS and
+// whether the boundary filter is used (automaton.hpp, Filter).
+void plan_engine(aha_ac *ac, const Placement &pl) {
+  const size_t in_bytes = (size_t)(kV2Threads / 64) * 64 * kV2Piece;
+  const size_t slot = ac->compact ? 4 : 8;
+  const size_t budget = kLdsPerCU - in_bytes;
+  ac->flt = Filter();
+  if ((size_t)ac->n_slots * slot <= budget) {  // the whole automaton lives in LDS
+    ac->v2_lds_slots = ac->n_slots;
+    return;
+  }
+  const char *fe = getenv("AHA_FILTER");
+  const bool want_filter = !(fe && strcmp(fe, "0") == 0);
+  uint32_t d0 = 0;
+  if (want_filter) {
+    for (uint32_t d = 2; d <= 4 && d + 1 <= kSegDepth + 1; d++) {
+      if ((size_t)pl.seg_start[d] * slot <= 32 * 1024 && pl.seg_start[d + 1] > pl.seg_start[d]) d0 = d;
+    }
+  }
+  if (d0) {
+    uint32_t words = (uint32_t)((budget - (size_t)pl.seg_start[d0] * slot) / 4) & ~3u;
+    build_filter(ac->aut, pl, d0, words, ac->flt);
+    ac->v2_lds_slots = pl.seg_start[d0];
+    return;
+  }
+  ac->v2_lds_slots = (uint32_t)(budget / slot) & ~3u;
+}
+
 void v2_setup(aha_ac *ac) {
   const char *eng = getenv("AHA_ENGINE");
   if (eng && strcmp(eng, "v1") == 0) return;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ac->device) != hipSuccess || cus <= 0)
     return;
-  const size_t in_bytes = (size_t)(kV2Threads / 64) * 64 * kV2Piece;
-  const size_t slot = ac->compact ? 4 : 8;
-  size_t budget = (kLdsPerCU - in_bytes) / slot;
-  uint32_t T = (uint32_t)std::min<size_t>(budget, ac->n_slots);
-  T &= ~3u;  // copied into LDS as 16-byte vectors
-  if (v2_prepare(ac->compact, v2_lds_bytes(T, ac->compact)) != 0) return;
-  ac->v2_lds_slots = T;
+  const bool filter = ac->flt.d0 != 0;
+  const uint32_t words = filter ? (uint32_t)ac->flt.bloom.size() : 0;
+  if (v2_prepare(ac->compact, filter, v2_lds_bytes(ac->v2_lds_slots, ac->compact, words)) != 0) return;
+  if (filter) {
+    DevAut &d = ac->dev;
+    if (upload(ac, ac->flt.bloom, &d.bloom) != AHA_OK) return;
+    if (upload(ac, ac->flt.xset, &d.xset) != AHA_OK) return;
+    d.d0 = ac->flt.d0;
+    d.t_rows = ac->flt.t_rows;
+    d.t_bend = ac->flt.t_bend;
+    d.bloom_words = words;
+    d.xmask = (uint32_t)(ac->flt.xset.size() - 1);
+  }
   ac->v2_grid = (uint32_t)cus;
   ac->v2_ok = true;
 }
@@ -348,6 +383,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   ac->n_slots = img.n_slots;
   ac->compact = img.compact;
   ac->slot_bytes = img.compact ? 4 : 8;
+  plan_engine(ac, pl);
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     int n = aha_device_count();
     if (n <= 0) {
@@ -405,6 +441,10 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->slot_bytes = ac->slot_bytes;
   info->lds_slots = ac->v2_lds_slots;
   info->device = ac->device;
+  info->filter_d0 = ac->flt.d0;
+  info->filter_words = (uint32_t)ac->flt.bloom.size();
+  info->filter_entries = ac->flt.n_entries;
+  info->boundary_end = ac->flt.t_bend;
   return AHA_OK;
 }
 
@@ -458,6 +498,14 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
     case AHA_IMG_KEY_KC:
       src = a.key_kc.data();
       bytes = a.key_kc.size() * 4;
+      break;
+    case AHA_IMG_BLOOM:
+      src = ac->flt.bloom.data();
+      bytes = ac->flt.bloom.size() * 4;
+      break;
+    case AHA_IMG_XSET:
+      src = ac->flt.xset.data();
+      bytes = ac->flt.xset.size() * 8;
       break;
     default:
       return AHA_E_INVALID;

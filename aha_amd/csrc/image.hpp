@@ -18,6 +18,15 @@ struct DevAut {
   uint32_t n_slots;
   uint32_t max_len;
   uint32_t compact;
+  // filter mode (0 = off): rows of states with depth < d0 live in LDS, states of
+  // depth d0 are guarded by the lookahead Bloom filter (automaton.hpp, Filter)
+  uint32_t d0;
+  uint32_t t_rows;
+  uint32_t t_bend;
+  uint32_t bloom_words;
+  const uint32_t *bloom;     // [bloom_words] copied into LDS by every workgroup
+  const uint64_t *xset;      // exact set in HBM (open addressing, 0 = empty)
+  uint32_t xmask;
 };
 
 struct MatchArgs {
@@ -90,8 +99,8 @@ struct V2Args {
   uint64_t *doc_hit_off;
 };
 
-size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
-int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
+size_t v2_lds_bytes(uint32_t lds_slots, bool compact, uint32_t bloom_words);
+int v2_prepare(bool compact, bool filter, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
 void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream);
 // scans ev_cnt (and lead_cnt) into ev_base / lead_base; totals[2] = events, totals[1] = leads
 void v2_launch_chunk_scan(const V2Args &M, void *stream);

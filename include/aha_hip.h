@@ -82,6 +82,11 @@ typedef struct {
   uint32_t slot_bytes;      /* 4 (compact) or 8 (wide) */
   uint32_t lds_slots;       /* slots of the image cached in LDS by the match kernel */
   int32_t device;           /* device the image lives on, -1 if host only */
+  uint32_t filter_d0;       /* filter mode: boundary depth (0 = filter off) */
+  uint32_t filter_words;    /* 32-bit words of the LDS Bloom filter */
+  uint64_t filter_entries;  /* entries of the exact set behind it */
+  uint32_t boundary_end;    /* slots below this belong to states of depth <= filter_d0 */
+  uint32_t reserved;
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded
@@ -155,7 +160,9 @@ enum {
   AHA_IMG_END_KEY = 1, /* int32[n_slots], compact only */
   AHA_IMG_KEY_LN = 2,  /* {uint32 len, int32 next}[K] */
   AHA_IMG_KEY_CNT = 3, /* uint32[K] */
-  AHA_IMG_KEY_KC = 4   /* uint32[K] */
+  AHA_IMG_KEY_KC = 4,  /* uint32[K] */
+  AHA_IMG_BLOOM = 5,   /* uint32[filter_words] (filter mode) */
+  AHA_IMG_XSET = 6     /* uint64[pow2] exact set behind the filter */
 };
 int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_bytes);
 

@@ -133,3 +133,61 @@ def test_synth_generators_deterministic():
     # keys are distinct and compile
     AC.compile_packed(b5, o5, host_only=True)
     orc.AC.compile_packed(b5, o5)
+
+
+# ---- filter mode (k3_traverse) logic on the CPU --------------------------------
+from imgsim import FilterSim  # noqa: E402
+
+
+def _filter_ac(keys, wide=False):
+    ac = AC.compile(keys, host_only=True, force_wide=wide)
+    return ac
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("seed", range(6))
+def test_filter_mode_matches_oracle(seed, wide):
+    # automata too large for the LDS budget switch to filter mode; the CPU twin
+    # of the FAST/PEND/EXACT lane logic must reproduce the oracle bit for bit
+    rng = random.Random(300 + seed)
+    if seed % 2 == 0:
+        alphabet = bytes(range(1, 256))
+        keys = rand_keys(rng, 14000, alphabet, 1, 9)
+    else:  # UTF-8-like mix with heavy shallow sharing and nested keys
+        alphabet = b"abcdefghijklmnop\xe4\xe5\xb8\xad\x80\x81"
+        keys = rand_keys(rng, 30000, alphabet, 1, 8)
+    ac = _filter_ac(keys, wide)
+    info = ac.info
+    if info["filter_d0"] == 0:
+        pytest.skip("automaton fits LDS: filter off")
+    pieces = []
+    for _ in range(600):
+        r = rng.random()
+        if r < 0.4:
+            pieces.append(rng.choice(keys))
+        elif r < 0.5:
+            k = rng.choice(keys)
+            pieces.append(k[: rng.randint(1, len(k))])  # broken-off prefixes: deep excursions that fail
+        else:
+            pieces.append(bytes(rng.choice(alphabet + b"\x00") for _ in range(rng.randint(1, 6))))
+    text = b"".join(pieces)
+    sim = FilterSim(ac)
+    got = sim.match(text)
+    assert got == as_list(orc.AC.compile(keys).match(text))
+    assert sim.stats["fast"] > 0 and sim.stats["exact"] > 0
+
+
+def test_filter_mode_on_headline_shape():
+    from aha_amd import synth
+
+    blob, offs, nf = synth.keys(3)
+    ac = AC.compile_packed(blob, offs, host_only=True)
+    assert ac.info["filter_d0"] >= 2
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 17, doc_bytes=1 << 17)
+    sim = FilterSim(ac)
+    got = sim.match(corpus.tobytes())
+    oh, _ = orc.AC.compile_packed(blob, offs).match_batch(corpus, doc)
+    assert got == as_list(oh)
+    s = sim.stats
+    # the point of the filter: HBM probes per byte drop by an order of magnitude
+    assert s["global"] / corpus.size < 0.25, s

@@ -44,6 +44,7 @@ struct aha_ac {
   bool v2_ok = false;
   uint32_t v2_lds_slots = 0;
   uint32_t v2_grid = 0;
+  uint32_t v2_bpc = 1;
   struct Buf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -164,16 +165,22 @@ constexpr size_t kLdsPerCU = 160 * 1024;
 // Host-only plan: how much of the image the traversal kernel keeps in LDS and
 // whether the boundary filter is used (automaton.hpp, Filter).
 void plan_engine(aha_ac *ac, const Placement &pl) {
-  const size_t in_bytes = (size_t)(kV2Threads / 64) * 64 * kV2Piece;
+  // LDS input window: 64 B rows of 16-byte columns in filter mode, padded rows otherwise
+  const size_t in_bytes = (size_t)(kV2Threads / 64) * 64 * (kV2Piece + 4);
   const size_t slot = ac->compact ? 4 : 8;
-  const size_t budget = kLdsPerCU - in_bytes;
+  // AHA_V2_BPC=2: two workgroups per CU (half the LDS each, twice the waves)
+  const char *bpc = getenv("AHA_V2_BPC");
+  ac->v2_bpc = (bpc && strcmp(bpc, "2") == 0) ? 2 : 1;
+  const size_t budget = kLdsPerCU / ac->v2_bpc - in_bytes;
   ac->flt = Filter();
   if ((size_t)ac->n_slots * slot <= budget) {  // the whole automaton lives in LDS
     ac->v2_lds_slots = ac->n_slots;
     return;
   }
+  // Filter mode is bit-exact but not yet faster than the plain LDS-prefix walk
+  // (DESIGN.md 4.4), so it is opt-in: AHA_FILTER=1.
   const char *fe = getenv("AHA_FILTER");
-  const bool want_filter = !(fe && strcmp(fe, "0") == 0);
+  const bool want_filter = fe && strcmp(fe, "1") == 0;
   uint32_t d0 = 0;
   if (want_filter) {
     for (uint32_t d = 2; d <= 4 && d + 1 <= kSegDepth + 1; d++) {
@@ -208,7 +215,7 @@ void v2_setup(aha_ac *ac) {
     d.bloom_words = words;
     d.xmask = (uint32_t)(ac->flt.xset.size() - 1);
   }
-  ac->v2_grid = (uint32_t)cus;
+  ac->v2_grid = (uint32_t)cus * ac->v2_bpc;
   ac->v2_ok = true;
 }
 
@@ -256,7 +263,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   int32_t rc;
   size_t sizes[16] = {M.ev_cap * 16,      M.ev_cap * 16,      M.ev_cap * 4,     n_slabs * 4,
                       M.n_chunks * 4,     (M.n_docs + 1) * 4, M.n_chunks * 8,   n_blk * 8,
-                      n_blk * 8,          5 * 8,              M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
+                      n_blk * 8,          16 * 8,             M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
                       M.chars ? M.n_chunks * 4 : 0, M.chars ? M.n_chunks * 4 : 0, M.chars ? (M.n_docs + 1) * 4 : 0,
                       M.chars ? M.n_chunks * 8 : 0};
   for (int i = 0; i < 16; i++)
@@ -281,7 +288,11 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
 
   const bool prof = ac->profiling && ac->ev_ready;
-  HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 5 * 8, s));
+  HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 16 * 8, s));
+  const bool dbg = getenv("AHA_DEBUG_STATS") != nullptr;
+  M.dbg = dbg ? (unsigned long long *)ac->v2buf[9].p + 8 : nullptr;
+  const char *dm = getenv("AHA_DEBUG_MODE");
+  M.dbg_mode = dm ? atoi(dm) : 0;
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
   v2_launch_traverse(ac->dev, M, ac->v2_grid, s);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
@@ -294,6 +305,13 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   HIPCHK(ac, hipGetLastError());
   HIPCHK(ac, hipMemcpyAsync(ac->h_v2, ac->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(ac, hipStreamSynchronize(s));
+  if (dbg) {
+    unsigned long long d[8];
+    if (hipMemcpy(d, (unsigned long long *)ac->v2buf[9].p + 8, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[aha stats] fast iters %llu (lanes/iter %.1f, cyc/iter %.0f) burst iters %llu (lanes/iter %.1f, cyc/iter %.0f)\n",
+              d[0], d[0] ? (double)d[1] / d[0] : 0.0, d[0] ? (double)d[4] / d[0] : 0.0, d[2],
+              d[2] ? (double)d[3] / d[2] : 0.0, d[2] ? (double)d[5] / d[2] : 0.0);
+  }
   if (ac->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = ac->h_v2[2];
   if (prof) {

@@ -56,7 +56,7 @@ constexpr int kBlock = 256;  // threads per block in the traversal kernels
 
 // ---- single-traversal engine (scan_v2.hip) ---------------------------------
 constexpr int kV2Threads = 1024;      // one persistent workgroup per CU
-constexpr int kV2Piece = 64;          // input bytes staged per lane per round
+constexpr int kV2Piece = 32;          // input bytes staged per lane per round (multiple of 16)
 constexpr uint32_t kV2Slab = 512;     // event records a wave reserves per atomic
 constexpr uint32_t kV2MaxS = 32768;   // super-chunk bytes per lane (rel/seq fit 15/16 bits)
 
@@ -94,6 +94,8 @@ struct V2Args {
   uint32_t *sorted_aux;      // [ev_cap]
   uint32_t *sorted_cnt;      // [ev_cap] hits per event
   uint64_t *totals;          // [0] hits [1] leads [2] events
+  unsigned long long *dbg;   // optional [8] traversal statistics (AHA_DEBUG_STATS=1)
+  int32_t dbg_mode;          // timing experiments only (AHA_DEBUG_MODE): 1 = fold every probe into LDS (wrong hits)
   aha_hit *out;
   uint64_t cap;
   uint64_t *doc_hit_off;

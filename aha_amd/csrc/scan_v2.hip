@@ -62,7 +62,16 @@ struct Slot<false> {
 };
 
 // ------------------------------------------------------------------ traverse
-template <bool COMPACT>
+// The hot loop is VALU-issue bound (measured: its time does not move with the
+// number of HBM probes nor with twice the waves), so it is written for few
+// instructions per trip: 32-bit positions relative to the staged piece, one
+// table lookup per trip (a goto probe OR the fail header of the previous
+// miss), conflict-free padded LDS input rows, 64-bit arithmetic only in the
+// rare paths (document boundaries, events).
+constexpr int kInStride = kV2Piece + 4;           // bytes per lane in the LDS input window (odd dword stride)
+constexpr int kWaveIn2 = 64 * kInStride;
+
+template <bool COMPACT, bool CHARS>
 __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   using S_ = Slot<COMPACT>;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint8_t *inl = in_base + wave * kWaveIn + lane * 16;  // this lane's 16-byte column
+  uint8_t *inl = in_base + wave * kWaveIn2 + lane * kInStride;
   const uint32_t root = A.root;
   const int64_t N = (int64_t)M.n_bytes;
   const uint64_t D = M.n_docs;
@@ -94,15 +103,52 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
   uint32_t slab_left = 0, slab_used_n = 0;
   uint64_t slab_id = ~0ull;
 
+  // lazy events: a lane keeps ONE pending record in registers; the wave
+  // flushes all pending records (ballot + mbcnt compaction into its slab)
+  // only when a lane that already holds one produces another.
+  bool pev = false;
+  uint32_t p_x = 0, p_y = 0, p_z = 0, p_w = 0, p_aux = 0;
+  auto flush_events = [&]() {
+    const unsigned long long mask = __ballot(pev);
+    if (!mask) return;
+    const uint32_t n = (uint32_t)__popcll(mask);
+    if (slab_left < n) {
+      if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(M.cursor, (unsigned long long)kV2Slab);
+      base = __shfl(base, 0, 64);
+      slab_pos = base;
+      slab_left = kV2Slab;
+      slab_used_n = 0;
+      slab_id = base / kV2Slab;
+      if (base + kV2Slab > M.ev_cap) {  // temp exhausted: the host falls back
+        if (lane == 0) M.cursor[1] = 1ull;
+        slab_id = ~0ull;
+      }
+    }
+    if (pev && slab_id != ~0ull) {
+      const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      M.ev[slab_pos + my] = make_uint4(p_x, p_y, p_z, p_w);
+      if (CHARS) M.ev_aux[slab_pos + my] = p_aux;
+    }
+    pev = false;
+    slab_pos += n;
+    slab_left -= n;
+    slab_used_n += n;
+  };
+
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t chunk = tile * kV2Threads + threadIdx.x;
+    p_x = (uint32_t)chunk;
     const bool live = chunk < M.n_chunks;
     const int64_t a = (int64_t)chunk * S;
     const int64_t e = live ? min(a + S, N) : a;
     uint64_t dn = 0;
     int64_t nb = INT64_MAX, doc_start = a, pos = e;
     uint32_t B = root, fr = 0, seq = 0;
+    bool hdr = false;  // the next lookup fetches the fail header of B (no byte consumed)
     uint32_t lc = 0, lc_exact = 0, lead_total = 0;
     if (live) {
       dn = first_boundary(M.doc_off, D, (uint64_t)a);
@@ -111,8 +157,8 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
       if (nb != a) {
         doc_start = (int64_t)M.doc_off[dn - 1];
         pos = a - min<int64_t>(a - doc_start, warm);
-        if (M.chars) M.chunk_doc0[chunk] = (uint32_t)(dn - 1);
-      } else if (M.chars) {
+        if (CHARS) M.chunk_doc0[chunk] = (uint32_t)(dn - 1);
+      } else if (CHARS) {
         M.chunk_doc0[chunk] = (uint32_t)dn;
       }
     }
@@ -122,9 +168,10 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
       const int64_t pend = min(pb + kV2Piece, e);
       const bool need = live && pos < pend;
       if (!__any(need)) continue;
+      uint32_t rel = kV2Piece, lim = 0;  // inactive: rel >= lim
       if (need) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < kV2Piece / 16; k++) {
           const int64_t g = pb + k * 16;
           uint4 v = make_uint4(0, 0, 0, 0);
           if (g >= 0 && g + 16 <= N) {
@@ -134,119 +181,103 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             for (int j = 0; j < 16 && g + j < N; j++) w[j >> 2] |= (uint32_t)M.text[g + j] << ((j & 3) * 8);
             v = make_uint4(w[0], w[1], w[2], w[3]);
           }
-          *reinterpret_cast<uint4 *>(inl + k * 1024) = v;
+          uint32_t *dst = reinterpret_cast<uint32_t *>(inl + k * 16);
+          dst[0] = v.x;
+          dst[1] = v.y;
+          dst[2] = v.z;
+          dst[3] = v.w;
         }
+        rel = (uint32_t)(pos - pb);
+        lim = (uint32_t)(pend - pb);
       }
-      // ---- hot loop: one probe per trip, lanes advance independently -------
+      // document boundary inside this piece, as a piece-relative offset
+      uint32_t nb_rel = (nb >= pb && nb < pb + kV2Piece) ? (uint32_t)(nb - pb) : ~0u;
+      int32_t docrel = (int32_t)(pb - doc_start);  // end offset in the document = docrel + rel + 1
+      const bool emit_ok = r >= 0;                 // warm-up rounds report nothing
+      const uint32_t chunk_rel0 = (uint32_t)(r * kV2Piece);
+
+      // ---- hot loop: one lookup per trip, lanes advance independently --------
+      // Written as predicated straight-line code (selects, not branches): the
+      // compiler's nested divergent branches cost ~64 SALU + 63 VALU per trip
+      // (rocprofv3 SQ_INSTS_*), which made the loop issue-bound.
       for (;;) {
-        const bool act = live && pos < pend;
+        const bool act = rel < lim;
         if (!__any(act)) break;
-        bool ev = false;
-        uint32_t ev_w = 0, ev_z = 0, ev_y = 0, ev_aux = 0;
-        if (act) {
-          if (pos == nb) {  // a document starts here: reset (match state is per sequence, ac.cr:177)
+        if (__any(act && rel == nb_rel)) {  // rare: a document starts here (ac.cr:177)
+          if (act && rel == nb_rel) {
+            const int64_t here = pb + rel;
             do {
               M.doc_ev_rank[dn] = seq;
-              if (M.chars) M.doc_lead_rank[dn] = lead_total;
+              if (CHARS) M.doc_lead_rank[dn] = lead_total;
               dn++;
               nb = dn <= D ? (int64_t)M.doc_off[dn] : INT64_MAX;
-            } while (nb == pos);
+            } while (nb == here);
+            asm volatile("" : "+v"(nb));  // retire the load inside this block
+            nb_rel = (nb < pb + kV2Piece) ? (uint32_t)(nb - pb) : ~0u;
             B = root;
             fr = 0;
-            doc_start = pos;
+            hdr = false;
+            doc_start = here;
+            docrel = -(int32_t)rel;
             lc = 0;
             lc_exact = 1;
           }
-          const uint32_t o = (uint32_t)(pos - pb);
-          const uint32_t b = inl[(o >> 4) * 1024 + (o & 15)];
-          bool consumed = false;
-          if (b == 0) {  // NUL contract: state := root, nothing reported
-            B = root;
-            fr = 0;
-            consumed = true;
-          } else {
-            const uint32_t idx = B ^ b;
-            slot_t en;
-            if (idx < T)
-              en = lt[idx];
-            else
-              en = gt[idx];
-            if (S_::match(en, b)) {  // goto (cedar.cr:441-447)
-              B = S_::base(en);
-              fr = S_::failroot(en);
-              consumed = true;
-              if (S_::end(en) && pos >= a) {  // is_end? -> fetch later (ac.cr:183-185)
-                ev = true;
-                ev_w = S_::payload(en);
-              }
-            } else if (B == root) {
-              consumed = true;  // break if nid == 0 (ac.cr:188)
-            } else if (fr) {
-              B = root;  // nid = fails[nid] with fail == root (ac.cr:189)
-              fr = 0;
-            } else {
-              slot_t h;
-              if (B < T)
-                h = lt[B];
-              else
-                h = gt[B];
-              B = S_::base(h);
-              fr = S_::failroot(h);
-            }
-          }
-          if (consumed) {
-            if (M.chars && pos >= a) {
-              const uint32_t isl = (b & 0xC0u) != 0x80u;
-              lc += isl;
-              lead_total += isl;
-            }
-            if (ev) {
-              const uint32_t last = (pos + 1 == nb) ? kLastFlag : 0u;
-              ev_y = (seq << 16) | last | (uint32_t)(pos - a);
-              ev_z = (uint32_t)(pos - doc_start) + 1u;
-              ev_aux = (lc << 1) | lc_exact;
-              seq++;
-            }
-            pos++;
-          }
         }
-        // ---- wave-level compaction of events (ballot + prefix count) --------
-        const unsigned long long mask = __ballot(ev);
-        if (mask) {
-          const uint32_t n = (uint32_t)__popcll(mask);
-          if (slab_left < n) {
-            if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(M.cursor, (unsigned long long)kV2Slab);
-            base = __shfl(base, 0, 64);
-            slab_pos = base;
-            slab_left = kV2Slab;
-            slab_used_n = 0;
-            slab_id = base / kV2Slab;
-            if (base + kV2Slab > M.ev_cap) {  // temp exhausted: the host falls back
-              if (lane == 0) M.cursor[1] = 1ull;
-              slab_id = ~0ull;
-            }
+        bool ev = false;
+        uint32_t en_keep = 0, b_keep = 0;
+        if (act) {
+          const uint32_t b = inl[rel];
+          const uint32_t idx = hdr ? B : (B ^ b);
+          slot_t en;
+          if (idx < T)
+            en = lt[idx];
+          else
+            en = gt[idx];
+          const bool m = !hdr && b != 0 && S_::match(en, b);   // goto (cedar.cr:441-447)
+          const bool take = hdr || m;                          // state := the entry's target
+          const bool atroot = (B == root) || (b == 0);         // break if nid == 0 (ac.cr:188); NUL: state := root
+          const bool miss = !take;
+          const bool toroot = miss && (atroot || fr != 0);     // fail == root (ac.cr:189)
+          const bool consumed = m || (miss && atroot);
+          const uint32_t nbase = S_::base(en), nfr = S_::failroot(en);
+          hdr = miss && !atroot && fr == 0;                    // next trip loads fails[nid]
+          B = take ? nbase : (toroot ? root : B);
+          fr = take ? nfr : (toroot ? 0u : fr);
+          ev = m && S_::end(en) && emit_ok;                    // is_end? -> fetch later (ac.cr:183-185)
+          if (CHARS) {
+            const uint32_t isl = (consumed && emit_ok && (b & 0xC0u) != 0x80u) ? 1u : 0u;
+            lc += isl;
+            lead_total += isl;
           }
-          if (ev && slab_id != ~0ull) {
-            const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            M.ev[slab_pos + my] = make_uint4((uint32_t)chunk, ev_y, ev_z, ev_w);
-            if (M.chars) M.ev_aux[slab_pos + my] = ev_aux;
+          rel += consumed ? 1u : 0u;
+          en_keep = S_::payload(en);
+          b_keep = b;
+        }
+        (void)b_keep;
+        if (__any(ev)) {
+          if (__any(ev && pev)) flush_events();
+          if (ev) {
+            // rel was already advanced: the hit ended at rel-1
+            const uint32_t last = (rel == nb_rel) ? kLastFlag : 0u;
+            pev = true;
+            p_y = (seq << 16) | last | (chunk_rel0 + rel - 1u);
+            p_z = (uint32_t)(docrel + (int32_t)rel);
+            p_w = en_keep;
+            p_aux = (lc << 1) | lc_exact;
+            seq++;
           }
-          slab_pos += n;
-          slab_left -= n;
-          slab_used_n += n;
         }
       }
+      if (need) pos = pb + rel;
     }
+    if (__any(pev)) flush_events();
     if (live) {
       M.ev_cnt[chunk] = seq;
-      if (M.chars) M.lead_cnt[chunk] = lead_total;
+      if (CHARS) M.lead_cnt[chunk] = lead_total;
       if (e == N) {  // documents that start at N (empty tail documents, and d = D)
         while (dn <= D) {
           M.doc_ev_rank[dn] = seq;
-          if (M.chars) M.doc_lead_rank[dn] = lead_total;
+          if (CHARS) M.doc_lead_rank[dn] = lead_total;
           dn++;
         }
       }
@@ -275,7 +306,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
 //          state is shallow again.
 // Exact steps of a wave are batched ("bursts") so that one L2 round trip
 // serves many lanes and FAST trips never wait on memory.
-constexpr int kBurstHi = 28, kBurstLo = 6;
+constexpr int kBurstHi = 40, kBurstLo = 8;
 
 __device__ __forceinline__ bool bloom_test(const uint32_t *flt, uint32_t words, uint32_t B, uint32_t w) {
   const uint32_t h = filter_hash(B, w);
@@ -327,6 +358,7 @@ __global__ __launch_bounds__(kV2Threads) void k3_traverse(DevAut A, V2Args M) {
   uint64_t slab_pos = 0;
   uint32_t slab_left = 0, slab_used_n = 0;
   uint64_t slab_id = ~0ull;
+  unsigned long long st_fi = 0, st_fl = 0, st_bi = 0, st_bl = 0, st_ft = 0, st_bt = 0;
 
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -364,7 +396,7 @@ __global__ __launch_bounds__(kV2Threads) void k3_traverse(DevAut A, V2Args M) {
       uint32_t la = 0;  // the 4 bytes after the piece (filter lookahead)
       if (need) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < kV2Piece / 16; k++) {
           const int64_t g = pb + k * 16;
           uint4 v = make_uint4(0, 0, 0, 0);
           if (g >= 0 && g + 16 <= N) {
@@ -383,6 +415,10 @@ __global__ __launch_bounds__(kV2Threads) void k3_traverse(DevAut A, V2Args M) {
           for (int j = 0; j < 4 && g + j < N; j++) la |= (uint32_t)M.text[g + j] << (j * 8);
         }
       }
+      // Retire the staging loads here: inside the hot loop a pending load would
+      // make hipcc wait with vmcnt(0) at its first use, and on CDNA4 vmcnt also
+      // counts the event STORES of earlier trips (a full write round trip per trip).
+      asm volatile("" : "+v"(la));
       auto byte_at = [&](int64_t q) -> uint32_t {
         const uint32_t o = (uint32_t)(q - pb);
         return o < (uint32_t)kV2Piece ? (uint32_t)inl[(o >> 4) * 1024 + (o & 15)] : (la >> ((o - kV2Piece) * 8)) & 0xFFu;
@@ -410,6 +446,17 @@ __global__ __launch_bounds__(kV2Threads) void k3_traverse(DevAut A, V2Args M) {
         bool ev = false;
         uint32_t ev_w = 0, ev_z = 0, ev_y = 0, ev_aux = 0;
         const bool act = has && (do_fast ? mode == 0 : mode != 0);
+        long long t_begin = 0;
+        if (M.dbg) {
+          t_begin = clock64();
+          if (do_fast) {
+            st_fi++;
+            st_fl += __popcll(mf);
+          } else {
+            st_bi++;
+            st_bl += __popcll(ms);
+          }
+        }
         if (act) {
           if (pos == nb) {  // a document starts here (ac.cr:177: state is per sequence)
             do {
@@ -418,6 +465,7 @@ __global__ __launch_bounds__(kV2Threads) void k3_traverse(DevAut A, V2Args M) {
               dn++;
               nb = dn <= D ? (int64_t)M.doc_off[dn] : INT64_MAX;
             } while (nb == pos);
+            asm volatile("" : "+v"(nb));  // retire the load here, not at the loop head (see staging note)
             B = root;
             fr = 0;
             doc_start = pos;
@@ -512,14 +560,23 @@ __global__ __launch_bounds__(kV2Threads) void k3_traverse(DevAut A, V2Args M) {
             // ------------------------------------------------ PEND: exact-set check
             const int64_t room = nb - pos;
             const uint32_t x1 = byte_at(pos);
-            bool real = xset_has(A.xset, A.xmask, B, filter_key(1, x1, 0, 0));
-            if (room >= 2) {
-              const uint32_t x2 = byte_at(pos + 1);
-              real = real || xset_has(A.xset, A.xmask, B, filter_key(2, x1, x2, 0));
-              if (room >= 3) {
-                const uint32_t x3 = byte_at(pos + 2);
-                real = real || xset_has(A.xset, A.xmask, B, filter_key(3, x1, x2, x3));
-              }
+            // the three keys are looked up together (independent loads in flight)
+            const uint32_t x2 = room >= 2 ? byte_at(pos + 1) : 0u;
+            const uint32_t x3 = room >= 3 ? byte_at(pos + 2) : 0u;
+            const uint32_t w1 = filter_key(1, x1, 0, 0), w2 = filter_key(2, x1, x2, 0), w3 = filter_key(3, x1, x2, x3);
+            uint32_t i1 = filter_hash(B, w1) & A.xmask, i2 = filter_hash(B, w2) & A.xmask,
+                     i3 = filter_hash(B, w3) & A.xmask;
+            const uint64_t k1 = ((uint64_t)B << 32) | w1, k2 = ((uint64_t)B << 32) | w2, k3 = ((uint64_t)B << 32) | w3;
+            bool real = false, open1 = true, open2 = room >= 2, open3 = room >= 3;
+            while (open1 || open2 || open3) {
+              uint64_t v1 = open1 ? A.xset[i1] : 0ull;
+              uint64_t v2 = open2 ? A.xset[i2] : 0ull;
+              uint64_t v3 = open3 ? A.xset[i3] : 0ull;
+              asm volatile("" : "+v"(v1), "+v"(v2), "+v"(v3));  // all three loads retire here (no pending load leaves this block)
+              if (open1) { if (v1 == k1) real = true; if (v1 == k1 || v1 == 0) open1 = false; else i1 = (i1 + 1) & A.xmask; }
+              if (open2) { if (v2 == k2) real = true; if (v2 == k2 || v2 == 0) open2 = false; else i2 = (i2 + 1) & A.xmask; }
+              if (open3) { if (v3 == k3) real = true; if (v3 == k3 || v3 == 0) open3 = false; else i3 = (i3 + 1) & A.xmask; }
+              if (real) break;
             }
             if (!real) {
               mode = 0;  // false positive: continue FAST, skipping the filter once
@@ -622,6 +679,13 @@ __global__ __launch_bounds__(kV2Threads) void k3_traverse(DevAut A, V2Args M) {
           slab_left -= n;
           slab_used_n += n;
         }
+        if (M.dbg) {
+          const long long dt = clock64() - t_begin;
+          if (do_fast)
+            st_ft += dt;
+          else
+            st_bt += dt;
+        }
       }
     }
     if (live) {
@@ -637,6 +701,14 @@ __global__ __launch_bounds__(kV2Threads) void k3_traverse(DevAut A, V2Args M) {
     }
   }
   if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
+  if (M.dbg && lane == 0) {
+    atomicAdd(M.dbg + 0, st_fi);
+    atomicAdd(M.dbg + 1, st_fl);
+    atomicAdd(M.dbg + 2, st_bi);
+    atomicAdd(M.dbg + 3, st_bl);
+    atomicAdd(M.dbg + 4, st_ft);
+    atomicAdd(M.dbg + 5, st_bt);
+  }
 }
 
 // ---------------------------------------------------------------- scans
@@ -802,16 +874,23 @@ __global__ __launch_bounds__(256) void k2_doc_offsets(V2Args M) {
 
 // ---------------------------------------------------------------- launchers
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact, uint32_t bloom_words) {
-  return (size_t)lds_slots * (compact ? 4 : 8) + (size_t)bloom_words * 4 + (size_t)(kV2Threads / 64) * kWaveIn;
+  // filter mode (bloom_words != 0) keeps the 16-byte-column window, the plain walk the padded rows
+  return (size_t)lds_slots * (compact ? 4 : 8) + (size_t)bloom_words * 4 +
+         (size_t)(kV2Threads / 64) * (bloom_words ? kWaveIn : kWaveIn2);
 }
 
 int v2_prepare(bool compact, bool filter, size_t lds_bytes) {
-  const void *f;
-  if (filter)
-    f = compact ? (const void *)k3_traverse<true> : (const void *)k3_traverse<false>;
-  else
-    f = compact ? (const void *)k2_traverse<true> : (const void *)k2_traverse<false>;
-  return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  const void *f = compact ? (const void *)k3_traverse<true> : (const void *)k3_traverse<false>;
+  if (filter) return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  const void *fs[4] = {(const void *)k2_traverse<false, false>, (const void *)k2_traverse<false, true>,
+                       (const void *)k2_traverse<true, false>, (const void *)k2_traverse<true, true>};
+  int rc = 0;
+  for (int i = 0; i < 2; i++) {
+    int e = (int)hipFuncSetAttribute(fs[(compact ? 2 : 0) + i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+    if (e) rc = e;
+  }
+  return rc;
 }
 
 void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream) {
@@ -823,9 +902,15 @@ void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *s
     else
       hipLaunchKernelGGL(k3_traverse<false>, dim3(grid), dim3(kV2Threads), lds, s, A, M);
   } else if (A.compact) {
-    hipLaunchKernelGGL(k2_traverse<true>, dim3(grid), dim3(kV2Threads), lds, s, A, M);
+    if (M.chars)
+      hipLaunchKernelGGL((k2_traverse<true, true>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
+    else
+      hipLaunchKernelGGL((k2_traverse<true, false>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
   } else {
-    hipLaunchKernelGGL(k2_traverse<false>, dim3(grid), dim3(kV2Threads), lds, s, A, M);
+    if (M.chars)
+      hipLaunchKernelGGL((k2_traverse<false, true>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
+    else
+      hipLaunchKernelGGL((k2_traverse<false, false>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
   }
 }
 

@@ -17,12 +17,15 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2f"], autouse=True)
 def engine(request, monkeypatch):
-    """Every parity test runs on both engines: the single-traversal engine
-    (scan_v2.hip, default) and the two-pass engine it falls back to
-    (kernels.hip; AHA_ENGINE is read when a handle is compiled)."""
-    monkeypatch.setenv("AHA_ENGINE", request.param)
+    """Every parity test runs on the single-traversal engine (scan_v2.hip,
+    default), on the two-pass engine it falls back to (kernels.hip) and on the
+    single-traversal engine with the opt-in boundary filter (k3_traverse; only
+    engages for automata larger than the LDS budget).  The variables are read
+    when a handle is compiled."""
+    monkeypatch.setenv("AHA_ENGINE", "v1" if request.param == "v1" else "v2")
+    monkeypatch.setenv("AHA_FILTER", "1" if request.param == "v2f" else "0")
     return request.param
 G = os.path.join(os.path.dirname(__file__), "golden")
 KATS = json.load(open(os.path.join(G, "reference_kats.json"), encoding="utf-8"))
@@ -218,7 +221,7 @@ def test_engine_selected(engine):
     ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] == (2 if engine == "v2" else 1)
+    assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
 
 
 def test_device_resident_entry_point():

@@ -139,6 +139,12 @@ def test_synth_generators_deterministic():
 from imgsim import FilterSim  # noqa: E402
 
 
+@pytest.fixture(autouse=True)
+def _filter_opt_in(monkeypatch):
+    # filter mode is opt-in (AHA_FILTER is read when a handle is compiled)
+    monkeypatch.setenv("AHA_FILTER", "1")
+
+
 def _filter_ac(keys, wide=False):
     ac = AC.compile(keys, host_only=True, force_wide=wide)
     return ac

@@ -291,8 +291,6 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 16 * 8, s));
   const bool dbg = getenv("AHA_DEBUG_STATS") != nullptr;
   M.dbg = dbg ? (unsigned long long *)ac->v2buf[9].p + 8 : nullptr;
-  const char *dm = getenv("AHA_DEBUG_MODE");
-  M.dbg_mode = dm ? atoi(dm) : 0;
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
   v2_launch_traverse(ac->dev, M, ac->v2_grid, s);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));

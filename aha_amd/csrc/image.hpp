@@ -95,7 +95,6 @@ struct V2Args {
   uint32_t *sorted_cnt;      // [ev_cap] hits per event
   uint64_t *totals;          // [0] hits [1] leads [2] events
   unsigned long long *dbg;   // optional [8] traversal statistics (AHA_DEBUG_STATS=1)
-  int32_t dbg_mode;          // timing experiments only (AHA_DEBUG_MODE): 1 = fold every probe into LDS (wrong hits)
   aha_hit *out;
   uint64_t cap;
   uint64_t *doc_hit_off;

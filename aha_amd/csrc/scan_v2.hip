@@ -71,7 +71,8 @@ struct Slot<false> {
 constexpr int kInStride = kV2Piece + 4;           // bytes per lane in the LDS input window (odd dword stride)
 constexpr int kWaveIn2 = 64 * kInStride;
 
-template <bool COMPACT, bool CHARS>
+// ALL_LDS: the whole image fits the LDS budget (cfg 2): no HBM probe path at all.
+template <bool COMPACT, bool CHARS, bool ALL_LDS>
 __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   using S_ = Slot<COMPACT>;
@@ -228,29 +229,33 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
         if (act) {
           const uint32_t b = inl[rel];
           const uint32_t idx = hdr ? B : (B ^ b);
+          // the root row is always LDS resident: its probe is issued beside the
+          // state's own lookup, so "fail to root, retry the byte there" costs no extra trip
+          const slot_t e0 = lt[root ^ b];
           slot_t en;
-          if (idx < T)
+          if (ALL_LDS || idx < T)
             en = lt[idx];
           else
             en = gt[idx];
-          const bool m = !hdr && b != 0 && S_::match(en, b);   // goto (cedar.cr:441-447)
-          const bool take = hdr || m;                          // state := the entry's target
-          const bool atroot = (B == root) || (b == 0);         // break if nid == 0 (ac.cr:188); NUL: state := root
-          const bool miss = !take;
-          const bool toroot = miss && (atroot || fr != 0);     // fail == root (ac.cr:189)
-          const bool consumed = m || (miss && atroot);
-          const uint32_t nbase = S_::base(en), nfr = S_::failroot(en);
-          hdr = miss && !atroot && fr == 0;                    // next trip loads fails[nid]
-          B = take ? nbase : (toroot ? root : B);
-          fr = take ? nfr : (toroot ? 0u : fr);
-          ev = m && S_::end(en) && emit_ok;                    // is_end? -> fetch later (ac.cr:183-185)
+          const bool bz = b == 0;                                 // NUL contract: state := root
+          const bool m = !hdr && !bz && S_::match(en, b);         // goto (cedar.cr:441-447)
+          const bool take = hdr || m;                             // state := the entry's target
+          const bool viaroot = !take && (B == root || fr != 0 || bz);  // nid = fails[nid] = root, then probe there
+          const bool m0 = viaroot && !bz && S_::match(e0, b);     // goto from root
+          const bool consumed = m || viaroot;                     // at root a miss consumes the byte (ac.cr:188)
+          hdr = !take && !viaroot;                                // next trip loads fails[nid] (ac.cr:189)
+          const slot_t ex = m0 ? e0 : en;
+          const bool land = take || m0;
+          B = land ? S_::base(ex) : (viaroot ? root : B);
+          fr = land ? S_::failroot(ex) : (viaroot ? 0u : fr);
+          ev = (m || m0) && S_::end(ex) && emit_ok;               // is_end? -> fetch later (ac.cr:183-185)
           if (CHARS) {
             const uint32_t isl = (consumed && emit_ok && (b & 0xC0u) != 0x80u) ? 1u : 0u;
             lc += isl;
             lead_total += isl;
           }
           rel += consumed ? 1u : 0u;
-          en_keep = S_::payload(en);
+          en_keep = S_::payload(ex);
           b_keep = b;
         }
         (void)b_keep;
@@ -882,11 +887,13 @@ size_t v2_lds_bytes(uint32_t lds_slots, bool compact, uint32_t bloom_words) {
 int v2_prepare(bool compact, bool filter, size_t lds_bytes) {
   const void *f = compact ? (const void *)k3_traverse<true> : (const void *)k3_traverse<false>;
   if (filter) return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  const void *fs[4] = {(const void *)k2_traverse<false, false>, (const void *)k2_traverse<false, true>,
-                       (const void *)k2_traverse<true, false>, (const void *)k2_traverse<true, true>};
+  const void *fs[8] = {(const void *)k2_traverse<false, false, false>, (const void *)k2_traverse<false, true, false>,
+                       (const void *)k2_traverse<false, false, true>,  (const void *)k2_traverse<false, true, true>,
+                       (const void *)k2_traverse<true, false, false>,  (const void *)k2_traverse<true, true, false>,
+                       (const void *)k2_traverse<true, false, true>,   (const void *)k2_traverse<true, true, true>};
   int rc = 0;
-  for (int i = 0; i < 2; i++) {
-    int e = (int)hipFuncSetAttribute(fs[(compact ? 2 : 0) + i], hipFuncAttributeMaxDynamicSharedMemorySize,
+  for (int i = 0; i < 4; i++) {
+    int e = (int)hipFuncSetAttribute(fs[(compact ? 4 : 0) + i], hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
     if (e) rc = e;
   }
@@ -901,16 +908,18 @@ void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *s
       hipLaunchKernelGGL(k3_traverse<true>, dim3(grid), dim3(kV2Threads), lds, s, A, M);
     else
       hipLaunchKernelGGL(k3_traverse<false>, dim3(grid), dim3(kV2Threads), lds, s, A, M);
-  } else if (A.compact) {
-    if (M.chars)
-      hipLaunchKernelGGL((k2_traverse<true, true>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
-    else
-      hipLaunchKernelGGL((k2_traverse<true, false>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
   } else {
-    if (M.chars)
-      hipLaunchKernelGGL((k2_traverse<false, true>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
-    else
-      hipLaunchKernelGGL((k2_traverse<false, false>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
+    const bool all = M.lds_slots >= A.n_slots;
+#define AHA_LAUNCH_K2(C, H, L) \
+  hipLaunchKernelGGL((k2_traverse<C, H, L>), dim3(grid), dim3(kV2Threads), lds, s, A, M)
+    if (A.compact) {
+      if (M.chars) { if (all) AHA_LAUNCH_K2(true, true, true); else AHA_LAUNCH_K2(true, true, false); }
+      else         { if (all) AHA_LAUNCH_K2(true, false, true); else AHA_LAUNCH_K2(true, false, false); }
+    } else {
+      if (M.chars) { if (all) AHA_LAUNCH_K2(false, true, true); else AHA_LAUNCH_K2(false, true, false); }
+      else         { if (all) AHA_LAUNCH_K2(false, false, true); else AHA_LAUNCH_K2(false, false, false); }
+    }
+#undef AHA_LAUNCH_K2
   }
 }
 

@@ -790,7 +790,10 @@ __device__ __forceinline__ void for_each_hit(const DevAut &A, const V2Args &M, u
   } while (k >= 0);
 }
 
-template <bool COMPACT>
+// PLAIN (no separator filter, byte offsets): an event needs only {key, end_b}
+// downstream, and its chain length is key_cnt[key], so the sorted stream is
+// 8 bytes per event instead of 20.
+template <bool COMPACT, bool PLAIN>
 __global__ __launch_bounds__(256) void k2_sort(DevAut A, V2Args M) {
   if (M.cursor[1]) return;  // temp overflow: results are discarded by the host
   const uint64_t n = min<uint64_t>(M.cursor[0], M.ev_cap);
@@ -799,6 +802,10 @@ __global__ __launch_bounds__(256) void k2_sort(DevAut A, V2Args M) {
     const uint4 rec = M.ev[i];
     const uint64_t p = M.ev_base[rec.x] + (rec.y >> 16);
     const uint32_t key = COMPACT ? (uint32_t)A.end_key[rec.w] : rec.w;
+    if (PLAIN) {
+      reinterpret_cast<uint2 *>(M.sorted_ev)[p] = make_uint2(key, rec.z);
+      continue;
+    }
     uint32_t cnt;
     if (!M.sep) {
       cnt = A.key_cnt[key];
@@ -810,6 +817,54 @@ __global__ __launch_bounds__(256) void k2_sort(DevAut A, V2Args M) {
     M.sorted_ev[p] = make_uint4(key, rec.z, rec.x, rec.y);
     M.sorted_cnt[p] = cnt;
     if (M.chars) M.sorted_aux[p] = M.ev_aux[i];
+  }
+}
+
+// PLAIN: per-256 block sums of key_cnt[key] over the sorted 8-byte stream
+__global__ __launch_bounds__(256) void k2_blocksum_keys(DevAut A, V2Args M) {
+  __shared__ uint64_t sm[4];
+  if (M.cursor[1]) return;
+  const uint64_t n = M.totals[2];
+  const uint64_t nblk = (n + 255) / 256;
+  const uint2 *sv = reinterpret_cast<const uint2 *>(M.sorted_ev);
+  for (uint64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const uint64_t i = b * 256 + threadIdx.x;
+    uint64_t tot;
+    block_excl_scan<uint64_t>(i < n ? A.key_cnt[sv[i].x] : 0u, sm, &tot);
+    if (threadIdx.x == 0) M.blk_a[b] = tot;
+  }
+}
+
+__global__ __launch_bounds__(256) void k2_expand_plain(DevAut A, V2Args M) {
+  __shared__ uint64_t sm[4];
+  if (M.cursor[1]) return;
+  const uint64_t n = M.totals[2];
+  const uint64_t nblk = (n + 255) / 256;
+  const uint2 *sv = reinterpret_cast<const uint2 *>(M.sorted_ev);
+  for (uint64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const uint64_t p = b * 256 + threadIdx.x;
+    const bool live = p < n;
+    uint2 rec = make_uint2(0, 0);
+    uint32_t cnt = 0;
+    if (live) {
+      rec = sv[p];
+      cnt = A.key_cnt[rec.x];
+    }
+    uint64_t idx = M.blk_a[b] + block_excl_scan<uint64_t>(cnt, sm, nullptr);
+    if (!live) continue;
+    int32_t k = (int32_t)rec.x;
+    do {  // fetch (ac.cr:265-278): own key, then the output chain
+      const uint2 ln = A.key_ln[k];
+      if (idx < M.cap) {
+        aha_hit h;
+        h.start = (int32_t)rec.y - (int32_t)ln.x;  // Hit(idx-len+1, idx+1) ac.cr:271-273
+        h.end = (int32_t)rec.y;
+        h.value = k;
+        M.out[idx] = h;
+      }
+      idx++;
+      k = (int32_t)ln.y;
+    } while (k >= 0);
   }
 }
 
@@ -857,7 +912,8 @@ __global__ __launch_bounds__(256) void k2_expand(DevAut A, V2Args M) {
 }
 
 // doc_hit_off[d] = index of the first hit at or after the document's start
-__global__ __launch_bounds__(256) void k2_doc_offsets(V2Args M) {
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void k2_doc_offsets(DevAut A, V2Args M) {
   if (M.cursor[1] || !M.doc_hit_off) return;
   const uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (d > M.n_docs) return;
@@ -869,7 +925,12 @@ __global__ __launch_bounds__(256) void k2_doc_offsets(V2Args M) {
     if (p < n_ev) {
       const uint64_t b = p / 256;
       r = M.blk_a[b];
-      for (uint64_t j = b * 256; j < p; j++) r += M.sorted_cnt[j];
+      if (PLAIN) {
+        const uint2 *sv = reinterpret_cast<const uint2 *>(M.sorted_ev);
+        for (uint64_t j = b * 256; j < p; j++) r += A.key_cnt[sv[j].x];
+      } else {
+        for (uint64_t j = b * 256; j < p; j++) r += M.sorted_cnt[j];
+      }
     }
   }
   M.doc_hit_off[d] = r;
@@ -949,24 +1010,42 @@ void v2_launch_chunk_scan(const V2Args &M, void *stream) {
 void v2_launch_sort(const DevAut &A, const V2Args &M, uint64_t n_records_hint, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t g = grid_for(n_records_hint, 256, 8192);
-  if (A.compact)
-    hipLaunchKernelGGL(k2_sort<true>, dim3(g), dim3(256), 0, s, A, M);
-  else
-    hipLaunchKernelGGL(k2_sort<false>, dim3(g), dim3(256), 0, s, A, M);
+  const bool plain = !M.sep && !M.chars;
+  if (A.compact) {
+    if (plain)
+      hipLaunchKernelGGL((k2_sort<true, true>), dim3(g), dim3(256), 0, s, A, M);
+    else
+      hipLaunchKernelGGL((k2_sort<true, false>), dim3(g), dim3(256), 0, s, A, M);
+  } else {
+    if (plain)
+      hipLaunchKernelGGL((k2_sort<false, true>), dim3(g), dim3(256), 0, s, A, M);
+    else
+      hipLaunchKernelGGL((k2_sort<false, false>), dim3(g), dim3(256), 0, s, A, M);
+  }
 }
 
 void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events_hint, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t g = grid_for(n_events_hint, 256, 8192);
+  const bool plain = !M.sep && !M.chars;
   // hits per event -> block sums -> bases (device-side counts: no host sync)
-  hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.sorted_cnt, (const uint64_t *)(M.totals + 2),
-                     (uint64_t)0, M.blk_a, (const unsigned long long *)(M.cursor + 1));
+  if (plain)
+    hipLaunchKernelGGL(k2_blocksum_keys, dim3(g), dim3(256), 0, s, A, M);
+  else
+    hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.sorted_cnt, (const uint64_t *)(M.totals + 2),
+                       (uint64_t)0, M.blk_a, (const unsigned long long *)(M.cursor + 1));
   hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_a, (const uint64_t *)(M.totals + 2),
                      (uint64_t)0, M.totals + 0, (const unsigned long long *)(M.cursor + 1));
-  hipLaunchKernelGGL(k2_expand, dim3(g), dim3(256), 0, s, A, M);
+  if (plain)
+    hipLaunchKernelGGL(k2_expand_plain, dim3(g), dim3(256), 0, s, A, M);
+  else
+    hipLaunchKernelGGL(k2_expand, dim3(g), dim3(256), 0, s, A, M);
   if (M.doc_hit_off) {
     const uint64_t nd = M.n_docs + 1;
-    hipLaunchKernelGGL(k2_doc_offsets, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, M);
+    if (plain)
+      hipLaunchKernelGGL(k2_doc_offsets<true>, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, A, M);
+    else
+      hipLaunchKernelGGL(k2_doc_offsets<false>, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, A, M);
   }
 }
 

@@ -741,11 +741,17 @@ __global__ __launch_bounds__(1024) void k2_scan_blocks(uint64_t *arr, const uint
   const uint64_t n_items = n_ptr ? *n_ptr : n_fixed;
   const uint64_t n = (n_items + 255) / 256;
   uint64_t carry = 0;
-  for (uint64_t t0 = 0; t0 < n; t0 += 1024) {
-    const uint64_t i = t0 + threadIdx.x;
-    const uint64_t v = i < n ? arr[i] : 0;
+  // 4 consecutive items per thread: 4096 per tile
+  for (uint64_t t0 = 0; t0 < n; t0 += 4096) {
+    const uint64_t i0 = t0 + (uint64_t)threadIdx.x * 4;
+    uint64_t v[4], s4 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      v[j] = (i0 + j < n) ? arr[i0 + j] : 0;
+      s4 += v[j];
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint64_t inc = wave_incl_scan(v);
+    const uint64_t inc = wave_incl_scan(s4);
     if (lane == 63) sm[w] = inc;
     __syncthreads();
     uint64_t base = 0, tot = 0;
@@ -754,7 +760,12 @@ __global__ __launch_bounds__(1024) void k2_scan_blocks(uint64_t *arr, const uint
       if (k < w) base += s;
       tot += s;
     }
-    if (i < n) arr[i] = carry + base + inc - v;
+    uint64_t run = carry + base + inc - s4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (i0 + j < n) arr[i0 + j] = run;
+      run += v[j];
+    }
     __syncthreads();
     carry += tot;
   }

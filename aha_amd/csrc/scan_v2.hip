@@ -201,11 +201,10 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
       // Written as predicated straight-line code (selects, not branches): the
       // compiler's nested divergent branches cost ~64 SALU + 63 VALU per trip
       // (rocprofv3 SQ_INSTS_*), which made the loop issue-bound.
-      for (;;) {
-        const bool act = rel < lim;
-        if (!__any(act)) break;
-        if (__any(act && rel == nb_rel)) {  // rare: a document starts here (ac.cr:177)
-          if (act && rel == nb_rel) {
+      for (;;) {  // outer: resolve document boundaries, then run the hot loop up to the next one
+        const bool bnd = rel < lim && rel == nb_rel;
+        if (__any(bnd)) {  // rare: a document starts here (ac.cr:177: state is per sequence)
+          if (bnd) {
             const int64_t here = pb + rel;
             do {
               M.doc_ev_rank[dn] = seq;
@@ -224,6 +223,10 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             lc_exact = 1;
           }
         }
+        const uint32_t lim2 = min(lim, nb_rel);  // lanes park at the next boundary: no boundary test per trip
+      for (;;) {
+        const bool act = rel < lim2;
+        if (!__any(act)) break;
         bool ev = false;
         uint32_t en_keep = 0, b_keep = 0;
         if (act) {
@@ -272,6 +275,8 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             seq++;
           }
         }
+      }
+        if (!__any(rel < lim)) break;
       }
       if (need) pos = pb + rel;
     }

@@ -851,8 +851,14 @@ __global__ __launch_bounds__(256) void k2_blocksum_keys(DevAut A, V2Args M) {
   }
 }
 
+// Hits of a block's 256 events are assembled in LDS (each thread walks its own
+// chain) and then streamed out with fully coalesced dword stores; hit-dense
+// inputs (cfg 5: ~10 hits per event) are write-bandwidth bound here.
+constexpr uint32_t kHitStage = 4096;  // hits staged per block (48 KiB of LDS)
+
 __global__ __launch_bounds__(256) void k2_expand_plain(DevAut A, V2Args M) {
   __shared__ uint64_t sm[4];
+  __shared__ uint32_t hbuf[kHitStage * 3];
   if (M.cursor[1]) return;
   const uint64_t n = M.totals[2];
   const uint64_t nblk = (n + 255) / 256;
@@ -866,21 +872,44 @@ __global__ __launch_bounds__(256) void k2_expand_plain(DevAut A, V2Args M) {
       rec = sv[p];
       cnt = A.key_cnt[rec.x];
     }
-    uint64_t idx = M.blk_a[b] + block_excl_scan<uint64_t>(cnt, sm, nullptr);
-    if (!live) continue;
-    int32_t k = (int32_t)rec.x;
-    do {  // fetch (ac.cr:265-278): own key, then the output chain
-      const uint2 ln = A.key_ln[k];
-      if (idx < M.cap) {
-        aha_hit h;
-        h.start = (int32_t)rec.y - (int32_t)ln.x;  // Hit(idx-len+1, idx+1) ac.cr:271-273
-        h.end = (int32_t)rec.y;
-        h.value = k;
-        M.out[idx] = h;
+    uint64_t tot64;
+    const uint64_t off = block_excl_scan<uint64_t>(cnt, sm, &tot64);
+    const uint64_t base = M.blk_a[b];
+    if (tot64 <= kHitStage) {
+      if (live) {
+        uint32_t w = (uint32_t)off * 3;
+        int32_t k = (int32_t)rec.x;
+        do {  // fetch (ac.cr:265-278): own key, then the output chain
+          const uint2 ln = A.key_ln[k];
+          hbuf[w] = rec.y - ln.x;  // Hit(idx-len+1, idx+1, value) ac.cr:271-273
+          hbuf[w + 1] = rec.y;
+          hbuf[w + 2] = (uint32_t)k;
+          w += 3;
+          k = (int32_t)ln.y;
+        } while (k >= 0);
       }
-      idx++;
-      k = (int32_t)ln.y;
-    } while (k >= 0);
+      __syncthreads();
+      const uint64_t room = base < M.cap ? M.cap - base : 0;
+      const uint32_t nd = (uint32_t)(tot64 < room ? tot64 : room) * 3;
+      uint32_t *dst = reinterpret_cast<uint32_t *>(M.out + base);
+      for (uint32_t i = threadIdx.x; i < nd; i += 256) dst[i] = hbuf[i];
+      __syncthreads();
+    } else if (live) {
+      uint64_t idx = base + off;
+      int32_t k = (int32_t)rec.x;
+      do {
+        const uint2 ln = A.key_ln[k];
+        if (idx < M.cap) {
+          aha_hit h;
+          h.start = (int32_t)rec.y - (int32_t)ln.x;
+          h.end = (int32_t)rec.y;
+          h.value = k;
+          M.out[idx] = h;
+        }
+        idx++;
+        k = (int32_t)ln.y;
+      } while (k >= 0);
+    }
   }
 }
 

@@ -93,6 +93,51 @@ class HitGatherer:
                 req.wait()
         return out[:total], counts
 
+    # -- overlapped form: the exchange of step i runs beside the match of step i+1 ------
+    def start(self, hits, n, slot=0):
+        """Issues the all-gatherv of hits[:n] without waiting for the payload
+        (the 8-byte counts exchange is synchronous).  Uses output buffer
+        `slot` (0/1) so that two exchanges can be in flight; the caller must not
+        overwrite hits[:n] before finish(slot).  Returns the counts."""
+        dist = self.dist
+        if not hasattr(self, "_pending"):
+            self._pending = {}
+            self._bufs = {}
+        self.finish(slot)
+        self._mine[0] = n
+        dist.all_gather_into_tensor(self._counts, self._mine, group=self.group)
+        counts = [int(c) for c in self._counts.tolist()]
+        total = sum(counts)
+        buf = self._bufs.get(slot)
+        if buf is None or buf.shape[0] < total:
+            buf = torch.empty((total + total // 8 + 16, 3), dtype=torch.int32, device=self.device)
+            self._bufs[slot] = buf
+        base = [0]
+        for c in counts:
+            base.append(base[-1] + c)
+        ops = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            if n:
+                ops.append(dist.P2POp(dist.isend, hits[:n], peer, group=self.group))
+            if counts[peer]:
+                ops.append(dist.P2POp(dist.irecv, buf[base[peer]:base[peer + 1]], peer, group=self.group))
+        if n:
+            buf[base[self.rank]:base[self.rank + 1]].copy_(hits[:n])
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        self._pending[slot] = (reqs, buf, total, counts)
+        return counts
+
+    def finish(self, slot=0):
+        """Waits for the exchange issued with start(slot); returns (gathered, counts) or None."""
+        if not hasattr(self, "_pending") or slot not in self._pending:
+            return None
+        reqs, buf, total, counts = self._pending.pop(slot)
+        for req in reqs:
+            req.wait()
+        return buf[:total], counts
+
     def gather_doc_hit_offsets(self, dho, counts):
         """Per-document hit offsets of all ranks, rebased to the global hit
         index (dho: [D_r+1] int64 on device).  Returns a [D+1] tensor."""

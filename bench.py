@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
     ap.add_argument("--gather", default="allgatherv", choices=["allgatherv", "none"],
                     help="N>1: exchange hit buffers over RCCL inside the timed step")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: wait for each step's all-gatherv before the next match (default: the exchange of "
+                         "step i runs beside the match of step i+1, double-buffered)")
     ap.add_argument("--force-wide", action="store_true")
     return ap.parse_args()
 
@@ -145,6 +148,7 @@ def main():
             raise
         n_hits = e.required
     d_out = torch.zeros((n_hits + 1024, 3), dtype=torch.int32, device=dev)
+    d_outs = [d_out]
     log(f"{n_hits} hits per pass ({n_hits / n_bytes:.4f} per byte); upload {t_upload:.2f}s "
         f"({n_bytes / t_upload / 1e9:.1f} GB/s PCIe-inclusive)")
 
@@ -154,11 +158,29 @@ def main():
 
         gather = HitGatherer(dist, dev)
 
+    overlap = gather is not None and not args.no_overlap
+    if overlap:
+        d_outs.append(torch.zeros_like(d_out))
+    step_no = [0]
+
     def step():
-        n = ac.match_batch_device(d_corpus, d_doc, d_out, d_dho, chars=args.chars)
-        if gather is not None:
-            gather.all_gatherv(d_out, n)
+        i = step_no[0]
+        step_no[0] += 1
+        if not overlap:
+            n = ac.match_batch_device(d_corpus, d_doc, d_out, d_dho, chars=args.chars)
+            if gather is not None:
+                gather.all_gatherv(d_out, n)
+            return n
+        slot = i & 1
+        gather.finish(slot)  # the exchange that last read d_outs[slot] (step i-2) must be done
+        n = ac.match_batch_device(d_corpus, d_doc, d_outs[slot], d_dho, chars=args.chars)
+        gather.start(d_outs[slot], n, slot)  # runs beside the next step's match
         return n
+
+    def drain():
+        if overlap:
+            gather.finish(0)
+            gather.finish(1)
 
     def fence():
         torch.cuda.synchronize()
@@ -168,6 +190,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     kern = {"ms_total": [], "ms_count": [], "ms_scan": [], "ms_write": [], "ms_aux": []}
     fence()
     t0 = time.perf_counter()
@@ -176,6 +199,7 @@ def main():
         t = ac.last_timing()
         for k in kern:
             kern[k].append(t[k])
+    drain()  # every exchange issued in the timed region completes inside it
     fence()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -243,7 +267,8 @@ def main():
                        "keys": K, "bytes_per_gpu": n_bytes, "docs_per_gpu": D, "hits_per_gpu": n_hits,
                        "slots": info["n_slots"], "slot_bytes": info["slot_bytes"], "max_key_len": info["max_key_len"],
                        "offsets": "chars" if args.chars else "bytes",
-                       "parallelism": f"doc-sharded x{world}" + (f" + {args.gather}" if world > 1 else "")},
+                       "parallelism": f"doc-sharded x{world}" + (f" + {args.gather}" if world > 1 else "")
+                                      + (" (overlapped)" if overlap else "")},
             "roofline": roofline,
         }
         if cpu is not None:

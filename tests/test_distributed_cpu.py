@@ -32,6 +32,13 @@ def _worker(rank, world, port, keys_blob, keys_offs, corpus, doc, out_q):
         t = torch.from_numpy(hits.view(np.int32).reshape(-1, 3).copy()) if len(hits) else torch.zeros((0, 3), dtype=torch.int32)
         g = HitGatherer(dist, torch.device("cpu"))
         allh, counts = g.all_gatherv(t, len(hits))
+        # overlapped form: two exchanges in flight on the two slots
+        g.start(t, len(hits), 0)
+        g.start(t, len(hits), 1)
+        for slot in (0, 1):
+            oh, oc = g.finish(slot)
+            assert oc == counts and torch.equal(oh, allh)
+        assert g.finish(0) is None
         alld = g.gather_doc_hit_offsets(torch.from_numpy(dho.astype(np.int64)), counts)
         out_q.put((rank, allh.numpy().copy(), alld.numpy().copy(), counts))
     finally:

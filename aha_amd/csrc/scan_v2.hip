@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
         const bool act = rel < lim2;
         if (!__any(act)) break;
         bool ev = false;
-        uint32_t en_keep = 0, b_keep = 0;
+        uint32_t en_keep = 0;
         if (act) {
           const uint32_t b = inl[rel];
           const uint32_t idx = hdr ? B : (B ^ b);
@@ -259,9 +259,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
           }
           rel += consumed ? 1u : 0u;
           en_keep = S_::payload(ex);
-          b_keep = b;
         }
-        (void)b_keep;
         if (__any(ev)) {
           if (__any(ev && pev)) flush_events();
           if (ev) {

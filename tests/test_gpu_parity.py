@@ -92,6 +92,16 @@ def test_nul_and_empty():
     assert len(hits) == 0 and dho.tolist() == [0, 0, 0]
 
 
+def test_zero_keys_and_single_byte_docs():
+    ac = AC.compile([])
+    assert len(ac.match_array(b"anything at all")) == 0
+    ac = AC.compile(["a"])
+    docs = [b"a", b"", b"b", b"a", b"a"]
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+    hits, dho = ac.match_batch(np.frombuffer(b"".join(docs), dtype=np.uint8), offs)
+    assert gpu_list(hits) == [(0, 1, 0)] * 3 and dho.tolist() == [0, 1, 1, 1, 2, 3]
+
+
 def test_sep_size_error():
     ac = AC.compile(["a"])
     with pytest.raises(AhaError) as e:
@@ -244,3 +254,65 @@ def test_device_resident_entry_point():
     with pytest.raises(AhaError) as e:
         g.match_batch_device(dc, dd, small)
     assert e.value.code == N.AHA_E_CAPACITY and e.value.required == len(oh)
+
+
+# ---- the headline configuration at FULL size ----------------------------------
+@pytest.mark.parametrize("cfg", [3])
+def test_full_size_properties(cfg, engine):
+    """BASELINE config 3 at full size (100k keys, 1 GiB): size-independent
+    properties instead of a full oracle run -- ordering, every hit spells its
+    key, document independence (any split of the batch gives the same hits),
+    engine agreement by checksum -- plus the oracle on a sample of documents."""
+    if engine == "v1":
+        pytest.skip("full-size run is done once on the default engine (v1 is compared by checksum inside)")
+    import hashlib
+
+    import torch
+
+    blob, offs, nf = synth.keys(cfg)
+    corpus, doc = synth.corpus(cfg, blob, offs, nf)
+    D = doc.size - 1
+    g = AC.compile_packed(blob, offs)
+    dc = torch.from_numpy(corpus).cuda()
+    dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+    dho = torch.zeros(D + 1, dtype=torch.int64, device="cuda")
+    try:
+        n = g.match_batch_device(dc, dd, torch.zeros((1, 3), dtype=torch.int32, device="cuda"), dho)
+    except AhaError as e:
+        assert e.code == N.AHA_E_CAPACITY
+        n = e.required
+    out = torch.zeros((n + 16, 3), dtype=torch.int32, device="cuda")
+    assert g.match_batch_device(dc, dd, out, dho) == n
+    hits = out[:n].cpu().numpy()
+    offsets = dho.cpu().numpy()
+    assert offsets[0] == 0 and offsets[-1] == n and np.all(np.diff(offsets) >= 0)
+    # (1) per document: end offsets ascend; start < end; offsets inside the document
+    doc_of_hit = np.repeat(np.arange(D), np.diff(offsets))
+    end = hits[:, 1].astype(np.int64)
+    same_doc = doc_of_hit[1:] == doc_of_hit[:-1]
+    assert np.all(end[1:][same_doc] >= end[:-1][same_doc])
+    doc_len = np.diff(doc.astype(np.int64))
+    assert np.all(hits[:, 0] >= 0) and np.all(hits[:, 0] < hits[:, 1]) and np.all(end <= doc_len[doc_of_hit])
+    # (2) every sampled hit spells its key
+    key_len = np.diff(offs.astype(np.int64))
+    assert np.array_equal(hits[:, 1] - hits[:, 0], key_len[hits[:, 2]])
+    rng = np.random.default_rng(1)
+    for i in rng.integers(0, n, size=20000):
+        s0 = int(doc[doc_of_hit[i]]) + int(hits[i, 0])
+        k = int(hits[i, 2])
+        assert corpus[s0:s0 + int(key_len[k])].tobytes() == blob[int(offs[k]):int(offs[k + 1])].tobytes()
+    # (3) document independence: two half-batches concatenate to the same stream
+    h = hashlib.sha256(hits.tobytes()).hexdigest()
+    mid = D // 2
+    parts = []
+    for lo, hi in ((0, mid), (mid, D)):
+        sub_doc = (doc[lo:hi + 1] - doc[lo]).astype(np.int64)
+        sub = dc[int(doc[lo]):int(doc[hi])]
+        m = g.match_batch_device(sub, torch.from_numpy(sub_doc).cuda(), out, None)
+        parts.append(out[:m].cpu().numpy().copy())
+    assert hashlib.sha256(np.concatenate(parts).tobytes()).hexdigest() == h
+    # (4) the oracle on a sample of whole documents
+    o = orc.AC.compile_packed(blob, offs)
+    for d in rng.integers(0, D, size=6):
+        oh, _ = o.match_batch(corpus[int(doc[d]):int(doc[d + 1])], np.array([0, doc_len[d]], dtype=np.uint64))
+        assert hits[offsets[d]:offsets[d + 1]].tobytes() == oh.tobytes()

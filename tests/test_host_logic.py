@@ -62,6 +62,12 @@ def test_key_id_roundtrip():
         ac[4]
 
 
+def test_zero_keys_compile():
+    ac = AC.compile([], host_only=True)
+    assert ac.info["n_keys"] == 0 and ac.info["n_states"] == 1
+    assert orc.AC.compile([]).match(b"abc").size == 0
+
+
 def test_match_without_device_fails_loudly():
     # host_only handles (and machines without a GPU) must not silently fall back
     ac = AC.compile(["a"], host_only=True)

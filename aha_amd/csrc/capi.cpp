@@ -30,6 +30,7 @@ struct aha_ac {
   std::vector<void *> dev_allocs;
   // scratch (grow-only, guarded by mu)
   std::mutex mu;
+  std::mutex hmu;  // host-buffer entry points (staging buffers)
   uint32_t *d_counts = nullptr, *d_leads = nullptr;
   uint64_t *d_blk_hits = nullptr, *d_blk_leads = nullptr, *d_docg = nullptr, *d_totals = nullptr;
   uint64_t cap_chunks = 0, cap_blocks = 0, cap_docs = 0;
@@ -50,6 +51,7 @@ struct aha_ac {
     size_t bytes = 0;
   };
   Buf v2buf[16];
+  Buf hostbuf[4];  // device staging of the host-buffer entry points (corpus, doc offsets, doc hit offsets, hits)
   unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
   std::string err;
 };
@@ -292,7 +294,8 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   const bool dbg = getenv("AHA_DEBUG_STATS") != nullptr;
   M.dbg = dbg ? (unsigned long long *)ac->v2buf[9].p + 8 : nullptr;
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
-  v2_launch_traverse(ac->dev, M, ac->v2_grid, s);
+  const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
+  v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
   v2_launch_chunk_scan(M, s);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
@@ -437,6 +440,8 @@ void aha_ac_free(aha_ac *ac) {
       if (p) (void)hipFree(p);
     if (ac->h_totals) (void)hipHostFree(ac->h_totals);
     for (auto &b : ac->v2buf)
+      if (b.p) (void)hipFree(b.p);
+    for (auto &b : ac->hostbuf)
       if (b.p) (void)hipFree(b.p);
     if (ac->h_v2) (void)hipHostFree(ac->h_v2);
     if (ac->ev_ready)
@@ -663,29 +668,38 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
   if (n_bytes && !corpus) return AHA_E_INVALID;
   if (cap && !out) return AHA_E_INVALID;
   DeviceGuard g(ac->device);
-  uint8_t *d_corpus = nullptr;
-  uint64_t *d_doc = nullptr, *d_dho = nullptr;
-  aha_hit *d_out = nullptr;
-  int32_t rc = AHA_OK;
-  auto cleanup = [&]() {
-    if (d_corpus) (void)hipFree(d_corpus);
-    if (d_doc) (void)hipFree(d_doc);
-    if (d_dho) (void)hipFree(d_dho);
-    if (d_out) (void)hipFree(d_out);
+  // device staging buffers are kept in the handle (grow-only): the reference's
+  // usage is one #match per string, so per-call hipMalloc/hipFree would dominate
+  std::unique_lock<std::mutex> lk(ac->hmu);
+  auto reserve = [&](int i, size_t bytes) -> void * {
+    aha_ac::Buf &b = ac->hostbuf[i];
+    if (b.bytes < bytes) {
+      if (b.p) (void)hipFree(b.p);
+      b.p = nullptr;
+      b.bytes = 0;
+      size_t want = bytes + bytes / 4 + 4096;
+      if (hipMalloc(&b.p, want) != hipSuccess) return nullptr;
+      b.bytes = want;
+    }
+    return b.p;
   };
+  uint8_t *d_corpus = (uint8_t *)reserve(0, n_bytes + 64);
+  uint64_t *d_doc = (uint64_t *)reserve(1, (n_docs + 1) * sizeof(uint64_t));
+  uint64_t *d_dho = (uint64_t *)reserve(2, (n_docs + 1) * sizeof(uint64_t));
+  aha_hit *d_out = cap ? (aha_hit *)reserve(3, cap * sizeof(aha_hit)) : nullptr;
+  if (!d_corpus || !d_doc || !d_dho || (cap && !d_out)) {
+    ac->err = "hipMalloc failed for the staging buffers";
+    return AHA_E_HIP;
+  }
+  int32_t rc = AHA_OK;
 #define HIPCHK2(call)                                                  \
   do {                                                                 \
     hipError_t e_ = (call);                                            \
     if (e_ != hipSuccess) {                                            \
       ac->err = std::string(#call) + ": " + hipGetErrorString(e_);     \
-      cleanup();                                                       \
       return AHA_E_HIP;                                                \
     }                                                                  \
   } while (0)
-  HIPCHK2(hipMalloc((void **)&d_corpus, n_bytes + 64));
-  HIPCHK2(hipMalloc((void **)&d_doc, (n_docs + 1) * sizeof(uint64_t)));
-  HIPCHK2(hipMalloc((void **)&d_dho, (n_docs + 1) * sizeof(uint64_t)));
-  if (cap) HIPCHK2(hipMalloc((void **)&d_out, cap * sizeof(aha_hit)));
   if (n_bytes) HIPCHK2(hipMemcpy(d_corpus, corpus, n_bytes, hipMemcpyHostToDevice));
   HIPCHK2(hipMemcpy(d_doc, doc_offsets, (n_docs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   rc = aha_ac_match_batch_device(ac, d_corpus, d_doc, n_docs, n_bytes, params, d_out, cap, d_dho,
@@ -696,7 +710,6 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
     if (doc_hit_offsets)
       HIPCHK2(hipMemcpy(doc_hit_offsets, d_dho, (n_docs + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
   }
-  cleanup();
 #undef HIPCHK2
   return rc;
 }

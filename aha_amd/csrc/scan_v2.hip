@@ -9,13 +9,17 @@
 //                 shallow states) are copied into LDS once per workgroup;
 //                 deeper states are probed in HBM/L2.  Each lane owns one
 //                 contiguous super-chunk of S bytes and streams it through a
-//                 wave-private LDS window (64 B per lane per round, loaded as
-//                 4 x 16 B).  Lanes advance independently: one table probe per
-//                 loop trip (goto hit, or a fail step).  A position whose state
-//                 ends a key is NOT expanded here: the wave compacts such
-//                 "events" with ballot + mbcnt and appends 16-byte records to
-//                 a slab it reserved with one atomic -- no key-table loads and
-//                 no ordering work in the hot loop.
+//                 wave-private LDS window (32 B per lane per round, rows padded
+//                 to an odd dword stride).  Lanes advance independently: one
+//                 state lookup per loop trip (goto probe or fail header) beside
+//                 an always-LDS probe of the root row.  A position whose state
+//                 ends a key is NOT expanded here: a lane keeps one pending
+//                 16-byte "event" in registers and the wave flushes pending
+//                 events with ballot + mbcnt into a slab it reserved with one
+//                 atomic -- no key-table loads, no ordering work in the loop.
+//   k3_traverse   opt-in filter mode (AHA_FILTER=1): only rows of depth < d0
+//                 in LDS, boundary states guarded by a lookahead Bloom filter,
+//                 exact verification in batched bursts.
 //   k2_sort       scatters the records into final (position) order using the
 //                 exclusive scan of per-chunk event counts, resolves the key
 //                 and its output-chain length.
@@ -36,7 +40,7 @@ namespace aha {
 
 namespace {
 
-constexpr int kWaveIn = 64 * kV2Piece;  // LDS input bytes per wave
+constexpr int kWaveIn = 64 * kV2Piece;  // LDS input bytes per wave in filter mode (16-byte columns)
 constexpr uint32_t kLastFlag = 0x8000u;
 
 template <bool COMPACT>

@@ -52,6 +52,9 @@ def parse():
                     help="N>1: wait for each step's all-gatherv before the next match (default: the exchange of "
                          "step i runs beside the match of step i+1, double-buffered)")
     ap.add_argument("--force-wide", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1 collective backend; gloo (hits staged through host memory) only to rehearse the "
+                         "multi-rank flow on a 1-GPU box together with AHA_BENCH_ONE_DEVICE=1")
     return ap.parse_args()
 
 
@@ -131,13 +134,19 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if os.environ.get("AHA_BENCH_ONE_DEVICE"):  # rehearsal of the N>1 path on a 1-GPU box (ranks share cuda:0)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective payloads live
 
     def log(msg):
         if rank == 0:
@@ -183,7 +192,7 @@ def main():
     if world > 1 and args.gather == "allgatherv":
         from aha_amd.distributed import HitGatherer
 
-        gather = HitGatherer(dist, dev)
+        gather = HitGatherer(dist, cdev)
 
     overlap = gather is not None and not args.no_overlap
     if overlap:
@@ -196,12 +205,12 @@ def main():
         if not overlap:
             n = ac.match_batch_device(d_corpus, d_doc, d_out, d_dho, chars=args.chars)
             if gather is not None:
-                gather.all_gatherv(d_out, n)
+                gather.all_gatherv(d_out if cdev == dev else d_out[:n].cpu(), n)
             return n
         slot = i & 1
         gather.finish(slot)  # the exchange that last read d_outs[slot] (step i-2) must be done
         n = ac.match_batch_device(d_corpus, d_doc, d_outs[slot], d_dho, chars=args.chars)
-        gather.start(d_outs[slot], n, slot)  # runs beside the next step's match
+        gather.start(d_outs[slot] if cdev == dev else d_outs[slot][:n].cpu(), n, slot)  # beside the next match
         return n
 
     def drain():
@@ -229,9 +238,9 @@ def main():
     drain()  # every exchange issued in the timed region completes inside it
     fence()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot_bytes = torch.tensor([float(n_bytes)], dtype=torch.float64, device=dev)
-    tot_hits = torch.tensor([float(n_hits)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    tot_bytes = torch.tensor([float(n_bytes)], dtype=torch.float64, device=cdev)
+    tot_hits = torch.tensor([float(n_hits)], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_bytes)

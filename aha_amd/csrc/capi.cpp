@@ -217,7 +217,12 @@ void v2_setup(aha_ac *ac) {
     d.bloom_words = words;
     d.xmask = (uint32_t)(ac->flt.xset.size() - 1);
   }
-  ac->v2_grid = (uint32_t)cus * ac->v2_bpc;
+  // AHA_RESERVE_CUS=n: leave n CUs without a persistent traversal workgroup so that
+  // collective (RCCL) kernels of an overlapped exchange can run beside it
+  const char *rs = getenv("AHA_RESERVE_CUS");
+  int reserve = rs ? atoi(rs) : 0;
+  if (reserve < 0 || reserve >= cus) reserve = 0;
+  ac->v2_grid = (uint32_t)(cus - reserve) * ac->v2_bpc;
   ac->v2_ok = true;
 }
 

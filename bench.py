@@ -156,6 +156,10 @@ def main():
     from aha_amd import _native as N
 
     cfg = args.config
+    if world > 1 and args.gather != "none" and not args.no_overlap:
+        # the traversal is a persistent grid that fills every CU's LDS: keep a few CUs free so the RCCL
+        # kernels of the overlapped exchange are not locked out until it ends (read at compile time)
+        os.environ.setdefault("AHA_RESERVE_CUS", "16")
     t0 = time.time()
     blob, offs, nf = synth.keys(cfg, K=args.keys)
     K = offs.size - 1

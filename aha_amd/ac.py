@@ -97,7 +97,10 @@ class AC:
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            N.lib().aha_ac_free(h)
+            try:
+                N.lib().aha_ac_free(h)
+            except Exception:  # interpreter shutdown: the module globals may already be gone
+                pass
 
     # -- Aha::AC.compile(keys) src/aha/ac.cr:62-69 ---------------------------
     @classmethod

@@ -108,10 +108,6 @@ void v2_launch_chunk_scan(const V2Args &M, void *stream);
 void v2_launch_sort(const DevAut &A, const V2Args &M, uint64_t n_records, void *stream);
 void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events, void *stream);
 
-struct LaunchCfg {
-  void *stream;
-};
-
 // launchers (kernels.hip)
 void launch_count(const DevAut &A, const MatchArgs &M, void *stream);
 void launch_scan_blocks(const MatchArgs &M, uint64_t n_blocks, void *stream);

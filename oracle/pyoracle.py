@@ -149,7 +149,10 @@ class AC:
 
     def __del__(self):
         if self._h:
-            lib().orc_ac_free(self._h)
+            try:
+                lib().orc_ac_free(self._h)
+            except Exception:
+                pass
 
     @classmethod
     def compile(cls, keys):

@@ -316,3 +316,38 @@ def test_full_size_properties(cfg, engine):
     for d in rng.integers(0, D, size=6):
         oh, _ = o.match_batch(corpus[int(doc[d]):int(doc[d + 1])], np.array([0, doc_len[d]], dtype=np.uint64))
         assert hits[offsets[d]:offsets[d + 1]].tobytes() == oh.tobytes()
+
+
+def test_single_large_document_vs_oracle(engine):
+    """SURVEY 8d single-document variant: one 256 MiB document, so every chunk
+    but the first starts in the middle of a sequence (warm-up overlap at scale).
+    Full comparison with the oracle."""
+    if engine == "v1":
+        pytest.skip("run on the single-traversal engines")
+    import torch
+
+    blob, offs, nf = synth.keys(3)
+    corpus, _ = synth.corpus(3, blob, offs, nf, n_bytes=1 << 28)
+    doc = np.array([0, corpus.size], dtype=np.uint64)
+    g = AC.compile_packed(blob, offs)
+    o = orc.AC.compile_packed(blob, offs)
+    oh, _ = o.match_batch(corpus, doc, cap=corpus.size // 16)
+    dc = torch.from_numpy(corpus).cuda()
+    dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+    out = torch.zeros((len(oh) + 16, 3), dtype=torch.int32, device="cuda")
+    dho = torch.zeros(2, dtype=torch.int64, device="cuda")
+    n = g.match_batch_device(dc, dd, out, dho)
+    assert n == len(oh)
+    assert out[:n].cpu().numpy().tobytes() == oh.tobytes()
+    assert dho.cpu().tolist() == [0, n]
+
+
+def test_sequence_longer_than_int32_is_rejected():
+    import ctypes as C
+
+    ac = AC.compile(["a"])
+    offs = np.array([0, 1 << 31], dtype=np.uint64)  # Int32 offsets (matcher.cr:3-5): one sequence < 2^31 bytes
+    t = np.zeros(16, dtype=np.uint8)
+    n = C.c_uint64(0)
+    rc = N.lib().aha_ac_match_batch(ac._h, t.ctypes.data, offs.ctypes.data, 1, None, None, 0, None, C.byref(n))
+    assert rc == N.AHA_E_TOO_LONG

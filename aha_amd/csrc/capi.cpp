@@ -46,11 +46,12 @@ struct aha_ac {
   uint32_t v2_lds_slots = 0;
   uint32_t v2_grid = 0;
   uint32_t v2_bpc = 1;
+  bool direct_overflowed = false;  // a chunk's event region overflowed once: keep to the slab pipeline
   struct Buf {
     void *p = nullptr;
     size_t bytes = 0;
   };
-  Buf v2buf[16];
+  Buf v2buf[24];
   Buf hostbuf[4];  // device staging of the host-buffer entry points (corpus, doc offsets, doc hit offsets, hits)
   unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
   std::string err;
@@ -239,7 +240,7 @@ int32_t v2_reserve(aha_ac *ac, int i, size_t bytes) {
 }
 
 // returns AHA_OK, an error, or +1 when the caller must fall back to the two-pass engine
-int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
+int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, bool allow_direct) {
   const uint64_t N = M1.n_bytes;
   const uint32_t Lmax = ac->aut.max_key_len;
   uint64_t s_min = std::max<uint64_t>(64, ((8ull * Lmax + 63) / 64) * 64);
@@ -263,17 +264,26 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   M.out = M1.out;
   M.cap = M1.cap;
   M.doc_hit_off = M1.doc_hit_off;
+  // plain mode (byte offsets, no separator filter, no boundary filter): per-chunk event regions, no sort
+  const char *de = getenv("AHA_DIRECT");
+  bool direct = !(de && strcmp(de, "0") == 0) && !M.chars && !M.sep && ac->flt.d0 == 0 && allow_direct &&
+                !ac->direct_overflowed;
   const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
-  M.ev_cap = ((M1.cap + waves * kV2Slab + kV2Slab) / kV2Slab) * kV2Slab;
+  M.direct = direct ? 1 : 0;
+  M.ev_stride = (uint32_t)std::max<uint64_t>(16, S / 4);
+  M.ev_cap = direct ? 0 : ((M1.cap + waves * kV2Slab + kV2Slab) / kV2Slab) * kV2Slab;
   const uint64_t n_slabs = M.ev_cap / kV2Slab + 2;
   const uint64_t n_blk = std::max<uint64_t>((M.n_chunks + 255) / 256, (M.ev_cap + 255) / 256) + 2;
+  const uint64_t n_reg = direct ? M.n_chunks * M.ev_stride : 0;
   int32_t rc;
-  size_t sizes[16] = {M.ev_cap * 16,      M.ev_cap * 16,      M.ev_cap * 4,     n_slabs * 4,
+  size_t sizes[24] = {M.ev_cap * 16,      M.ev_cap * 16,      M.ev_cap * 4,     direct ? 0 : n_slabs * 4,
                       M.n_chunks * 4,     (M.n_docs + 1) * 4, M.n_chunks * 8,   n_blk * 8,
                       n_blk * 8,          16 * 8,             M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
                       M.chars ? M.n_chunks * 4 : 0, M.chars ? M.n_chunks * 4 : 0, M.chars ? (M.n_docs + 1) * 4 : 0,
-                      M.chars ? M.n_chunks * 8 : 0};
-  for (int i = 0; i < 16; i++)
+                      M.chars ? M.n_chunks * 8 : 0,
+                      n_reg * 8,          n_reg * 4,          direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
+                      0, 0, 0, 0};
+  for (int i = 0; i < 24; i++)
     if (sizes[i] && (rc = v2_reserve(ac, i, sizes[i]))) return rc;
   M.ev = (uint4 *)ac->v2buf[0].p;
   M.sorted_ev = (uint4 *)ac->v2buf[1].p;
@@ -292,6 +302,10 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   M.chunk_doc0 = (uint32_t *)ac->v2buf[13].p;
   M.doc_lead_rank = (uint32_t *)ac->v2buf[14].p;
   M.lead_base = (uint64_t *)ac->v2buf[15].p;
+  M.evd = (uint2 *)ac->v2buf[16].p;
+  M.evoff = (uint32_t *)ac->v2buf[17].p;
+  M.chunk_hits = (uint32_t *)ac->v2buf[18].p;
+  M.hit_base = (uint64_t *)ac->v2buf[19].p;
   if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
 
   const bool prof = ac->profiling && ac->ev_ready;
@@ -302,11 +316,16 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
   v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
-  v2_launch_chunk_scan(M, s);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
-  v2_launch_sort(ac->dev, M, M.ev_cap, s);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[3], s));
-  v2_launch_expand(ac->dev, M, M.ev_cap, s);
+  if (direct) {
+    if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
+    v2_launch_direct_post(ac->dev, M, s, prof ? (void *)ac->ev[3] : nullptr);
+  } else {
+    v2_launch_chunk_scan(M, s);
+    if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
+    v2_launch_sort(ac->dev, M, M.ev_cap, s);
+    if (prof) HIPCHK(ac, hipEventRecord(ac->ev[3], s));
+    v2_launch_expand(ac->dev, M, M.ev_cap, s);
+  }
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[4], s));
   HIPCHK(ac, hipGetLastError());
   HIPCHK(ac, hipMemcpyAsync(ac->h_v2, ac->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
@@ -317,6 +336,10 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
       fprintf(stderr, "[aha stats] fast iters %llu (lanes/iter %.1f, cyc/iter %.0f) burst iters %llu (lanes/iter %.1f, cyc/iter %.0f)\n",
               d[0], d[0] ? (double)d[1] / d[0] : 0.0, d[0] ? (double)d[4] / d[0] : 0.0, d[2],
               d[2] ? (double)d[3] / d[2] : 0.0, d[2] ? (double)d[5] / d[2] : 0.0);
+  }
+  if (ac->h_v2[1] == 2) {  // a chunk's event region overflowed (hit-dense input): slab pipeline from now on
+    ac->direct_overflowed = true;
+    return 2;
   }
   if (ac->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = ac->h_v2[2];
@@ -593,7 +616,8 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
   M.cap = cap;
   M.doc_hit_off = d_doc_hit_offsets;
   if (ac->v2_ok) {
-    rc = match_v2(ac, M, s, n_hits);
+    rc = match_v2(ac, M, s, n_hits, true);
+    if (rc == 2) rc = match_v2(ac, M, s, n_hits, false);  // hit-dense input: slab pipeline
     if (rc < 0) return rc;
     if (rc == AHA_OK) {
       if (*n_hits > cap) {

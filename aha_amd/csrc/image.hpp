@@ -95,6 +95,14 @@ struct V2Args {
   uint32_t *sorted_cnt;      // [ev_cap] hits per event
   uint64_t *totals;          // [0] hits [1] leads [2] events
   unsigned long long *dbg;   // optional [8] traversal statistics (AHA_DEBUG_STATS=1)
+  // direct event regions (plain mode): chunk c stores its events in order at evd[c * ev_stride + seq], so the
+  // post passes need no sort: count (wave per chunk) -> scan -> expand (wave per chunk)
+  int32_t direct;
+  uint32_t ev_stride;        // events a chunk may store (S / 4); more -> overflow flag, slab pipeline instead
+  uint2 *evd;                // [n_chunks * ev_stride] {state base (compact) or key id, end offset in the document}
+  uint32_t *evoff;           // [n_chunks * ev_stride] hits of the chunk before this event
+  uint32_t *chunk_hits;      // [n_chunks]
+  uint64_t *hit_base;        // [n_chunks] exclusive scan of chunk_hits
   aha_hit *out;
   uint64_t cap;
   uint64_t *doc_hit_off;
@@ -107,6 +115,8 @@ void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *s
 void v2_launch_chunk_scan(const V2Args &M, void *stream);
 void v2_launch_sort(const DevAut &A, const V2Args &M, uint64_t n_records, void *stream);
 void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events, void *stream);
+// direct pipeline (plain mode): per-chunk hit counts, their scan, expansion and document offsets
+void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid);
 
 // launchers (kernels.hip)
 void launch_count(const DevAut &A, const MatchArgs &M, void *stream);

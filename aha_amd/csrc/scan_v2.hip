@@ -147,6 +147,8 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t chunk = tile * kV2Threads + threadIdx.x;
     p_x = (uint32_t)chunk;
+    uint2 *evreg = M.direct ? M.evd + chunk * M.ev_stride : nullptr;  // this chunk's event region (plain mode)
+    const uint32_t ev_stride = M.ev_stride;
     const bool live = chunk < M.n_chunks;
     const int64_t a = (int64_t)chunk * S;
     const int64_t e = live ? min(a + S, N) : a;
@@ -278,16 +280,27 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
           en_keep = S_::payload(ex);
         }
         if (__any(ev)) {
-          if (__any(ev && pev)) flush_events();
-          if (ev) {
-            // rel was already advanced: the hit ended at rel-1
-            const uint32_t last = (rel == nb_rel) ? kLastFlag : 0u;
-            pev = true;
-            p_y = (seq << 16) | last | (chunk_rel0 + rel - 1u);
-            p_z = (uint32_t)(docrel + (int32_t)rel);
-            p_w = en_keep;
-            p_aux = (lc << 1) | lc_exact;
-            seq++;
+          if (M.direct) {
+            // plain mode: the chunk's events go, in order, to its own region -- no compaction, no sort
+            if (ev) {
+              if (seq < ev_stride)
+                evreg[seq] = make_uint2(en_keep, (uint32_t)(docrel + (int32_t)rel));
+              else
+                M.cursor[1] = 2ull;  // region full: the host repeats the call with the slab pipeline
+              seq++;
+            }
+          } else {
+            if (__any(ev && pev)) flush_events();
+            if (ev) {
+              // rel was already advanced: the hit ended at rel-1
+              const uint32_t last = (rel == nb_rel) ? kLastFlag : 0u;
+              pev = true;
+              p_y = (seq << 16) | last | (chunk_rel0 + rel - 1u);
+              p_z = (uint32_t)(docrel + (int32_t)rel);
+              p_w = en_keep;
+              p_aux = (lc << 1) | lc_exact;
+              seq++;
+            }
           }
         }
       }
@@ -998,6 +1011,116 @@ __global__ __launch_bounds__(256) void k2_doc_offsets(DevAut A, V2Args M) {
 
 }  // namespace
 
+// ------------------------------------------------ direct pipeline (plain mode)
+// One wave per chunk region: hits per chunk (and the key of every event, written back over the
+// state base in the compact format so that the expansion needs no second end_key lookup).
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void k2d_count(DevAut A, V2Args M) {
+  if (M.cursor[1]) return;
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const uint64_t n_waves = ((uint64_t)gridDim.x * 256) >> 6;
+  for (uint64_t c = wave; c < M.n_chunks; c += n_waves) {
+    const uint32_t n = M.ev_cnt[c];
+    uint2 *reg = M.evd + c * M.ev_stride;
+    uint32_t sum = 0;
+    for (uint32_t i = lane; i < n; i += 64) {
+      uint32_t key = reg[i].x;
+      if (COMPACT) {
+        key = (uint32_t)A.end_key[key];
+        reg[i].x = key;
+      }
+      sum += A.key_cnt[key];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if (lane == 0) M.chunk_hits[c] = sum;
+  }
+}
+
+// One wave (= one 64-thread workgroup) per chunk: in-wave scan of hits per event, chains
+// assembled in LDS and streamed out with coalesced stores.
+constexpr uint32_t kWaveStage = 1024;  // hits staged per batch of 64 events (12 KiB of LDS)
+
+__global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
+  __shared__ uint32_t hbuf[kWaveStage * 3];
+  if (M.cursor[1]) return;
+  const int lane = threadIdx.x;
+  for (uint64_t c = blockIdx.x; c < M.n_chunks; c += gridDim.x) {
+    const uint32_t n = M.ev_cnt[c];
+    if (n == 0) continue;
+    const uint2 *reg = M.evd + c * M.ev_stride;
+    uint32_t *eoff = M.evoff + c * M.ev_stride;
+    const uint64_t base = M.hit_base[c];
+    uint32_t run = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool live = i < n;
+      uint2 rec = make_uint2(0, 0);
+      uint32_t cnt = 0;
+      if (live) {
+        rec = reg[i];
+        cnt = A.key_cnt[rec.x];
+      }
+      const uint32_t incl = wave_incl_scan(cnt);
+      const uint32_t tot = __shfl(incl, 63, 64);
+      const uint32_t off = incl - cnt;
+      if (live) eoff[i] = run + off;
+      if (tot <= kWaveStage) {
+        if (live) {
+          uint32_t w = off * 3;
+          int32_t k = (int32_t)rec.x;
+          do {  // fetch (ac.cr:265-278): own key, then the output chain
+            const uint2 ln = A.key_ln[k];
+            hbuf[w] = rec.y - ln.x;  // Hit(idx-len+1, idx+1, value) ac.cr:271-273
+            hbuf[w + 1] = rec.y;
+            hbuf[w + 2] = (uint32_t)k;
+            w += 3;
+            k = (int32_t)ln.y;
+          } while (k >= 0);
+        }
+        __syncthreads();
+        const uint64_t first = base + run;
+        const uint64_t room = first < M.cap ? M.cap - first : 0;
+        const uint32_t nd = (uint32_t)(tot < room ? tot : room) * 3;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(M.out + first);
+        for (uint32_t j = lane; j < nd; j += 64) dst[j] = hbuf[j];
+        __syncthreads();
+      } else if (live) {
+        uint64_t idx = base + run + off;
+        int32_t k = (int32_t)rec.x;
+        do {
+          const uint2 ln = A.key_ln[k];
+          if (idx < M.cap) {
+            aha_hit h;
+            h.start = (int32_t)rec.y - (int32_t)ln.x;
+            h.end = (int32_t)rec.y;
+            h.value = k;
+            M.out[idx] = h;
+          }
+          idx++;
+          k = (int32_t)ln.y;
+        } while (k >= 0);
+      }
+      run += tot;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k2d_doc_offsets(V2Args M) {
+  if (M.cursor[1] || !M.doc_hit_off) return;
+  const uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (d > M.n_docs) return;
+  const uint64_t q = M.doc_off[d];
+  uint64_t r = M.totals[0];
+  if (q < M.n_bytes) {
+    const uint64_t c = q / M.S;
+    const uint32_t rank = M.doc_ev_rank[d];
+    r = M.hit_base[c] + (rank < M.ev_cnt[c] ? M.evoff[c * M.ev_stride + rank] : M.chunk_hits[c]);
+  }
+  M.doc_hit_off[d] = r;
+}
+
 // ---------------------------------------------------------------- launchers
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact, uint32_t bloom_words) {
   // filter mode (bloom_words != 0) keeps the 16-byte-column window, the plain walk the padded rows
@@ -1106,6 +1229,28 @@ void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events_hint, 
       hipLaunchKernelGGL(k2_doc_offsets<true>, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, A, M);
     else
       hipLaunchKernelGGL(k2_doc_offsets<false>, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, A, M);
+  }
+}
+
+void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid) {
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t gw = grid_for(M.n_chunks, 4, 8192);  // 4 waves (chunks) per 256-thread block
+  if (A.compact)
+    hipLaunchKernelGGL(k2d_count<true>, dim3(gw), dim3(256), 0, s, A, M);
+  else
+    hipLaunchKernelGGL(k2d_count<false>, dim3(gw), dim3(256), 0, s, A, M);
+  const uint32_t g = grid_for(M.n_chunks, 256, 4096);
+  const unsigned long long *abortf = (const unsigned long long *)(M.cursor + 1);
+  hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.chunk_hits, (const uint64_t *)nullptr, M.n_chunks,
+                     M.blk_a, abortf);
+  hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_a, (const uint64_t *)nullptr, M.n_chunks,
+                     M.totals + 0, abortf);
+  hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.chunk_hits, M.n_chunks, M.blk_a, M.hit_base);
+  if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
+  hipLaunchKernelGGL(k2d_expand, dim3(grid_for(M.n_chunks, 1, 16384)), dim3(64), 0, s, A, M);
+  if (M.doc_hit_off) {
+    const uint64_t nd = M.n_docs + 1;
+    hipLaunchKernelGGL(k2d_doc_offsets, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, M);
   }
 }
 

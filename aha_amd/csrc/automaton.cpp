@@ -252,9 +252,28 @@ void place_states(const Automaton &a, Placement &p) {
     nfree[blk]--;
   };
 
+  // Placement order: level by level (BFS ids are grouped by depth), and inside a
+  // level the states with the most keys below them first.  Text that resembles the
+  // keys visits those states most, so the LDS prefix (and, deeper, the same cache
+  // lines) holds the rows that are probed most instead of the first labels.
+  std::vector<uint32_t> weight(S, 0), order(S);
+  for (uint32_t s = S; s-- > 0;) {
+    weight[s] += a.key_of[s] >= 0 ? 1u : 0u;
+    if (s) weight[a.parent[s]] += weight[s];
+  }
+  for (uint32_t s = 0; s < S; s++) order[s] = s;
+  for (uint32_t lo = 0; lo < S;) {
+    uint32_t hi = lo;
+    while (hi < S && a.depth[hi] == a.depth[lo]) hi++;
+    std::stable_sort(order.begin() + lo, order.begin() + hi,
+                     [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
+    lo = hi;
+  }
+
   uint32_t cur_depth = 0;
   for (uint32_t d = 0; d < kSegDepth + 2; d++) p.seg_start[d] = 0;
-  for (uint32_t s = 0; s < S; s++) {
+  for (uint32_t oi = 0; oi < S; oi++) {
+    const uint32_t s = order[oi];
     const unsigned nc = a.n_child[s];
     const uint8_t *labels = a.in_label.data() + a.first_child[s];
     if (a.depth[s] != cur_depth) {

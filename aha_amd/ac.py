@@ -128,6 +128,45 @@ class AC:
             raise AhaError(rc, msg, ek.value)
         return cls(h)
 
+    # -- AC#save(io) / AC.load(io): src/aha/ac.cr:45-60 (own container, see include/aha_hip.h) --
+    def to_bytes(self):
+        n = N.lib().aha_ac_save(self._h, None, 0)
+        if n < 0:
+            raise AhaError(int(n))
+        buf = np.zeros(int(n), dtype=np.uint8)
+        got = N.lib().aha_ac_save(self._h, _ptr(buf), int(n))
+        assert got == n
+        return buf.tobytes()
+
+    def save(self, io):
+        """io: a path or a binary file object."""
+        data = self.to_bytes()
+        if hasattr(io, "write"):
+            io.write(data)
+        else:
+            with open(io, "wb") as f:
+                f.write(data)
+
+    @classmethod
+    def from_bytes(cls, data, device=-1, host_only=False, force_wide=False):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        opts = N.aha_options()
+        opts.struct_size = C.sizeof(N.aha_options)
+        opts.device = device
+        opts.flags = (N.AHA_OPT_HOST_ONLY if host_only else 0) | (N.AHA_OPT_FORCE_WIDE if force_wide else 0)
+        h = C.c_void_p()
+        rc = N.lib().aha_ac_load(_ptr(buf), buf.size, C.byref(opts), C.byref(h))
+        if rc != N.AHA_OK:
+            raise AhaError(rc, "not an aha_hip automaton file" if rc == N.AHA_E_INVALID else None)
+        return cls(h)
+
+    @classmethod
+    def load(cls, io, **kw):
+        if hasattr(io, "read"):
+            return cls.from_bytes(io.read(), **kw)
+        with open(io, "rb") as f:
+            return cls.from_bytes(f.read(), **kw)
+
     def _check(self, rc):
         if rc != N.AHA_OK:
             msg = N.lib().aha_last_error(self._h).decode() or None

@@ -478,6 +478,65 @@ void aha_ac_free(aha_ac *ac) {
   delete ac;
 }
 
+// ---- save / load: the library's own container (see include/aha_hip.h) ----------
+namespace {
+constexpr char kSaveMagic[8] = {'A', 'H', 'A', 'H', 'I', 'P', '0', '1'};
+inline uint64_t fnv1a(const uint8_t *p, uint64_t n) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (uint64_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+  return h;
+}
+}  // namespace
+
+int64_t aha_ac_save(const aha_ac *ac, void *buf, uint64_t cap_bytes) {
+  if (!ac) return AHA_E_INVALID;
+  const uint32_t K = ac->aut.n_keys;
+  const uint64_t blob_bytes = ac->aut.blob.size();
+  const uint64_t need = 8 + 4 + 4 + 8 + 8ull * (K + 1) + blob_bytes + 8;
+  if (!buf || cap_bytes < need) return (int64_t)need;
+  uint8_t *w = static_cast<uint8_t *>(buf);
+  uint64_t o = 0;
+  auto put = [&](const void *src, uint64_t n) {
+    if (n) memcpy(w + o, src, n);
+    o += n;
+  };
+  const uint32_t format = 1;
+  put(kSaveMagic, 8);
+  put(&format, 4);
+  put(&K, 4);
+  put(&blob_bytes, 8);
+  put(ac->aut.offs.data(), 8ull * (K + 1));
+  put(ac->aut.blob.data(), blob_bytes);
+  const uint64_t h = fnv1a(w, o);
+  put(&h, 8);
+  return (int64_t)o;
+}
+
+int32_t aha_ac_load(const void *buf, uint64_t n_bytes, const aha_options *opts, aha_ac **out) {
+  if (!buf || !out) return AHA_E_INVALID;
+  *out = nullptr;
+  const uint8_t *r = static_cast<const uint8_t *>(buf);
+  if (n_bytes < 8 + 4 + 4 + 8 + 8 + 8 || memcmp(r, kSaveMagic, 8) != 0) return AHA_E_INVALID;
+  uint32_t format, K;
+  uint64_t blob_bytes;
+  memcpy(&format, r + 8, 4);
+  memcpy(&K, r + 12, 4);
+  memcpy(&blob_bytes, r + 16, 8);
+  if (format != 1) return AHA_E_INVALID;
+  const uint64_t head = 24, offs_bytes = 8ull * ((uint64_t)K + 1);
+  if (blob_bytes > n_bytes || offs_bytes > n_bytes || head + offs_bytes + blob_bytes + 8 != n_bytes)
+    return AHA_E_INVALID;
+  uint64_t h;
+  memcpy(&h, r + n_bytes - 8, 8);
+  if (h != fnv1a(r, n_bytes - 8)) return AHA_E_INVALID;
+  std::vector<uint64_t> offs((size_t)K + 1);
+  memcpy(offs.data(), r + head, offs_bytes);
+  if (offs[0] != 0 || offs[K] != blob_bytes) return AHA_E_INVALID;
+  for (uint32_t k = 0; k < K; k++)
+    if (offs[k + 1] < offs[k]) return AHA_E_INVALID;
+  return aha_ac_compile(r + head + offs_bytes, offs.data(), K, opts, out, nullptr);
+}
+
 int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   if (!ac || !info) return AHA_E_INVALID;
   memset(info, 0, sizeof(*info));

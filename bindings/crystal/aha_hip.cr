@@ -48,6 +48,8 @@ lib LibAhaHip
   fun aha_ac_free(ac : Ac) : Void
   fun aha_ac_key(ac : Ac, id : Int32, buf : UInt8*, cap : Int32) : Int32
   fun aha_ac_id(ac : Ac, key : UInt8*, len : Int32) : Int32
+  fun aha_ac_save(ac : Ac, buf : Void*, cap_bytes : UInt64) : Int64
+  fun aha_ac_load(buf : Void*, n_bytes : UInt64, opts : Options*, out : Ac*) : Int32
   fun aha_ac_match_bytes(ac : Ac, text : UInt8*, n : UInt64, params : MatchParams*,
                          out : Hit*, cap : UInt64, n_hits : UInt64*) : Int32
   fun aha_ac_match_batch(ac : Ac, corpus : UInt8*, doc_offsets : UInt64*, n_docs : UInt64,
@@ -135,6 +137,22 @@ module Aha
 
     def match(seq : String, sep : BitArray, &block)
       run(seq.to_slice, true, sep) { |hit| yield hit }
+    end
+
+    # AC#to_io / AC.from_io (src/aha/ac.cr:45-60) on the library's own container
+    def to_io(io : IO, format : IO::ByteFormat = IO::ByteFormat::LittleEndian)
+      n = LibAhaHip.aha_ac_save(@handle, Pointer(Void).null, 0_u64)
+      raise "save failed" if n < 0
+      buf = Bytes.new(n)
+      LibAhaHip.aha_ac_save(@handle, buf.to_unsafe.as(Void*), n.to_u64)
+      io.write buf
+    end
+
+    def self.from_io(io : IO, format : IO::ByteFormat = IO::ByteFormat::LittleEndian) : self
+      data = io.gets_to_end.to_slice
+      rc = LibAhaHip.aha_ac_load(data.to_unsafe.as(Void*), data.size.to_u64, Pointer(LibAhaHip::Options).null, out h)
+      raise String.new(LibAhaHip.aha_strerror(rc)) if rc != 0
+      new(h)
     end
 
     def [](sid : Int) : String

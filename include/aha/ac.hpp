@@ -111,6 +111,23 @@ class AC {
     if (r < 0) throw Error(r, "Index out of bounds");
     return r;
   }
+  // AC#save / AC.load (src/aha/ac.cr:45-60): the library's own container, see aha_hip.h
+  std::vector<uint8_t> to_bytes() const {
+    int64_t n = aha_ac_save(h_, nullptr, 0);
+    if (n < 0) throw Error((int32_t)n, aha_strerror((int32_t)n));
+    std::vector<uint8_t> v((size_t)n);
+    aha_ac_save(h_, v.data(), (uint64_t)n);
+    return v;
+  }
+  static AC from_bytes(const std::vector<uint8_t> &data, int device = -1) {
+    aha_options o{};
+    o.struct_size = sizeof(o);
+    o.device = device;
+    aha_ac *h = nullptr;
+    int32_t rc = aha_ac_load(data.data(), data.size(), &o, &h);
+    if (rc != AHA_OK) throw Error(rc, aha_strerror(rc));
+    return AC(h);
+  }
   aha_ac *handle() const { return h_; }
 
  private:

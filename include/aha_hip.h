@@ -166,6 +166,21 @@ enum {
 };
 int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_bytes);
 
+/* AC#to_io / AC.from_io -- src/aha/ac.cr:45-60 (`save`/`load` in the reference's
+ * README).  The reference's on-disk framing goes through the un-vendored
+ * `super_io` shard and no reference test reads a loaded automaton back
+ * (parity unpinned), so this is the library's OWN
+ * container, not the Crystal byte stream: little endian
+ *   "AHAHIP01" | u32 format=1 | u32 K | u64 blob_bytes | u64 offs[K+1] | blob |
+ *   u64 FNV-1a of everything before it.
+ * It stores the keys in `compile` order; aha_ac_load re-derives the automaton
+ * (deterministic, same key ids), so a file written by one build loads in any
+ * later one.  aha_ac_save returns the size in bytes (cap_bytes = 0 sizes the
+ * buffer) or <0; aha_ac_load returns AHA_E_INVALID for a truncated/corrupt
+ * buffer, else whatever aha_ac_compile returns. */
+int64_t aha_ac_save(const aha_ac *ac, void *buf, uint64_t cap_bytes);
+int32_t aha_ac_load(const void *buf, uint64_t n_bytes, const aha_options *opts, aha_ac **out);
+
 /* Enable/disable HIP-event timing of device matches on this handle. */
 int32_t aha_ac_set_profiling(aha_ac *ac, int32_t enabled);
 int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t);

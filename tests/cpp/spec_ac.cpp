@@ -35,6 +35,13 @@ int main() {
       std::printf("FAIL []\n");
     }
   }
+  {  // it "ac save load"  spec/ac_spec.cr:14-23 (here the LOADED automaton is the one matched)
+    auto matcher = aha::AC::compile({"我", "我是", "是中"});
+    auto loaded = aha::AC::from_bytes(matcher.to_bytes());
+    std::vector<Pair> matched;
+    loaded.match_string("我是中国人", [&](const aha::Hit &hit) { matched.push_back({hit.end, hit.value}); });
+    expect("ac save load", matched, {{1, 0}, {2, 1}, {3, 2}});
+  }
   {  // it "ac with sep"  spec/ac_spec.cr:25-34
     auto matcher = aha::AC::compile({"a", "aa"});
     aha::BitArray sep(256);

@@ -57,6 +57,20 @@ def test_spec_ac_char_array():  # spec/ac_spec.cr:36-43
     assert matched == [(1, 0), (2, 1), (3, 2)]
 
 
+def test_spec_ac_save_load(tmp_path):  # spec/ac_spec.cr:14-23 -- and, unlike the spec, the LOADED automaton is matched
+    matcher = AC.compile(["我", "我是", "是中"])
+    matcher.save(str(tmp_path / "aha.bin"))
+    loaded = AC.load(str(tmp_path / "aha.bin"))
+    matched = [(hit.end, hit.value) for hit in loaded.match("我是中国人")]
+    assert matched == [(1, 0), (2, 1), (3, 2)]
+    rng = random.Random(5)
+    keys = rand_keys(rng, 300, b"abc", 1, 7)
+    a = AC.compile(keys)
+    b = AC.from_bytes(a.to_bytes())
+    text = bytes(rng.choice(b"abc") for _ in range(5000))
+    assert gpu_list(b.match_array(text)) == gpu_list(a.match_array(text)) == as_list(orc.AC(keys).match(text))
+
+
 @pytest.mark.parametrize("kat", KATS["ac_match"], ids=lambda k: k["cite"][:24] + k["api"])
 def test_reference_kats(kat):
     ac = AC.compile(kat["keys"])

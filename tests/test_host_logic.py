@@ -203,3 +203,41 @@ def test_filter_mode_on_headline_shape():
     s = sim.stats
     # the point of the filter: HBM probes per byte drop by an order of magnitude
     assert s["global"] / corpus.size < 0.25, s
+
+
+# ---- save / load (src/aha/ac.cr:45-60; own container) -----------------
+def test_save_load_round_trip_keeps_ids_and_image(tmp_path):
+    keys = ["我", "我是", "是中", "abc", "bcd", "c"]
+    a = AC.compile(keys, host_only=True)
+    data = a.to_bytes()
+    assert data[:8] == b"AHAHIP01"
+    b = AC.from_bytes(data, host_only=True)
+    assert b.info["n_keys"] == len(keys)
+    for i, k in enumerate(keys):
+        assert b[i] == k and b[k] == i
+    for which, dt in ((0, np.uint32), (1, np.int32), (2, np.uint32), (3, np.uint32)):
+        assert np.array_equal(a.export(which, dt), b.export(which, dt))
+    path = tmp_path / "ac.bin"
+    a.save(str(path))
+    c = AC.load(str(path), host_only=True)
+    assert c.to_bytes() == data
+    with open(path, "rb") as f:
+        assert AC.load(f, host_only=True).to_bytes() == data
+
+
+def test_load_rejects_corrupt_or_truncated_input():
+    data = bytearray(AC.compile(["ab", "bc"], host_only=True).to_bytes())
+    for bad in (bytes(data[:-1]), bytes(data[:10]), b"", b"NOTAHA00" + bytes(data[8:])):
+        with pytest.raises(AhaError) as e:
+            AC.from_bytes(bad, host_only=True)
+        assert e.value.code == N.AHA_E_INVALID
+    data[30] ^= 0x40  # flip one bit of the payload: the checksum must catch it
+    with pytest.raises(AhaError) as e:
+        AC.from_bytes(bytes(data), host_only=True)
+    assert e.value.code == N.AHA_E_INVALID
+
+
+def test_save_load_empty_key_set():
+    a = AC.compile([], host_only=True)
+    b = AC.from_bytes(a.to_bytes(), host_only=True)
+    assert b.info["n_keys"] == 0

@@ -1,0 +1,40 @@
+"""Turns gpurun_out/<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/."""
+import collections, csv, glob, json, os, re, shutil, sys
+
+tag, rnd = sys.argv[1], sys.argv[2]  # e.g. prof_b r01b
+src = os.path.join("gpurun_out", tag)
+note = ("rocprofv3 --pmc, separate passes with --kernel-trace only, over `python3 bench.py --steps 2 --warmup 1 "
+        "--no-cpu-baseline` (cfg3: 100k keys, 1 GiB); averages per launch. FETCH_SIZE/WRITE_SIZE raw units are KB; "
+        "gfx950 FETCH_SIZE can under-report wide coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM) -- "
+        "per-lane 16 B strided loads are uncalibrated, so raw values are quoted. SQ_* cycle counters are quad-cycles.")
+out = {"_note": note, "config": 3, "bytes_per_gpu": 1 << 30, "kernels": {}}
+
+
+def short(k):
+    m = re.search(r"(k2?d?_[a-z_]+)", k)
+    return m.group(1) if m else None
+
+
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if "aha::" not in r["Kernel_Name"]:
+            continue
+        k = short(r["Kernel_Name"])
+        if k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in agg.items():
+        for c, v in cs.items():
+            out["kernels"].setdefault(k, {})[c] = round(sum(v) / len(v), 1)
+for k, d in out["kernels"].items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["hbm_bytes_per_launch"] = int((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
+json.dump(out, open(f"profiles/{rnd}_pmc.json", "w"), indent=1)
+json.dump(out, open("profiles/pmc_traffic_latest.json", "w"), indent=1)
+shutil.copy(os.path.join(src, "bench.json"), f"profiles/{rnd}_bench_cfg3.json")
+shutil.copy(os.path.join(src, "bench_under_rocprof.json"), f"profiles/{rnd}_bench_under_rocprof.json")
+st = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+shutil.copy(st[0], f"profiles/{rnd}_rocprofv3_kernel_stats.csv")
+b = json.load(open(os.path.join(src, "bench.json")))
+print(b["value"], b["m_hits_per_s"], b["roofline"], b["cpu_baseline"])
+print(out["kernels"].get("k2_traverse"))

@@ -68,7 +68,7 @@ def test_spec_ac_save_load(tmp_path):  # spec/ac_spec.cr:14-23 -- and, unlike th
     a = AC.compile(keys)
     b = AC.from_bytes(a.to_bytes())
     text = bytes(rng.choice(b"abc") for _ in range(5000))
-    assert gpu_list(b.match_array(text)) == gpu_list(a.match_array(text)) == as_list(orc.AC(keys).match(text))
+    assert gpu_list(b.match_array(text)) == gpu_list(a.match_array(text)) == as_list(orc.AC.compile(keys).match(text))
 
 
 @pytest.mark.parametrize("kat", KATS["ac_match"], ids=lambda k: k["cite"][:24] + k["api"])

@@ -26,6 +26,7 @@ AHA_E_TOO_LARGE = -11
 
 AHA_OPT_HOST_ONLY = 1
 AHA_OPT_FORCE_WIDE = 2
+AHA_IMG_SLOTS, AHA_IMG_END_KEY, AHA_IMG_KEY_LN, AHA_IMG_KEY_CNT, AHA_IMG_KEY_KC = 0, 1, 2, 3, 4
 
 
 class aha_options(C.Structure):
@@ -71,6 +72,8 @@ SIGNATURES = {
     "aha_ac_match_batch_device": (_i32, [_vp, _vp, _vp, _u64, _u64, C.POINTER(aha_match_params), _vp, _u64,
                                          _vp, C.POINTER(_u64), _vp]),
     "aha_ac_export": (C.c_int64, [_vp, _i32, _vp, _u64]),
+    "aha_ac_hits_pack_device": (_i32, [_vp, _vp, _u64, _vp, _vp]),
+    "aha_ac_hits_unpack_device": (_i32, [_vp, _vp, _u64, _i32, _vp, _vp]),
     "aha_ac_save": (C.c_int64, [_vp, _vp, _u64]),
     "aha_ac_load": (_i32, [_vp, _u64, C.POINTER(aha_options), C.POINTER(_vp)]),
     "aha_ac_set_profiling": (_i32, [_vp, _i32]),

@@ -269,6 +269,33 @@ class AC:
         self._check(rc)
         return int(n.value)
 
+    # -- exchange format of the multi-GPU all-gatherv: {end, value} pairs <-> Hit triples ------------
+    def hits_pack_device(self, hits, n, pairs, stream=None):
+        """hits [>=n,3] int32 -> pairs [>=n,2] int32, both on the handle's device (asynchronous)."""
+        import torch
+
+        assert hits.is_cuda and pairs.is_cuda and hits.dtype == pairs.dtype == torch.int32
+        assert hits.is_contiguous() and pairs.is_contiguous() and hits.numel() >= 3 * n and pairs.numel() >= 2 * n
+        s = stream if stream is not None else torch.cuda.current_stream(hits.device).cuda_stream
+        self._check(N.lib().aha_ac_hits_pack_device(self._h, hits.data_ptr(), n, pairs.data_ptr(), C.c_void_p(s)))
+
+    def hits_unpack_device(self, pairs, n, hits, chars=False, stream=None):
+        """pairs [>=n,2] int32 -> hits [>=n,3] int32 (start = end - key length), asynchronous."""
+        import torch
+
+        assert hits.is_cuda and pairs.is_cuda and hits.dtype == pairs.dtype == torch.int32
+        assert hits.is_contiguous() and pairs.is_contiguous() and hits.numel() >= 3 * n and pairs.numel() >= 2 * n
+        s = stream if stream is not None else torch.cuda.current_stream(hits.device).cuda_stream
+        self._check(N.lib().aha_ac_hits_unpack_device(self._h, pairs.data_ptr(), n, 1 if chars else 0,
+                                                      hits.data_ptr(), C.c_void_p(s)))
+
+    def key_lengths(self, chars=False):
+        """Length of every key in bytes (or in chars): Hit#end - Hit#start of its hits."""
+        ln = self.export(N.AHA_IMG_KEY_LN, np.uint32).reshape(-1, 2)[:, 0].astype(np.int32)
+        if chars:
+            return self.export(N.AHA_IMG_KEY_KC, np.uint32).astype(np.int32) + 1
+        return ln
+
     def export(self, which, dtype):
         """One array of the automaton image (data; host-logic tests, debugging)."""
         n = N.lib().aha_ac_export(self._h, which, None, 0)

@@ -478,6 +478,23 @@ void aha_ac_free(aha_ac *ac) {
   delete ac;
 }
 
+int32_t aha_ac_hits_pack_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, int32_t *d_pairs, void *stream) {
+  if (!ac || ac->device < 0 || (n && (!d_hits || !d_pairs))) return AHA_E_INVALID;
+  DeviceGuard g(ac->device);
+  launch_hits_pack(reinterpret_cast<const int32_t *>(d_hits), n, d_pairs, stream);
+  HIPCHK(ac, hipGetLastError());
+  return AHA_OK;
+}
+
+int32_t aha_ac_hits_unpack_device(aha_ac *ac, const int32_t *d_pairs, uint64_t n, int32_t char_offsets,
+                                  aha_hit *d_hits, void *stream) {
+  if (!ac || ac->device < 0 || (n && (!d_hits || !d_pairs))) return AHA_E_INVALID;
+  DeviceGuard g(ac->device);
+  launch_hits_unpack(ac->dev, d_pairs, n, char_offsets ? 1 : 0, reinterpret_cast<int32_t *>(d_hits), stream);
+  HIPCHK(ac, hipGetLastError());
+  return AHA_OK;
+}
+
 // ---- save / load: the library's own container (see include/aha_hip.h) ----------
 namespace {
 constexpr char kSaveMagic[8] = {'A', 'H', 'A', 'H', 'I', 'P', '0', '1'};

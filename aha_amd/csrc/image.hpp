@@ -118,6 +118,10 @@ void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events, void 
 // direct pipeline (plain mode): per-chunk hit counts, their scan, expansion and document offsets
 void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid);
 
+// exchange format of the multi-GPU all-gatherv (kernels.hip): {end, value} pairs <-> Hit triples
+void launch_hits_pack(const int32_t *hits, uint64_t n, int32_t *pairs, void *stream);
+void launch_hits_unpack(const DevAut &A, const int32_t *pairs, uint64_t n, int chars, int32_t *hits, void *stream);
+
 // launchers (kernels.hip)
 void launch_count(const DevAut &A, const MatchArgs &M, void *stream);
 void launch_scan_blocks(const MatchArgs &M, uint64_t n_blocks, void *stream);

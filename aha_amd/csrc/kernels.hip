@@ -16,6 +16,8 @@
 // the reference's order by count -> scan -> ordered write.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "automaton.hpp"
 #include "devcommon.hpp"
 #include "image.hpp"
@@ -212,6 +214,48 @@ __global__ __launch_bounds__(kBlock) void k_write(DevAut A, MatchArgs M) {
       dn++;
     }
   }
+}
+
+// ------------------------------------------------ exchange format (multi-GPU)
+// A hit's start is its end minus the key's length (ac.cr:270-272; in char
+// offsets: minus the key's UTF-8 lead bytes), so ranks exchange {end, value}
+// pairs -- 8 instead of 12 bytes per hit on the xGMI links -- and rebuild the
+// triples on arrival.  One thread per 32-bit word on both sides: fully
+// coalesced loads and stores.
+__global__ __launch_bounds__(256) void k_hits_pack(const int32_t *hits, uint64_t n_words, int32_t *pairs) {
+  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < n_words; j += (uint64_t)gridDim.x * 256) {
+    const uint64_t i = j >> 1;
+    pairs[j] = hits[i * 3 + 1 + (j & 1)];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_hits_unpack(const int32_t *pairs, uint64_t n_words, const uint2 *key_ln,
+                                                      const uint32_t *key_kc, int chars, int32_t *hits) {
+  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < n_words; j += (uint64_t)gridDim.x * 256) {
+    const uint64_t i = j / 3;
+    const uint32_t f = (uint32_t)(j - i * 3);
+    int32_t v = pairs[i * 2 + (f == 2 ? 1 : 0)];  // end for start/end, value for value
+    if (f == 0) {
+      const int32_t key = pairs[i * 2 + 1];
+      v -= chars ? (int32_t)key_kc[key] + 1 : (int32_t)key_ln[key].x;
+    }
+    hits[j] = v;
+  }
+}
+
+void launch_hits_pack(const int32_t *hits, uint64_t n, int32_t *pairs, void *stream) {
+  if (!n) return;
+  const uint64_t w = n * 2;
+  const uint32_t g = (uint32_t)std::min<uint64_t>((w + 255) / 256, 1u << 16);
+  hipLaunchKernelGGL(k_hits_pack, dim3(g), dim3(256), 0, (hipStream_t)stream, hits, w, pairs);
+}
+
+void launch_hits_unpack(const DevAut &A, const int32_t *pairs, uint64_t n, int chars, int32_t *hits, void *stream) {
+  if (!n) return;
+  const uint64_t w = n * 3;
+  const uint32_t g = (uint32_t)std::min<uint64_t>((w + 255) / 256, 1u << 16);
+  hipLaunchKernelGGL(k_hits_unpack, dim3(g), dim3(256), 0, (hipStream_t)stream, pairs, w, A.key_ln, A.key_kc, chars,
+                     hits);
 }
 
 // ---------------------------------------------------------------- launchers

@@ -14,7 +14,9 @@ RCCL over xGMI on ROCm; "gloo" in the CPU tests):
                         Send/Recv .. GroupEnd under RCCL).  On MI355X's fully
                         connected xGMI mesh every rank then drives its 7 links
                         at once (time ~ 12*max_r H_r / 153 GB/s), where a ring
-                        all-gather would be per-link bound.
+                        all-gather would be per-link bound.  packed=True puts
+                        {end, value} pairs on the links (8 B per hit; the start
+                        is end - key length) and rebuilds the triples on arrival.
 
 The automaton is replicated: every rank compiles the same keys (~0.2 s for
 100k keys), which is cheaper than broadcasting and needs no collective.
@@ -51,9 +53,17 @@ def local_shard(corpus, doc_offsets, rank, world):
 
 
 class HitGatherer:
-    """all-gatherv of hit triples ([n,3] int32 tensors) across ranks."""
+    """all-gatherv of hit triples ([n,3] int32 tensors) across ranks.
 
-    def __init__(self, dist, device, group=None):
+    packed=True (needs `ac`, the rank's automaton -- replicated, so every rank
+    holds the same key lengths): the payload on the links is {end, value} pairs,
+    8 instead of 12 bytes per hit, because Hit#start = Hit#end - len(key[value])
+    (src/aha/ac.cr:270-272); the triples are rebuilt on arrival
+    (aha_ac_hits_pack_device / _unpack_device on device tensors; plain torch
+    indexing on CPU tensors, i.e. in the gloo rehearsal).  xGMI links are the
+    scarce resource of the exchange (one link per peer), HBM bandwidth is not."""
+
+    def __init__(self, dist, device, group=None, ac=None, packed=False, chars=False):
         self.dist = dist
         self.device = device
         self.group = group
@@ -62,11 +72,55 @@ class HitGatherer:
         self._counts = torch.zeros(self.world, dtype=torch.int64, device=device)
         self._mine = torch.zeros(1, dtype=torch.int64, device=device)
         self._buf = None
+        self.packed = bool(packed)
+        self.chars = bool(chars)
+        self.ac = ac
+        if self.packed:
+            if ac is None:
+                raise ValueError("packed exchange needs the automaton (key lengths)")
+            self._klen = None if torch.device(device).type == "cuda" else torch.from_numpy(ac.key_lengths(chars))
+            self._pk = {}  # slot -> (send pairs, recv pairs)
+
+    # -- packed payload helpers --------------------------------------------------------
+    def _pack(self, hits, n, slot):
+        """hits[:n] -> contiguous [n,2] pairs in a per-slot send buffer."""
+        send, recv = self._pk.get(slot, (None, None))
+        if send is None or send.shape[0] < n:
+            send = torch.empty((n + n // 8 + 16, 2), dtype=torch.int32, device=hits.device)
+        self._pk[slot] = (send, recv)
+        if n:
+            if hits.is_cuda:
+                self.ac.hits_pack_device(hits, n, send)
+            else:
+                send[:n].copy_(hits[:n, 1:3])
+        return send
+
+    def _recv_pairs(self, total, slot):
+        send, recv = self._pk.get(slot, (None, None))
+        if recv is None or recv.shape[0] < total:
+            recv = torch.empty((total + total // 8 + 16, 2), dtype=torch.int32, device=self.device)
+        self._pk[slot] = (send, recv)
+        return recv
+
+    def _unpack(self, pairs, lo, hi, out):
+        """pairs[lo:hi] -> out[lo:hi] triples."""
+        n = hi - lo
+        if n <= 0:
+            return
+        if pairs.is_cuda:
+            self.ac.hits_unpack_device(pairs[lo:hi], n, out[lo:hi], chars=self.chars)
+        else:
+            p = pairs[lo:hi]
+            out[lo:hi, 1:3] = p
+            out[lo:hi, 0] = p[:, 0] - self._klen[p[:, 1].long()]
 
     def all_gatherv(self, hits, n):
         """hits: [cap,3] int32 on self.device, first n rows valid.  Returns
         (gathered [sum_n,3] view, counts list); rank r's hits start at
         sum(counts[:r]) -- global order = rank order (contiguous doc ranges)."""
+        if self.packed:
+            self.start(hits, n, slot=2)
+            return self.finish(2)
         dist = self.dist
         self._mine[0] = n
         dist.all_gather_into_tensor(self._counts, self._mine, group=self.group)
@@ -115,27 +169,35 @@ class HitGatherer:
         base = [0]
         for c in counts:
             base.append(base[-1] + c)
+        payload, landing = hits, buf
+        if self.packed:  # 8 B per hit on the links; triples rebuilt in finish()
+            payload = self._pack(hits, n, slot)
+            landing = self._recv_pairs(total, slot)
         ops = []
         for peer in range(self.world):
             if peer == self.rank:
                 continue
             if n:
-                ops.append(dist.P2POp(dist.isend, hits[:n], peer, group=self.group))
+                ops.append(dist.P2POp(dist.isend, payload[:n], peer, group=self.group))
             if counts[peer]:
-                ops.append(dist.P2POp(dist.irecv, buf[base[peer]:base[peer + 1]], peer, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, landing[base[peer]:base[peer + 1]], peer, group=self.group))
         if n:
             buf[base[self.rank]:base[self.rank + 1]].copy_(hits[:n])
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        self._pending[slot] = (reqs, buf, total, counts)
+        self._pending[slot] = (reqs, buf, total, counts, base)
         return counts
 
     def finish(self, slot=0):
         """Waits for the exchange issued with start(slot); returns (gathered, counts) or None."""
         if not hasattr(self, "_pending") or slot not in self._pending:
             return None
-        reqs, buf, total, counts = self._pending.pop(slot)
+        reqs, buf, total, counts, base = self._pending.pop(slot)
         for req in reqs:
             req.wait()
+        if self.packed:  # the received pairs of every peer -> triples at their final place
+            pairs = self._pk[slot][1]
+            self._unpack(pairs, 0, base[self.rank], buf)
+            self._unpack(pairs, base[self.rank + 1], total, buf)
         return buf[:total], counts
 
     def gather_doc_hit_offsets(self, dho, counts):

@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--chars", action="store_true", help="String overload (char offsets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
+    ap.add_argument("--exchange", default="packed", choices=["packed", "triples"],
+                    help="N>1 payload of the all-gatherv: {end,value} pairs (8 B per hit, triples rebuilt on arrival; "
+                         "default) or the 12-byte Hit triples themselves")
     ap.add_argument("--gather", default="allgatherv", choices=["allgatherv", "none"],
                     help="N>1: exchange hit buffers over RCCL inside the timed step")
     ap.add_argument("--no-overlap", action="store_true",
@@ -196,7 +199,7 @@ def main():
     if world > 1 and args.gather == "allgatherv":
         from aha_amd.distributed import HitGatherer
 
-        gather = HitGatherer(dist, cdev)
+        gather = HitGatherer(dist, cdev, ac=ac, packed=args.exchange == "packed", chars=args.chars)
 
     overlap = gather is not None and not args.no_overlap
     if overlap:
@@ -307,7 +310,7 @@ def main():
                        "keys": K, "bytes_per_gpu": n_bytes, "docs_per_gpu": D, "hits_per_gpu": n_hits,
                        "slots": info["n_slots"], "slot_bytes": info["slot_bytes"], "max_key_len": info["max_key_len"],
                        "offsets": "chars" if args.chars else "bytes",
-                       "parallelism": f"doc-sharded x{world}" + (f" + {args.gather}" if world > 1 else "")
+                       "parallelism": f"doc-sharded x{world}" + (f" + {args.gather} ({args.exchange})" if world > 1 else "")
                                       + (" (overlapped)" if overlap else "")},
             "roofline": roofline,
         }

@@ -152,6 +152,17 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
                                   aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets,
                                   uint64_t *n_hits, void *stream);
 
+/* Exchange format for the multi-GPU all-gatherv of hit buffers (SURVEY.md
+ * section 8 e): Hit#start = Hit#end - length of key[value] (src/aha/ac.cr:270-272;
+ * with char offsets: - number of chars of the key), so ranks send {end, value}
+ * pairs (8 B per hit instead of 12 on the xGMI links) and rebuild the triples
+ * on arrival.  All pointers are HBM on the handle's device; the calls are
+ * asynchronous on `stream`.  d_pairs holds 2*n int32, d_hits n triples. */
+int32_t aha_ac_hits_pack_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, int32_t *d_pairs,
+                                void *stream);
+int32_t aha_ac_hits_unpack_device(aha_ac *ac, const int32_t *d_pairs, uint64_t n, int32_t char_offsets,
+                                  aha_hit *d_hits, void *stream);
+
 /* Copies one array of the automaton image (as uploaded to HBM) into buf;
  * returns its size in bytes (call with cap_bytes = 0 to size the buffer).
  * Data only -- used by host-logic tests and debugging tools. */

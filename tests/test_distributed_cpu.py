@@ -39,6 +39,18 @@ def _worker(rank, world, port, keys_blob, keys_offs, corpus, doc, out_q):
             oh, oc = g.finish(slot)
             assert oc == counts and torch.equal(oh, allh)
         assert g.finish(0) is None
+        # packed exchange ({end, value} pairs on the wire, triples rebuilt on arrival): same result
+        from aha_amd import AC
+
+        pac = AC.compile_packed(keys_blob, keys_offs, host_only=True)
+        gp = HitGatherer(dist, torch.device("cpu"), ac=pac, packed=True)
+        ph, pc = gp.all_gatherv(t, len(hits))
+        assert pc == counts and torch.equal(ph, allh)
+        gp.start(t, len(hits), 0)
+        gp.start(t, len(hits), 1)
+        for slot in (0, 1):
+            oh, oc = gp.finish(slot)
+            assert oc == counts and torch.equal(oh, allh)
         alld = g.gather_doc_hit_offsets(torch.from_numpy(dho.astype(np.int64)), counts)
         out_q.put((rank, allh.numpy().copy(), alld.numpy().copy(), counts))
     finally:

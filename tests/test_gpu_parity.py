@@ -356,6 +356,33 @@ def test_single_large_document_vs_oracle(engine):
     assert dho.cpu().tolist() == [0, n]
 
 
+@pytest.mark.parametrize("chars", [False, True])
+def test_exchange_pairs_round_trip(chars):
+    """{end, value} pairs <-> Hit triples (aha_ac_hits_pack_device / _unpack_device): the multi-GPU payload."""
+    import torch
+
+    rng = random.Random(11)
+    alphabet = ["a", "b", "我", "是", "ж"]
+    keys = sorted({"".join(rng.choice(alphabet) for _ in range(rng.randint(1, 5))) for _ in range(200)})
+    text = "".join(rng.choice(alphabet) for _ in range(20000))
+    ac = AC.compile(keys)
+    hits = ac.match_array(text, chars=chars)
+    assert len(hits) > 1000
+    ref = as_list(orc.AC.compile(keys).match(text, chars=chars))
+    assert gpu_list(hits) == ref
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(hits.view(np.int32).reshape(-1, 3).copy()).to(dev)
+    n = t.shape[0]
+    pairs = torch.zeros((n + 7, 2), dtype=torch.int32, device=dev)
+    out = torch.full((n + 5, 3), -7, dtype=torch.int32, device=dev)
+    ac.hits_pack_device(t, n, pairs)
+    assert torch.equal(pairs[:n], t[:, 1:3]) and int(pairs[n:].abs().sum()) == 0
+    ac.hits_unpack_device(pairs, n, out, chars=chars)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:n], t) and bool((out[n:] == -7).all())
+    assert np.array_equal(ac.key_lengths(chars)[hits["value"]], hits["end"] - hits["start"])
+
+
 def test_sequence_longer_than_int32_is_rejected():
     import ctypes as C
 

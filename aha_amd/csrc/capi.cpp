@@ -46,7 +46,9 @@ struct aha_ac {
   uint32_t v2_lds_slots = 0;
   uint32_t v2_grid = 0;
   uint32_t v2_bpc = 1;
-  bool direct_overflowed = false;  // a chunk's event region overflowed once: keep to the slab pipeline
+  uint32_t direct_div = 4;         // plain mode: a chunk's event region holds S / direct_div events; set to 1 (one
+                                   // event per input byte: cannot overflow) once a region overflowed (hit-dense input)
+  bool direct_overflowed = false;  // event regions not usable (temp too large): keep to the slab pipeline
   struct Buf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -270,7 +272,11 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
                 !ac->direct_overflowed;
   const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
   M.direct = direct ? 1 : 0;
-  M.ev_stride = (uint32_t)std::max<uint64_t>(16, S / 4);
+  M.ev_stride = (uint32_t)std::max<uint64_t>(16, S / ac->direct_div);
+  if (direct && M.n_chunks * (uint64_t)M.ev_stride * 12 > (48ull << 30)) {  // regions + offsets beyond 48 GiB of temp
+    direct = false;
+    M.direct = 0;
+  }
   M.ev_cap = direct ? 0 : ((M1.cap + waves * kV2Slab + kV2Slab) / kV2Slab) * kV2Slab;
   const uint64_t n_slabs = M.ev_cap / kV2Slab + 2;
   const uint64_t n_blk = std::max<uint64_t>((M.n_chunks + 255) / 256, (M.ev_cap + 255) / 256) + 2;
@@ -337,8 +343,11 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
               d[0], d[0] ? (double)d[1] / d[0] : 0.0, d[0] ? (double)d[4] / d[0] : 0.0, d[2],
               d[2] ? (double)d[3] / d[2] : 0.0, d[2] ? (double)d[5] / d[2] : 0.0);
   }
-  if (ac->h_v2[1] == 2) {  // a chunk's event region overflowed (hit-dense input): slab pipeline from now on
-    ac->direct_overflowed = true;
+  if (ac->h_v2[1] == 2) {  // a chunk's event region overflowed (hit-dense input): full-size regions from now on
+    if (ac->direct_div > 1)
+      ac->direct_div = 1;
+    else
+      ac->direct_overflowed = true;
     return 2;
   }
   if (ac->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
@@ -693,7 +702,8 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
   M.doc_hit_off = d_doc_hit_offsets;
   if (ac->v2_ok) {
     rc = match_v2(ac, M, s, n_hits, true);
-    if (rc == 2) rc = match_v2(ac, M, s, n_hits, false);  // hit-dense input: slab pipeline
+    if (rc == 2) rc = match_v2(ac, M, s, n_hits, true);   // hit-dense input: regions of one event per byte
+    if (rc == 2) rc = match_v2(ac, M, s, n_hits, false);  // regions unusable: slab pipeline
     if (rc < 0) return rc;
     if (rc == AHA_OK) {
       if (*n_hits > cap) {

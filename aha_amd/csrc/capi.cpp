@@ -49,6 +49,8 @@ struct aha_ac {
   uint32_t direct_div = 4;         // plain mode: a chunk's event region holds S / direct_div events; set to 1 (one
                                    // event per input byte: cannot overflow) once a region overflowed (hit-dense input)
   bool direct_overflowed = false;  // event regions not usable (temp too large): keep to the slab pipeline
+  bool sparse_hits = false;        // the last call produced < 16 hits per chunk: the slab pipeline (cost ~ events)
+                                   // beats the region pipeline (cost ~ chunks) on such input
   struct Buf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -269,7 +271,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   // plain mode (byte offsets, no separator filter, no boundary filter): per-chunk event regions, no sort
   const char *de = getenv("AHA_DIRECT");
   bool direct = !(de && strcmp(de, "0") == 0) && !M.chars && !M.sep && ac->flt.d0 == 0 && allow_direct &&
-                !ac->direct_overflowed;
+                !ac->direct_overflowed && !ac->sparse_hits;
   const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
   M.direct = direct ? 1 : 0;
   M.ev_stride = (uint32_t)std::max<uint64_t>(16, S / ac->direct_div);
@@ -352,6 +354,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   }
   if (ac->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = ac->h_v2[2];
+  if (!M.chars && !M.sep) ac->sparse_hits = *n_hits < 16ull * M.n_chunks;
   if (prof) {
     aha_timing &t = ac->last;
     memset(&t, 0, sizeof(t));

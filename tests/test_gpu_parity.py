@@ -383,6 +383,35 @@ def test_exchange_pairs_round_trip(chars):
     assert np.array_equal(ac.key_lengths(chars)[hits["value"]], hits["end"] - hits["start"])
 
 
+def test_concurrent_calls_on_one_handle():
+    """The handle is immutable after compile; concurrent #match calls must be safe (SURVEY.md 8 b, threading)."""
+    import threading
+
+    rng = random.Random(21)
+    keys = rand_keys(rng, 400, b"abcd", 1, 6)
+    ac = AC.compile(keys)
+    o = orc.AC.compile(keys)
+    texts = [bytes(rng.choice(b"abcd") for _ in range(rng.randint(1000, 60000))) for _ in range(6)]
+    want = [as_list(o.match(t)) for t in texts]
+    got = [None] * len(texts)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                got[i] = gpu_list(ac.match_array(texts[i]))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(texts))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert got == want
+
+
 def test_sequence_longer_than_int32_is_rejected():
     import ctypes as C
 

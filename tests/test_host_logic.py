@@ -241,3 +241,34 @@ def test_save_load_empty_key_set():
     a = AC.compile([], host_only=True)
     b = AC.from_bytes(a.to_bytes(), host_only=True)
     assert b.info["n_keys"] == 0
+
+
+# ---- C ABI misuse: every entry point answers a bad argument with a status, never a crash -------
+def test_c_abi_rejects_bad_arguments():
+    L = N.lib()
+    assert L.aha_ac_info(None, None) == N.AHA_E_INVALID
+    assert L.aha_ac_key(None, 0, None, 0) == N.AHA_E_INVALID
+    assert L.aha_ac_id(None, None, 0) == N.AHA_E_INVALID
+    assert L.aha_ac_save(None, None, 0) == N.AHA_E_INVALID
+    h = C.c_void_p()
+    assert L.aha_ac_load(None, 0, None, C.byref(h)) == N.AHA_E_INVALID and not h.value
+    assert L.aha_ac_match_bytes(None, None, 0, None, None, 0, None) == N.AHA_E_INVALID
+    assert L.aha_ac_match_batch(None, None, None, 0, None, None, 0, None, None) == N.AHA_E_INVALID
+    assert L.aha_ac_match_batch_device(None, None, None, 0, 0, None, None, 0, None, None, None) == N.AHA_E_INVALID
+    assert L.aha_ac_hits_pack_device(None, None, 0, None, None) == N.AHA_E_INVALID
+    assert L.aha_ac_hits_unpack_device(None, None, 0, 0, None, None) == N.AHA_E_INVALID
+    assert L.aha_ac_set_profiling(None, 1) == N.AHA_E_INVALID
+    assert L.aha_ac_last_timing(None, None) == N.AHA_E_INVALID
+    assert L.aha_ac_export(None, 0, None, 0) < 0
+    L.aha_ac_free(None)  # no-op
+    assert L.aha_strerror(N.AHA_E_NO_DEVICE).decode().startswith("no usable HIP device")
+    a = AC.compile(["ab"], host_only=True)
+    assert a[0] == "ab"
+    assert L.aha_ac_key(a._h, 5, None, 0) == N.AHA_E_NOT_FOUND
+    with pytest.raises(IndexError):  # IndexError in the reference too (src/aha/cedar.cr:830-834)
+        a[5]
+    with pytest.raises(IndexError):
+        a["zz"]
+    # a host-only handle has no device: pack/unpack and profiling refuse it
+    assert L.aha_ac_hits_pack_device(a._h, None, 0, None, None) == N.AHA_E_INVALID
+    assert L.aha_ac_set_profiling(a._h, 1) == N.AHA_E_NO_DEVICE

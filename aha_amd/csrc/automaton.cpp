@@ -230,7 +230,7 @@ inline int popcnt(const Mask &m) {
 }
 }  // namespace
 
-void place_states(const Automaton &a, Placement &p) {
+void place_states(const Automaton &a, Placement &p, bool defer_deep_fail) {
   const uint32_t S = a.n_states;
   p.base.assign(S, 0);
   std::vector<Mask> freeb;        // per block free bitmap
@@ -261,14 +261,27 @@ void place_states(const Automaton &a, Placement &p) {
     weight[s] += a.key_of[s] >= 0 ? 1u : 0u;
     if (s) weight[a.parent[s]] += weight[s];
   }
-  for (uint32_t s = 0; s < S; s++) order[s] = s;
+  // States of depth >= 3 whose fail link is itself deeper than 2 ("deep-fail"; rare) go last, into their own
+  // region: for every other state of depth >= 3 the fail target is a function of the last two bytes, which the
+  // traversal keeps at hand, so base in [seg_start[3], deep_fail_start) means "no fail header needed".
+  order.clear();
+  std::vector<uint32_t> deferred;
   for (uint32_t lo = 0; lo < S;) {
     uint32_t hi = lo;
     while (hi < S && a.depth[hi] == a.depth[lo]) hi++;
-    std::stable_sort(order.begin() + lo, order.begin() + hi,
-                     [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
+    const size_t at = order.size();
+    for (uint32_t s = lo; s < hi; s++) {
+      if (defer_deep_fail && a.depth[s] >= 3 && a.depth[a.fail[s]] >= 3)
+        deferred.push_back(s);
+      else
+        order.push_back(s);
+    }
+    std::stable_sort(order.begin() + at, order.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
     lo = hi;
   }
+  const size_t n_regular = order.size();
+  order.insert(order.end(), deferred.begin(), deferred.end());
+  p.deep_fail_start = 0;
 
   uint32_t cur_depth = 0;
   for (uint32_t d = 0; d < kSegDepth + 2; d++) p.seg_start[d] = 0;
@@ -276,7 +289,13 @@ void place_states(const Automaton &a, Placement &p) {
     const uint32_t s = order[oi];
     const unsigned nc = a.n_child[s];
     const uint8_t *labels = a.in_label.data() + a.first_child[s];
-    if (a.depth[s] != cur_depth) {
+    if (oi == n_regular) {  // the deep-fail region starts in fresh blocks
+      open.clear();
+      open_head = 0;
+      leafpool.clear();
+      p.deep_fail_start = (uint32_t)freeb.size() * 256u;
+    }
+    if (oi < n_regular && a.depth[s] != cur_depth) {
       // BFS reached the next level: for the shallow levels close every open
       // block so that deeper states never fill holes of shallower regions
       cur_depth = a.depth[s];
@@ -339,6 +358,7 @@ void place_states(const Automaton &a, Placement &p) {
     (void)popcnt;
   }
   p.n_slots = (uint32_t)freeb.size() * 256u;
+  if (n_regular == S) p.deep_fail_start = p.n_slots;
   for (uint32_t d = cur_depth + 1; d < kSegDepth + 2; d++) p.seg_start[d] = p.n_slots;
 }
 

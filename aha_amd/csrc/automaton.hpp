@@ -76,8 +76,11 @@ struct Placement {
   std::vector<uint32_t> base;  // [n_states]
   uint32_t n_slots = 0;        // multiple of 256
   uint32_t seg_start[kSegDepth + 2] = {0};  // first slot of depth d; [kSegDepth+1] = n_slots sentinel if shallower
+  // defer_deep_fail: states of depth >= 3 whose fail target has depth >= 3 are placed last, from this slot on
+  // (the seg_start equivalence then holds for d <= 3 only); n_slots when there is none or the option is off
+  uint32_t deep_fail_start = 0;
 };
-void place_states(const Automaton &a, Placement &p);
+void place_states(const Automaton &a, Placement &p, bool defer_deep_fail = false);
 
 // ---- device image formats -------------------------------------------------
 // Wide slot (8 bytes, one 64-bit load):

@@ -46,6 +46,7 @@ struct aha_ac {
   uint32_t v2_lds_slots = 0;
   uint32_t v2_grid = 0;
   uint32_t v2_bpc = 1;
+  uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
   uint32_t direct_div = 4;         // plain mode: a chunk's event region holds S / direct_div events; set to 1 (one
                                    // event per input byte: cannot overflow) once a region overflowed (hit-dense input)
   bool direct_overflowed = false;  // event regions not usable (temp too large): keep to the slab pipeline
@@ -91,6 +92,9 @@ int32_t upload_image(aha_ac *ac, const Image &img) {
   d.n_slots = img.n_slots;
   d.max_len = a.max_key_len;
   d.compact = img.compact ? 1u : 0u;
+  d.s1_lo = ac->s1_lo;
+  d.s2_lo = ac->s2_lo;
+  d.s2_hi = ac->s2_hi;
   int32_t rc;
   if (img.compact) {
     const uint32_t *p = nullptr;
@@ -433,7 +437,14 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     return be.code;
   }
   Placement pl;
-  place_states(ac->aut, pl);
+  // the boundary-filter engine relies on the depth segments of every level; the plain walk on the deep-fail region
+  const char *fe = getenv("AHA_FILTER");
+  const char *sf = getenv("AHA_SHADOW_FAIL");
+  const bool defer = !(fe && strcmp(fe, "1") == 0) && !(sf && strcmp(sf, "0") == 0);
+  place_states(ac->aut, pl, defer);
+  ac->s1_lo = defer ? pl.seg_start[2] : 0;
+  ac->s2_lo = defer ? pl.seg_start[3] : 0;
+  ac->s2_hi = defer ? pl.deep_fail_start : 0;
   Image &img = ac->img;
   if (!encode_image(ac->aut, pl, (flags & AHA_OPT_FORCE_WIDE) != 0, img)) {
     delete ac;
@@ -443,6 +454,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   ac->compact = img.compact;
   ac->slot_bytes = img.compact ? 4 : 8;
   plan_engine(ac, pl);
+  if (pl.seg_start[2] > ac->v2_lds_slots) ac->s1_lo = ac->s2_lo = ac->s2_hi = 0;  // shadow fail probes depth-1 rows in LDS
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     int n = aha_device_count();
     if (n <= 0) {

@@ -18,6 +18,11 @@ struct DevAut {
   uint32_t n_slots;
   uint32_t max_len;
   uint32_t compact;
+  // shadow fail: a state with base in [s2_lo, s2_hi) has depth >= 3 and a fail target of depth <= 2, i.e. its fail
+  // target is the depth<=2 state of the last two input bytes, which k2_traverse keeps in registers (0,0 = off)
+  uint32_t s1_lo;            // [s1_lo, s2_lo): depth-2 states; their fail target is the depth-1 state of the last byte
+  uint32_t s2_lo;
+  uint32_t s2_hi;
   // filter mode (0 = off): rows of states with depth < d0 live in LDS, states of
   // depth d0 are guarded by the lookahead Bloom filter (automaton.hpp, Filter)
   uint32_t d0;

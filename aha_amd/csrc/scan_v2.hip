@@ -156,6 +156,10 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
     int64_t nb = INT64_MAX, doc_start = a, pos = e;
     uint32_t B = root, fr = 0, seq = 0;
     bool hdr = false;  // the next lookup fetches the fail header of B (no byte consumed)
+    // shadow fail (A.s2_lo < A.s2_hi): r1 = root-row entry of the last consumed byte (0 = none), s2 = entry of the
+    // depth<=2 state of the last two consumed bytes.  A miss in a state whose base lies in [s2_lo, s2_hi) continues
+    // in s2's state in the same trip: no header trip, no far header load.
+    slot_t r1 = slot_t{}, s2 = slot_t{};
     uint32_t lc = 0, lc_exact = 0, lead_total = 0;
     if (live) {
       dn = first_boundary(M.doc_off, D, (uint64_t)a);
@@ -223,6 +227,8 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             B = root;
             fr = 0;
             hdr = false;
+            r1 = slot_t{};
+            s2 = slot_t{};
             doc_start = here;
             docrel = -(int32_t)rel;
             lc = 0;
@@ -254,11 +260,23 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
           const bool m = !hdr && !bz && S_::match(en, b);         // goto (cedar.cr:441-447)
           const bool take = hdr || m;                             // state := the entry's target
           const bool viaroot = !take && (B == root || fr != 0 || bz);  // nid = fails[nid] = root, then probe there
-          const bool m0 = viaroot && !bz && S_::match(e0, b);     // goto from root
+          const bool mr = !bz && S_::match(e0, b);                // b has a depth-1 state
+          const bool m0 = viaroot && mr;                          // goto from root
           const bool consumed = m || viaroot;                     // at root a miss consumes the byte (ac.cr:188)
-          hdr = !take && !viaroot;                                // next trip loads fails[nid] (ac.cr:189)
-          const slot_t ex = m0 ? e0 : en;
-          const bool land = take || m0;
+          bool s2go = false;
+          slot_t e2 = e0, sx = e0;
+          if constexpr (!ALL_LDS) {
+            // fails[nid] of a deep state = depth<=2 state of the last two bytes: continue there right away
+            // (a depth-2 state fails to the depth-1 state of its last byte: r1)
+            const bool s1go = !take && !viaroot && (B - A.s1_lo) < (A.s2_lo - A.s1_lo);
+            s2go = !take && !viaroot && (B - A.s2_lo) < (A.s2_hi - A.s2_lo);
+            e2 = lt[S_::base(r1) ^ b];                            // depth-1 rows are always LDS resident
+            sx = s1go ? r1 : s2;
+            s2go = s2go || s1go;
+          }
+          hdr = !take && !viaroot && !s2go;                       // next trip loads fails[nid] (ac.cr:189)
+          const slot_t ex = s2go ? sx : (m0 ? e0 : en);
+          const bool land = take || m0 || s2go;
           B = land ? S_::base(ex) : (viaroot ? root : B);
           fr = land ? S_::failroot(ex) : (viaroot ? 0u : fr);
           if constexpr (ALL_LDS) {
@@ -271,6 +289,13 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             }
           }
           ev = (m || m0) && S_::end(ex) && emit_ok;               // is_end? -> fetch later (ac.cr:183-185)
+          if constexpr (!ALL_LDS) {
+            // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
+            const bool m2 = !bz && S_::match(e2, b);
+            const slot_t s2n = m2 ? e2 : (mr ? e0 : slot_t{});
+            s2 = consumed ? s2n : s2;
+            r1 = consumed ? (mr ? e0 : slot_t{}) : r1;
+          }
           if (CHARS) {
             const uint32_t isl = (consumed && emit_ok && (b & 0xC0u) != 0x80u) ? 1u : 0u;
             lc += isl;

@@ -184,7 +184,10 @@ void plan_engine(aha_ac *ac, const Placement &pl) {
   ac->v2_bpc = (bpc && strcmp(bpc, "2") == 0) ? 2 : 1;
   const size_t budget = kLdsPerCU / ac->v2_bpc - in_bytes;
   ac->flt = Filter();
-  if ((size_t)ac->n_slots * slot <= budget) {  // the whole automaton lives in LDS
+  // AHA_LDS_SLOTS=n caps the prefix (tests: forces the partial-prefix kernel on small automata)
+  const char *cap_s = getenv("AHA_LDS_SLOTS");
+  const size_t cap_slots = cap_s ? (size_t)std::max(256, atoi(cap_s)) & ~(size_t)255 : SIZE_MAX;
+  if ((size_t)ac->n_slots * slot <= budget && ac->n_slots <= cap_slots) {  // the whole automaton lives in LDS
     ac->v2_lds_slots = ac->n_slots;
     return;
   }
@@ -204,7 +207,7 @@ void plan_engine(aha_ac *ac, const Placement &pl) {
     ac->v2_lds_slots = pl.seg_start[d0];
     return;
   }
-  ac->v2_lds_slots = (uint32_t)(budget / slot) & ~3u;
+  ac->v2_lds_slots = (uint32_t)std::min<size_t>(std::min<size_t>(budget / slot, cap_slots), ac->n_slots) & ~3u;
 }
 
 void v2_setup(aha_ac *ac) {

@@ -17,15 +17,21 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1", "v2f"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2f", "v2p"], autouse=True)
 def engine(request, monkeypatch):
     """Every parity test runs on the single-traversal engine (scan_v2.hip,
-    default), on the two-pass engine it falls back to (kernels.hip) and on the
+    default), on the two-pass engine it falls back to (kernels.hip), on the
     single-traversal engine with the opt-in boundary filter (k3_traverse; only
-    engages for automata larger than the LDS budget).  The variables are read
-    when a handle is compiled."""
+    engages for automata larger than the LDS budget) and on the single-traversal
+    engine with its LDS prefix capped at 1024 slots ("v2p": small automata then
+    also take the partial-prefix kernel with the shadow fail links and the HBM
+    probe path).  The variables are read when a handle is compiled."""
     monkeypatch.setenv("AHA_ENGINE", "v1" if request.param == "v1" else "v2")
     monkeypatch.setenv("AHA_FILTER", "1" if request.param == "v2f" else "0")
+    if request.param == "v2p":
+        monkeypatch.setenv("AHA_LDS_SLOTS", "1024")
+    else:
+        monkeypatch.delenv("AHA_LDS_SLOTS", raising=False)
     return request.param
 G = os.path.join(os.path.dirname(__file__), "golden")
 KATS = json.load(open(os.path.join(G, "reference_kats.json"), encoding="utf-8"))

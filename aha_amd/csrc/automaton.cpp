@@ -208,9 +208,9 @@ inline uint64_t perm6(uint64_t x, unsigned c) {
   return x;
 }
 
-// candidates x (header slot) such that x and x^l (all l) are free
-inline Mask candidates(const Mask &freeb, const uint8_t *labels, unsigned n) {
-  Mask m = freeb;
+// positions x such that x^l is free for all labels l
+inline Mask children_free(const Mask &freeb, const uint8_t *labels, unsigned n) {
+  Mask m = Mask{~0ull, ~0ull, ~0ull, ~0ull};
   for (unsigned i = 0; i < n; i++) {
     unsigned l = labels[i];
     unsigned wsel = l >> 6, c = l & 63;
@@ -230,20 +230,31 @@ inline int popcnt(const Mask &m) {
 }
 }  // namespace
 
-void place_states(const Automaton &a, Placement &p, bool defer_deep_fail) {
+bool needs_header(const Automaton &a, const Placement &p, uint32_t s) {
+  if (!p.headerless || s == 0) return true;
+  return a.depth[s] >= 3 && a.depth[a.fail[s]] >= 3;  // deep-fail: the only fail links that are looked up
+}
+
+void place_states(const Automaton &a, Placement &p, bool defer_deep_fail, bool headerless) {
+  p.headerless = headerless && defer_deep_fail;
   const uint32_t S = a.n_states;
   p.base.assign(S, 0);
   std::vector<Mask> freeb;        // per block free bitmap
+  std::vector<Mask> baseb;        // per block: positions that are not yet the base of a state
   std::vector<uint16_t> nfree;    // per block free count
+  std::vector<uint16_t> nbase;    // per block: base ids left
   std::vector<uint8_t> nfail;     // failed placement attempts
   std::vector<uint32_t> open;     // blocks tried for multi-slot states (oldest first)
   std::vector<uint32_t> leafpool; // retired blocks that still have single free slots
+  std::vector<uint32_t> basepool; // blocks without free slots that still have base ids (header-less leaves)
   size_t open_head = 0;
   constexpr unsigned TRIES = 6, MAXFAIL = 6;
 
   auto new_block = [&]() -> uint32_t {
     freeb.push_back(Mask{~0ull, ~0ull, ~0ull, ~0ull});
+    baseb.push_back(Mask{~0ull, ~0ull, ~0ull, ~0ull});
     nfree.push_back(256);
+    nbase.push_back(256);
     nfail.push_back(0);
     return (uint32_t)freeb.size() - 1;
   };
@@ -293,6 +304,7 @@ void place_states(const Automaton &a, Placement &p, bool defer_deep_fail) {
       open.clear();
       open_head = 0;
       leafpool.clear();
+      basepool.clear();
       p.deep_fail_start = (uint32_t)freeb.size() * 256u;
     }
     if (oi < n_regular && a.depth[s] != cur_depth) {
@@ -303,19 +315,63 @@ void place_states(const Automaton &a, Placement &p, bool defer_deep_fail) {
         open.clear();
         open_head = 0;
         leafpool.clear();
+        basepool.clear();
         p.seg_start[cur_depth] = (uint32_t)freeb.size() * 256u;
       }
     }
+    // A state owns a unique base (its identity) and the slots base^label of its children; the slot at the base
+    // itself (the header: fail link) only where fail links are looked up (needs_header).
+    const bool hdr = needs_header(a, p, s);
+    const unsigned need = nc + (hdr ? 1u : 0u);
+    auto cand = [&](uint32_t b) -> Mask {
+      Mask m = baseb[b];
+      if (hdr)
+        for (int j = 0; j < 4; j++) m[j] &= freeb[b][j];
+      if (nc) {
+        Mask c = children_free(freeb[b], labels, nc);
+        for (int j = 0; j < 4; j++) m[j] &= c[j];
+      }
+      return m;
+    };
     uint32_t blk = UINT32_MAX;
     int x = -1;
-    if (nc == 0) {
-      // leaf: any single free slot; drain retired blocks first
-      while (!leafpool.empty() && nfree[leafpool.back()] == 0) leafpool.pop_back();
-      if (!leafpool.empty()) {
-        blk = leafpool.back();
-        x = first_bit(freeb[blk]);
+    if (need == 0) {
+      // a header-less leaf needs nothing but a base id: drain blocks that are full of slots but not of ids
+      while (!basepool.empty() && nbase[basepool.back()] == 0) basepool.pop_back();
+      if (!basepool.empty()) {
+        blk = basepool.back();
+        x = first_bit(baseb[blk]);
       }
     }
+    if (need == 1 && hdr) {
+      // leaf with a header: any single free slot; drain retired blocks first
+      while (!leafpool.empty() && (nfree[leafpool.back()] == 0 || nbase[leafpool.back()] == 0)) leafpool.pop_back();
+      if (!leafpool.empty()) {
+        Mask m = cand(leafpool.back());
+        int c = first_bit(m);
+        if (c >= 0) {
+          blk = leafpool.back();
+          x = c;
+        }
+      }
+    }
+    // youngest open blocks first (most recently opened = most room); failures here are not held against a block
+    auto try_youngest = [&]() {
+      unsigned tried = 0;
+      for (size_t i = open.size(); i-- > open_head && tried < 2 * TRIES;) {
+        const uint32_t b = open[i];
+        if (b == UINT32_MAX || nfree[b] < need || nbase[b] == 0) continue;
+        tried++;
+        const int c = first_bit(cand(b));
+        if (c >= 0) {
+          blk = b;
+          x = c;
+          return;
+        }
+      }
+    };
+    // a wide row needs whole label groups: it looks at the youngest blocks before the old, fragmented ones
+    if (x < 0 && need > 16) try_youngest();
     if (x < 0) {
       unsigned tried = 0, scanned = 0;
       for (size_t i = open_head; i < open.size() && tried < TRIES && scanned < 48; i++) {
@@ -324,17 +380,22 @@ void place_states(const Automaton &a, Placement &p, bool defer_deep_fail) {
           if (i == open_head) open_head++;
           continue;
         }
+        if (nfree[b] == 0 || nbase[b] == 0) {  // exhausted: out of the scan window for good
+          if (nbase[b]) basepool.push_back(b);
+          open[i] = UINT32_MAX;
+          continue;
+        }
         scanned++;
-        if (nfree[b] < nc + 1) {
+        if (nfree[b] < need) {
           // cannot host this state; count as a failure only for small states
-          if (nc <= 2 && ++nfail[b] >= MAXFAIL) {
-            if (nfree[b]) leafpool.push_back(b);
+          if (need <= 3 && ++nfail[b] >= MAXFAIL) {
+            if (nfree[b] && nbase[b]) leafpool.push_back(b);
             open[i] = UINT32_MAX;
           }
           continue;
         }
         tried++;
-        Mask m = candidates(freeb[b], labels, nc);
+        Mask m = cand(b);
         int c = first_bit(m);
         if (c >= 0) {
           blk = b;
@@ -342,17 +403,20 @@ void place_states(const Automaton &a, Placement &p, bool defer_deep_fail) {
           break;
         }
         if (++nfail[b] >= MAXFAIL) {
-          if (nfree[b]) leafpool.push_back(b);
+          if (nfree[b] && nbase[b]) leafpool.push_back(b);
           open[i] = UINT32_MAX;
         }
       }
     }
+    if (x < 0 && need <= 16) try_youngest();  // the old blocks had no room for it
     if (x < 0) {
       blk = new_block();
       open.push_back(blk);
-      x = 0;
+      x = first_bit(cand(blk));  // a fresh block hosts any state (at position 0 unless a label is 0, which none is)
     }
-    take(blk, (unsigned)x);
+    baseb[blk][(unsigned)x >> 6] &= ~(1ull << ((unsigned)x & 63));
+    nbase[blk]--;
+    if (hdr) take(blk, (unsigned)x);
     for (unsigned i = 0; i < nc; i++) take(blk, (unsigned)x ^ labels[i]);
     p.base[s] = blk * 256u + (uint32_t)x;
     (void)popcnt;
@@ -421,7 +485,8 @@ bool encode_image(const Automaton &a, const Placement &p, bool force_wide, Image
     for (uint32_t s = 0; s < S; s++) {
       uint32_t b = p.base[s];
       // header: label 0, lo = fail base | W_FAILROOT when the fail state's own fail is root
-      img.wide[b] = (uint64_t)(p.base[a.fail[s]] | (a.fail[a.fail[s]] == 0 ? W_FAILROOT : 0u));
+      if (needs_header(a, p, s))
+        img.wide[b] = (uint64_t)(p.base[a.fail[s]] | (a.fail[a.fail[s]] == 0 ? W_FAILROOT : 0u));
       for (uint32_t j = 0; j < a.n_child[s]; j++) {
         uint32_t c = a.first_child[s] + j;
         uint8_t lab = a.in_label[c];
@@ -441,7 +506,8 @@ bool encode_image(const Automaton &a, const Placement &p, bool force_wide, Image
     for (uint32_t s = 0; s < S; s++) {
       uint32_t b = p.base[s];
       // header: label 0, fail base, C_FAILROOT when the fail state's own fail is root
-      img.narrow[b] = (p.base[a.fail[s]] << C_BASE_SHIFT) | (a.fail[a.fail[s]] == 0 ? C_FAILROOT : 0u);
+      if (needs_header(a, p, s))
+        img.narrow[b] = (p.base[a.fail[s]] << C_BASE_SHIFT) | (a.fail[a.fail[s]] == 0 ? C_FAILROOT : 0u);
       if (a.key_of[s] >= 0) img.end_key[b] = a.key_of[s];
       for (uint32_t j = 0; j < a.n_child[s]; j++) {
         uint32_t c = a.first_child[s] + j;

@@ -79,8 +79,15 @@ struct Placement {
   // defer_deep_fail: states of depth >= 3 whose fail target has depth >= 3 are placed last, from this slot on
   // (the seg_start equivalence then holds for d <= 3 only); n_slots when there is none or the option is off
   uint32_t deep_fail_start = 0;
+  // headerless (needs defer_deep_fail): only the root and the deep-fail states own a header slot.  Every other
+  // fail link is a function of the last two input bytes (depth 1: root; depth 2: the depth-1 state of the last
+  // byte; depth >= 3 below deep_fail_start: the depth<=2 state of the last two bytes), so its slot is never read:
+  // the base is then a pure identity (unique, but it may coincide with another state's transition slot), the
+  // image holds little more than one slot per transition, and full 64-label rows pack four to a block.
+  bool headerless = false;
 };
-void place_states(const Automaton &a, Placement &p, bool defer_deep_fail = false);
+void place_states(const Automaton &a, Placement &p, bool defer_deep_fail = false, bool headerless = false);
+bool needs_header(const Automaton &a, const Placement &p, uint32_t s);
 
 // ---- device image formats -------------------------------------------------
 // Wide slot (8 bytes, one 64-bit load):

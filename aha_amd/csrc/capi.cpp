@@ -440,24 +440,30 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     return be.code;
   }
   Placement pl;
-  // the boundary-filter engine relies on the depth segments of every level; the plain walk on the deep-fail region
+  Image &img = ac->img;
+  // Shadow fail links (default): fail links of depth <= 2 targets are recomputed from the last two input bytes, so
+  // only the root and the deep-fail states keep a header slot (automaton.hpp, Placement::headerless).  The
+  // boundary-filter engine (AHA_FILTER=1) and AHA_SHADOW_FAIL=0 keep a header for every state.
   const char *fe = getenv("AHA_FILTER");
   const char *sf = getenv("AHA_SHADOW_FAIL");
-  const bool defer = !(fe && strcmp(fe, "1") == 0) && !(sf && strcmp(sf, "0") == 0);
-  place_states(ac->aut, pl, defer);
-  ac->s1_lo = defer ? pl.seg_start[2] : 0;
-  ac->s2_lo = defer ? pl.seg_start[3] : 0;
-  ac->s2_hi = defer ? pl.deep_fail_start : 0;
-  Image &img = ac->img;
-  if (!encode_image(ac->aut, pl, (flags & AHA_OPT_FORCE_WIDE) != 0, img)) {
-    delete ac;
-    return AHA_E_TOO_LARGE;
+  bool shadow = !(fe && strcmp(fe, "1") == 0) && !(sf && strcmp(sf, "0") == 0);
+  for (;;) {
+    place_states(ac->aut, pl, shadow, shadow);
+    if (!encode_image(ac->aut, pl, (flags & AHA_OPT_FORCE_WIDE) != 0, img)) {
+      delete ac;
+      return AHA_E_TOO_LARGE;
+    }
+    ac->n_slots = img.n_slots;
+    ac->compact = img.compact;
+    ac->slot_bytes = img.compact ? 4 : 8;
+    plan_engine(ac, pl);
+    // the traversal probes the depth-1 rows in LDS to keep the shadow state: they must all be resident
+    if (!shadow || pl.seg_start[2] <= ac->v2_lds_slots) break;
+    shadow = false;
   }
-  ac->n_slots = img.n_slots;
-  ac->compact = img.compact;
-  ac->slot_bytes = img.compact ? 4 : 8;
-  plan_engine(ac, pl);
-  if (pl.seg_start[2] > ac->v2_lds_slots) ac->s1_lo = ac->s2_lo = ac->s2_hi = 0;  // shadow fail probes depth-1 rows in LDS
+  ac->s1_lo = shadow ? pl.seg_start[2] : 0;
+  ac->s2_lo = shadow ? pl.seg_start[3] : 0;
+  ac->s2_hi = shadow ? pl.deep_fail_start : 0;
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     int n = aha_device_count();
     if (n <= 0) {
@@ -597,6 +603,9 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->filter_words = (uint32_t)ac->flt.bloom.size();
   info->filter_entries = ac->flt.n_entries;
   info->boundary_end = ac->flt.t_bend;
+  info->fail_s1_lo = ac->s1_lo;
+  info->fail_s2_lo = ac->s2_lo;
+  info->fail_hdr_lo = ac->s2_hi;
   return AHA_OK;
 }
 

@@ -33,6 +33,11 @@ struct Probe<false> {
   static __device__ __forceinline__ uint32_t fail(const DevAut &A, uint32_t B) {
     return reinterpret_cast<const uint2 *>(A.slots)[B].x & W_BASE_MASK;
   }
+  // child(B, b) or A.root when there is none
+  static __device__ __forceinline__ uint32_t child_or_root(const DevAut &A, uint32_t B, uint32_t b) {
+    const uint2 e = reinterpret_cast<const uint2 *>(A.slots)[B ^ b];
+    return (e.y & 0xFFu) == b ? (e.x & W_BASE_MASK) : A.root;
+  }
 };
 
 template <>
@@ -53,12 +58,36 @@ struct Probe<true> {
   static __device__ __forceinline__ uint32_t fail(const DevAut &A, uint32_t B) {
     return (reinterpret_cast<const uint32_t *>(A.slots)[B] >> C_BASE_SHIFT) & C_BASE_MASK;
   }
+  static __device__ __forceinline__ uint32_t child_or_root(const DevAut &A, uint32_t B, uint32_t b) {
+    const uint32_t e = reinterpret_cast<const uint32_t *>(A.slots)[B ^ b];
+    return (e & 0xFFu) == b ? ((e >> C_BASE_SHIFT) & C_BASE_MASK) : A.root;
+  }
 };
+
+// fails[nid] (ac.cr:189) of a non-root state B.  tp points at the current (not yet consumed) input byte; the
+// bytes before it spell the state.  Only the root and the states with base >= s2_hi own a fail header; the other
+// fail targets are functions of the last one or two bytes (automaton.hpp, Placement::headerless).
+template <bool COMPACT>
+__device__ __forceinline__ uint32_t fail_of(const DevAut &A, uint32_t B, const uint8_t *tp) {
+  if (B >= A.s2_hi) return Probe<COMPACT>::fail(A, B);  // header (every state when the ranges are all 0)
+  if (B < A.s1_lo) return A.root;                       // depth 1
+  const uint32_t y = tp[-1];
+  if (B >= A.s2_lo) {  // depth >= 3: the deepest state of depth <= 2 spelled by the last two bytes
+    const uint32_t x = tp[-2];
+    const uint32_t s1 = Probe<COMPACT>::child_or_root(A, A.root, x);
+    if (s1 != A.root) {
+      const uint32_t s2 = Probe<COMPACT>::child_or_root(A, s1, y);
+      if (s2 != A.root) return s2;
+    }
+  }
+  return Probe<COMPACT>::child_or_root(A, A.root, y);  // depth-1 state of the last byte, or root
+}
 
 // delta(B, b): goto/fail loop of match_ (ac.cr:179-190).  Returns true when
 // the new state ends a key (is_end?, cedar.cr:657-660 <=> output.value >= 0).
 template <bool COMPACT>
-__device__ __forceinline__ bool aut_step(const DevAut &A, uint32_t &B, uint32_t b, uint32_t &key) {
+__device__ __forceinline__ bool aut_step(const DevAut &A, uint32_t &B, const uint8_t *tp, uint32_t &key) {
+  const uint32_t b = *tp;
   if (b == 0) {  // NUL contract: state := root, nothing reported
     B = A.root;
     return false;
@@ -67,7 +96,7 @@ __device__ __forceinline__ bool aut_step(const DevAut &A, uint32_t &B, uint32_t 
     int r = Probe<COMPACT>::go(A, B, b, key);
     if (r) return r == 2;
     if (B == A.root) return false;
-    B = Probe<COMPACT>::fail(A, B);
+    B = fail_of<COMPACT>(A, B, tp);
   }
 }
 

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void k_count(DevAut A, MatchArgs M) {
     if (nb != a) {
       doc_start = M.doc_off[dn - 1];
       uint64_t back = min<uint64_t>(a - doc_start, (uint64_t)(A.max_len ? A.max_len - 1 : 0));
-      for (uint64_t p = a - back; p < a; p++) aut_step<COMPACT>(A, B, M.text[p], key);
+      for (uint64_t p = a - back; p < a; p++) aut_step<COMPACT>(A, B, M.text + p, key);
     }
     for (uint64_t p = a; p < e; p++) {
       if (p == nb) {
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_count(DevAut A, MatchArgs M) {
       }
       const uint32_t b = M.text[p];
       if (M.chars) leads += (b & 0xC0u) != 0x80u;
-      if (aut_step<COMPACT>(A, B, b, key)) {
+      if (aut_step<COMPACT>(A, B, M.text + p, key)) {
         if (!M.sep) {
           hits += A.key_cnt[key];
         } else {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void k_write(DevAut A, MatchArgs M) {
     doc_start = M.doc_off[dn - 1];
     if (M.chars) doc_lead0 = M.docg[dn - 1];
     uint64_t back = min<uint64_t>(a - doc_start, (uint64_t)(A.max_len ? A.max_len - 1 : 0));
-    for (uint64_t p = a - back; p < a; p++) aut_step<COMPACT>(A, B, M.text[p], key);
+    for (uint64_t p = a - back; p < a; p++) aut_step<COMPACT>(A, B, M.text + p, key);
   }
   for (uint64_t p = a; p < e; p++) {
     if (p == nb) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_write(DevAut A, MatchArgs M) {
     }
     const uint32_t b = M.text[p];
     if (M.chars) lead_abs += (b & 0xC0u) != 0x80u;
-    if (aut_step<COMPACT>(A, B, b, key)) {
+    if (aut_step<COMPACT>(A, B, M.text + p, key)) {
       if (M.sep && p + 1 < nb && sep_blocked(M, M.text[p + 1])) continue;
       const int32_t end_b = (int32_t)(p - doc_start) + 1;
       int32_t k = (int32_t)key;

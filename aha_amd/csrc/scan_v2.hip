@@ -247,10 +247,6 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
           // the root row is always LDS resident: its probe is issued beside the
           // state's own lookup, so "fail to root, retry the byte there" costs no extra trip
           const slot_t e0 = lt[root ^ b];
-          // ALL_LDS: the fail header of the current state is loaded beside the probe (used only on a
-          // non-root miss).  With a partial prefix the conditional load costs more than it saves (measured).
-          slot_t eh = e0;
-          if constexpr (ALL_LDS) eh = lt[B];
           slot_t en;
           if (ALL_LDS || idx < T)
             en = lt[idx];
@@ -263,33 +259,21 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
           const bool mr = !bz && S_::match(e0, b);                // b has a depth-1 state
           const bool m0 = viaroot && mr;                          // goto from root
           const bool consumed = m || viaroot;                     // at root a miss consumes the byte (ac.cr:188)
-          bool s2go = false;
-          slot_t e2 = e0, sx = e0;
-          if constexpr (!ALL_LDS) {
-            // fails[nid] of a deep state = depth<=2 state of the last two bytes: continue there right away
-            // (a depth-2 state fails to the depth-1 state of its last byte: r1)
-            const bool s1go = !take && !viaroot && (B - A.s1_lo) < (A.s2_lo - A.s1_lo);
-            s2go = !take && !viaroot && (B - A.s2_lo) < (A.s2_hi - A.s2_lo);
-            e2 = lt[S_::base(r1) ^ b];                            // depth-1 rows are always LDS resident
-            sx = s1go ? r1 : s2;
-            s2go = s2go || s1go;
-          }
+          // fails[nid] of a deep state = the depth<=2 state of the last two bytes (s2), of a depth-2 state = the
+          // depth-1 state of the last byte (r1): continue there right away -- no header trip, and such states own
+          // no header slot at all (automaton.hpp, Placement::headerless).  All ranges are empty when off.
+          const bool s1go = !take && !viaroot && (B - A.s1_lo) < (A.s2_lo - A.s1_lo);
+          bool s2go = !take && !viaroot && (B - A.s2_lo) < (A.s2_hi - A.s2_lo);
+          const slot_t e2 = lt[S_::base(r1) ^ b];                 // depth-1 rows are always LDS resident
+          const slot_t sx = s1go ? r1 : s2;
+          s2go = s2go || s1go;
           hdr = !take && !viaroot && !s2go;                       // next trip loads fails[nid] (ac.cr:189)
           const slot_t ex = s2go ? sx : (m0 ? e0 : en);
           const bool land = take || m0 || s2go;
           B = land ? S_::base(ex) : (viaroot ? root : B);
           fr = land ? S_::failroot(ex) : (viaroot ? 0u : fr);
-          if constexpr (ALL_LDS) {
-            // a miss that has to follow a non-root fail link does so in this trip (eh) instead of
-            // spending one on the header: cfg 2 goes from 2.1 to 1.55 trips per byte
-            if (hdr) {
-              B = S_::base(eh);
-              fr = S_::failroot(eh);
-              hdr = false;
-            }
-          }
           ev = (m || m0) && S_::end(ex) && emit_ok;               // is_end? -> fetch later (ac.cr:183-185)
-          if constexpr (!ALL_LDS) {
+          {
             // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
             const bool m2 = !bz && S_::match(e2, b);
             const slot_t s2n = m2 ? e2 : (mr ? e0 : slot_t{});

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AHA_ABI_VERSION 1
+#define AHA_ABI_VERSION 2
 
 /* Aha::Hit -- src/aha/matcher.cr:2-11.  Half-open [start,end) offsets
  * relative to the start of the sequence (document); value = key index in
@@ -87,6 +87,14 @@ typedef struct {
   uint64_t filter_entries;  /* entries of the exact set behind it */
   uint32_t boundary_end;    /* slots below this belong to states of depth <= filter_d0 */
   uint32_t reserved;
+  /* Shadow fail links (all 0 = every state has a fail header at slot[base]).  Otherwise only the root and the
+   * states with base >= fail_hdr_lo own one; for the others the fail target follows from the last input bytes:
+   * base < fail_s1_lo: root; base < fail_s2_lo: the depth-1 state of the last byte; base < fail_hdr_lo: the
+   * deepest state of depth <= 2 spelled by the last two bytes. */
+  uint32_t fail_s1_lo;
+  uint32_t fail_s2_lo;
+  uint32_t fail_hdr_lo;
+  uint32_t reserved2;
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded

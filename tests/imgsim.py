@@ -20,6 +20,8 @@ class ImageSim:
         self.key_cnt = ac.export(3, np.uint32)
         self.root = 0
         assert self.slots.size == info["n_slots"]
+        # shadow fail links (include/aha_hip.h, aha_ac_info_t): all 0 = every state has a header
+        self.s1_lo, self.s2_lo, self.hdr_lo = info["fail_s1_lo"], info["fail_s2_lo"], info["fail_hdr_lo"]
 
     def _probe(self, B, b):
         e = int(self.slots[B ^ b])
@@ -33,14 +35,31 @@ class ImageSim:
             return lo & W_BASE_MASK, ((hi >> 8) if lo & W_END else -1)
         return None
 
-    def _fail(self, B):
-        e = int(self.slots[B])
-        return ((e >> C_BASE_SHIFT) & C_BASE_MASK) if self.compact else (e & W_BASE_MASK)
+    def _child_or_root(self, B, b):
+        r = self._probe(B, b)
+        return self.root if r is None else r[0]
+
+    def _fail(self, B, last2=(0, 0)):
+        """fails[nid] of a non-root state; last2 = the two bytes consumed before the current one."""
+        if B >= self.hdr_lo:  # header slot (every state when the ranges are all 0)
+            e = int(self.slots[B])
+            return ((e >> C_BASE_SHIFT) & C_BASE_MASK) if self.compact else (e & W_BASE_MASK)
+        if B < self.s1_lo:
+            return self.root
+        x, y = last2
+        if B >= self.s2_lo:
+            s1 = self._child_or_root(self.root, x)
+            if s1 != self.root:
+                s2 = self._child_or_root(s1, y)
+                if s2 != self.root:
+                    return s2
+        return self._child_or_root(self.root, y)
 
     def match(self, text):
         out = []
         B = self.root
-        for i, b in enumerate(bytes(text)):
+        t = bytes(text)
+        for i, b in enumerate(t):
             if b == 0:
                 B = self.root
                 continue
@@ -52,7 +71,7 @@ class ImageSim:
                     break
                 if B == self.root:
                     break
-                B = self._fail(B)
+                B = self._fail(B, (t[i - 2] if i >= 2 else 0, t[i - 1] if i >= 1 else 0))
             if key >= 0:
                 k = key
                 n = 0

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/aha_hip.h but not exported"
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
-    assert N.lib().aha_abi_version() == 1
+    assert N.lib().aha_abi_version() == 2
 
 
 def test_compile_errors_follow_reference():
@@ -80,26 +80,39 @@ def test_match_without_device_fails_loudly():
         assert e.value.code == N.AHA_E_NO_DEVICE
 
 
+@pytest.fixture(params=["shadow", "headers"])
+def fail_links(request, monkeypatch):
+    """Image variants: shadow fail links (default: only the root and deep-fail states own a fail header) and a
+    header for every state (AHA_SHADOW_FAIL=0)."""
+    monkeypatch.setenv("AHA_SHADOW_FAIL", "1" if request.param == "shadow" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("seed", range(8))
-def test_image_matches_oracle_small_alphabet(seed, wide):
+def test_image_matches_oracle_small_alphabet(seed, wide, fail_links):
     rng = random.Random(seed)
     alphabet = [b"ab", b"abc", b"abcd\xe4\xb8"][seed % 3]
     keys = rand_keys(rng, rng.randint(1, 60), alphabet, 1, 8)
     text = bytes(rng.choice(alphabet + b"\x00") for _ in range(500))
-    sim = ImageSim(AC.compile(keys, host_only=True, force_wide=wide))
-    assert sim.match(text) == as_list(orc.AC.compile(keys).match(text))
+    ac = AC.compile(keys, host_only=True, force_wide=wide)
+    assert (ac.info["fail_hdr_lo"] > 0) == (fail_links == "shadow")
+    assert ImageSim(ac).match(text) == as_list(orc.AC.compile(keys).match(text))
 
 
 @pytest.mark.parametrize("wide", [False, True])
-def test_image_matches_oracle_many_keys(wide):
+def test_image_matches_oracle_many_keys(wide, fail_links):
     rng = random.Random(99)
     alphabet = bytes(range(1, 256))
     keys = rand_keys(rng, 4000, alphabet, 1, 10)
     ac = AC.compile(keys, host_only=True, force_wide=wide)
     info = ac.info
     assert info["slot_bytes"] == (8 if wide else 4)
-    assert info["n_slots"] % 256 == 0 and info["n_slots"] >= 2 * info["n_states"] - 1
+    assert info["n_slots"] % 256 == 0
+    if fail_links == "headers":  # a header and a transition slot per state
+        assert info["n_slots"] >= 2 * info["n_states"] - 1 and info["fail_hdr_lo"] == 0
+    else:  # one slot per transition (+ the few headers), one base id per state
+        assert info["n_states"] - 1 <= info["n_slots"] < 2 * info["n_states"] - 1
     text = b"".join(rng.choice(keys) if rng.random() < 0.6 else bytes([rng.choice(alphabet)]) for _ in range(800))
     assert ImageSim(ac).match(text) == as_list(orc.AC.compile(keys).match(text))
 
@@ -115,6 +128,13 @@ def test_image_unique_bases_and_labels():
     labels = slots & 0xFF
     # no occupied slot may carry label 0 except headers; headers are exactly n_states
     assert int(np.count_nonzero(labels)) == ac.info["n_states"] - 1
+    # the state IS its base: the targets of all transitions are pairwise different (and none is the root)
+    targets = (slots[labels != 0] >> 8) & 0x3FFFFF
+    assert np.unique(targets).size == targets.size == ac.info["n_states"] - 1 and 0 not in targets
+    # shadow fail links: only the root and the deep-fail region keep fail headers, so the image holds
+    # little more than one slot per transition
+    info = ac.info
+    assert 0 < info["fail_s1_lo"] <= info["fail_s2_lo"] <= info["fail_hdr_lo"] <= info["n_slots"]
 
 
 def test_synth_generators_deterministic():
@@ -145,8 +165,8 @@ def test_synth_generators_deterministic():
 from imgsim import FilterSim  # noqa: E402
 
 
-@pytest.fixture(autouse=True)
-def _filter_opt_in(monkeypatch):
+@pytest.fixture
+def filter_opt_in(monkeypatch):
     # filter mode is opt-in (AHA_FILTER is read when a handle is compiled)
     monkeypatch.setenv("AHA_FILTER", "1")
 
@@ -158,7 +178,7 @@ def _filter_ac(keys, wide=False):
 
 @pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("seed", range(6))
-def test_filter_mode_matches_oracle(seed, wide):
+def test_filter_mode_matches_oracle(seed, wide, filter_opt_in):
     # automata too large for the LDS budget switch to filter mode; the CPU twin
     # of the FAST/PEND/EXACT lane logic must reproduce the oracle bit for bit
     rng = random.Random(300 + seed)
@@ -189,7 +209,7 @@ def test_filter_mode_matches_oracle(seed, wide):
     assert sim.stats["fast"] > 0 and sim.stats["exact"] > 0
 
 
-def test_filter_mode_on_headline_shape():
+def test_filter_mode_on_headline_shape(filter_opt_in):
     from aha_amd import synth
 
     blob, offs, nf = synth.keys(3)

@@ -30,7 +30,7 @@ kb, ko, nf = synth.keys(3)
 ob, oo, onf = synth.keys(3, seed=0x5EED1234)
 run("100k keys, own key tokens   ", kb, ko, kb, ko, nf)
 run("100k keys, foreign tokens   ", kb, ko, ob, oo, onf)
-for K in (30000, 10000):
+for K in (50000, 30000, 10000):
     sb, so, snf = synth.keys(3, K=K)
     run("%6d keys, own key tokens " % K, sb, so, sb, so, snf)
     run("%6d keys, foreign tokens " % K, sb, so, ob, oo, onf)

@@ -1,5 +1,6 @@
 """CPU model of k2_traverse's lookups on a cfg-3 sample: where do the lookups
-that leave LDS go (by state depth, probe hit/miss, fail header)?"""
+that leave LDS go (by state depth, probe hit/miss, fail header)?  Follows the
+kernel's trip incl. the shadow fail links (include/aha_hip.h, aha_ac_info_t)."""
 import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +12,7 @@ ac = AC.compile_packed(kb, ko, host_only=True)
 info = ac.info
 slots = ac.export(0, np.uint32)
 T = info["lds_slots"]
+S1, S2, HDR = info["fail_s1_lo"], info["fail_s2_lo"], info["fail_hdr_lo"]
 n = slots.size
 label = slots & 0xFF
 base = (slots >> 8) & 0x3FFFFF
@@ -32,10 +34,7 @@ while level.size:
     level = np.concatenate(nxt) if nxt else np.array([], dtype=np.int64)
     d += 1
     depth[level] = d
-print("states per depth", counts[:10], "T", T, "slots", n)
-for dd in range(1, 7):
-    b = np.nonzero(depth == dd)[0]
-    print("depth", dd, "header slots: min", b.min(), "max", b.max(), "in LDS", int((b < T).sum()), "of", b.size)
+print("states per depth", counts[:8], "T", T, "slots", n, "fail ranges", S1, S2, HDR)
 
 NB = 1 << 21
 corpus, doc = synth.corpus(3, kb, ko, nf, n_bytes=NB)
@@ -43,6 +42,7 @@ sl = slots.tolist()
 dep = depth.tolist()
 cat = collections.Counter()
 B = 0; fr = 0; hdr = False
+r1 = 0; s2 = 0
 i = 0
 text = corpus.tobytes()
 trips = 0
@@ -52,27 +52,35 @@ while i < NB:
     trips += 1
     idx = B if hdr else (B ^ b)
     en = sl[idx]
-    where = "lds" if idx < T else "l2"
+    where = "lds" if idx < T else "far"
     if hdr:
         cat[("hdr", where, dep[B])] += 1
         B = (en >> 8) & 0x3FFFFF; fr = en & FR; hdr = False
         continue
     m = (en & 0xFF) == b
     cat[("probe", where, dep[B], "hit" if m else "miss")] += 1
+    e0 = sl[b]
+    mr = (e0 & 0xFF) == b
+    e2 = sl[((r1 >> 8) & 0x3FFFFF) ^ b]
+    consumed = False
     if m:
-        B = (en >> 8) & 0x3FFFFF; fr = en & FR; i += 1
-        continue
-    if B == 0 or fr:
-        e0 = sl[b]
-        if (e0 & 0xFF) == b:
-            B = (e0 >> 8) & 0x3FFFFF; fr = e0 & FR
-        else:
-            B = 0; fr = 0
-        i += 1
+        B = (en >> 8) & 0x3FFFFF; fr = en & FR; consumed = True
+    elif B == 0 or fr:
+        if mr: B = (e0 >> 8) & 0x3FFFFF; fr = e0 & FR
+        else: B = 0; fr = 0
+        consumed = True
+    elif S1 <= B < S2:
+        B = (r1 >> 8) & 0x3FFFFF; fr = r1 & FR
+    elif S2 <= B < HDR:
+        B = (s2 >> 8) & 0x3FFFFF; fr = s2 & FR
     else:
         hdr = True
+    if consumed:
+        s2 = e2 if (e2 & 0xFF) == b else (e0 if mr else 0)
+        r1 = e0 if mr else 0
+        i += 1
 print("trips/byte %.3f" % (trips / NB))
-tot_l2 = sum(v for k, v in cat.items() if k[1] == "l2")
-print("lookups leaving LDS per byte %.3f" % (tot_l2 / NB))
-for k, v in sorted(cat.items(), key=lambda kv: -kv[1]):
+tot_far = sum(v for k, v in cat.items() if k[1] == "far")
+print("lookups leaving LDS per byte %.3f" % (tot_far / NB))
+for k, v in sorted(cat.items(), key=lambda kv: -kv[1])[:18]:
     print("%-34s %.4f /byte" % (str(k), v / NB))

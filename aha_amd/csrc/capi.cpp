@@ -447,6 +447,10 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   const char *fe = getenv("AHA_FILTER");
   const char *sf = getenv("AHA_SHADOW_FAIL");
   bool shadow = !(fe && strcmp(fe, "1") == 0) && !(sf && strcmp(sf, "0") == 0);
+  // A small automaton that fits LDS with a header for every state keeps them: its kernel (ALL_LDS) reads the
+  // header beside the probe, which is cheaper than keeping the shadow state.
+  bool try_headers_first = shadow && (size_t)ac->aut.n_states * 2 * 8 <= kLdsPerCU;
+  if (try_headers_first) shadow = false;
   for (;;) {
     place_states(ac->aut, pl, shadow, shadow);
     if (!encode_image(ac->aut, pl, (flags & AHA_OPT_FORCE_WIDE) != 0, img)) {
@@ -457,6 +461,12 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     ac->compact = img.compact;
     ac->slot_bytes = img.compact ? 4 : 8;
     plan_engine(ac, pl);
+    if (try_headers_first) {
+      try_headers_first = false;
+      if (ac->v2_lds_slots >= ac->n_slots) break;  // fits: done
+      shadow = true;
+      continue;
+    }
     // the traversal probes the depth-1 rows in LDS to keep the shadow state: they must all be resident
     if (!shadow || pl.seg_start[2] <= ac->v2_lds_slots) break;
     shadow = false;

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
     // depth<=2 state of the last two consumed bytes.  A miss in a state whose base lies in [s2_lo, s2_hi) continues
     // in s2's state in the same trip: no header trip, no far header load.
     slot_t r1 = slot_t{}, s2 = slot_t{};
+    uint32_t hm = 0xFFu;  // partial-prefix trip: 0xFF = probe trip, 0 = header trip (label 0)
     uint32_t lc = 0, lc_exact = 0, lead_total = 0;
     if (live) {
       dn = first_boundary(M.doc_off, D, (uint64_t)a);
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             hdr = false;
             r1 = slot_t{};
             s2 = slot_t{};
+            hm = 0xFFu;
             doc_start = here;
             docrel = -(int32_t)rel;
             lc = 0;
@@ -242,66 +244,109 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
         bool ev = false;
         uint32_t en_keep = 0;
         if (act) {
-          const uint32_t b = inl[rel];
-          const uint32_t idx = hdr ? B : (B ^ b);
-          // the root row is always LDS resident: its probe is issued beside the
-          // state's own lookup, so "fail to root, retry the byte there" costs no extra trip
-          const slot_t e0 = lt[root ^ b];
-          // ALL_LDS (small automata, a fail header for every state): the header of the current state is loaded
-          // beside the probe and used on a non-root miss -- cfg 2 runs 1.55 instead of 2.1 trips per byte.
-          slot_t eh = e0;
-          if constexpr (ALL_LDS) eh = lt[B];
-          slot_t en;
-          if (ALL_LDS || idx < T)
-            en = lt[idx];
-          else
-            en = gt[idx];
-          const bool bz = b == 0;                                 // NUL contract: state := root
-          const bool m = !hdr && !bz && S_::match(en, b);         // goto (cedar.cr:441-447)
-          const bool take = hdr || m;                             // state := the entry's target
-          const bool viaroot = !take && (B == root || fr != 0 || bz);  // nid = fails[nid] = root, then probe there
-          const bool mr = !bz && S_::match(e0, b);                // b has a depth-1 state
-          const bool m0 = viaroot && mr;                          // goto from root
-          const bool consumed = m || viaroot;                     // at root a miss consumes the byte (ac.cr:188)
-          // fails[nid] of a deep state = the depth<=2 state of the last two bytes (s2), of a depth-2 state = the
-          // depth-1 state of the last byte (r1): continue there right away -- no header trip, and such states own
-          // no header slot at all (automaton.hpp, Placement::headerless).  All ranges are empty when off.
-          bool s2go = false;
-          slot_t e2 = e0, sx = e0;
-          if constexpr (!ALL_LDS) {
-            const bool s1go = !take && !viaroot && (B - A.s1_lo) < (A.s2_lo - A.s1_lo);
-            s2go = !take && !viaroot && (B - A.s2_lo) < (A.s2_hi - A.s2_lo);
-            e2 = lt[S_::base(r1) ^ b];                            // depth-1 rows are always LDS resident
-            sx = s1go ? r1 : s2;
-            s2go = s2go || s1go;
-          }
-          hdr = !take && !viaroot && !s2go;                       // next trip loads fails[nid] (ac.cr:189)
-          const slot_t ex = s2go ? sx : (m0 ? e0 : en);
-          const bool land = take || m0 || s2go;
-          B = land ? S_::base(ex) : (viaroot ? root : B);
-          fr = land ? S_::failroot(ex) : (viaroot ? 0u : fr);
           if constexpr (ALL_LDS) {
-            if (hdr) {  // follow the fail link in this trip instead of spending one on the header
-              B = S_::base(eh);
-              fr = S_::failroot(eh);
-              hdr = false;
+            const uint32_t b = inl[rel];
+            const uint32_t idx = hdr ? B : (B ^ b);
+            // the root row is always LDS resident: its probe is issued beside the
+            // state's own lookup, so "fail to root, retry the byte there" costs no extra trip
+            const slot_t e0 = lt[root ^ b];
+            // ALL_LDS (small automata, a fail header for every state): the header of the current state is loaded
+            // beside the probe and used on a non-root miss -- cfg 2 runs 1.55 instead of 2.1 trips per byte.
+            slot_t eh = e0;
+            if constexpr (ALL_LDS) eh = lt[B];
+            slot_t en;
+            if (ALL_LDS || idx < T)
+              en = lt[idx];
+            else
+              en = gt[idx];
+            const bool bz = b == 0;                                 // NUL contract: state := root
+            const bool m = !hdr && !bz && S_::match(en, b);         // goto (cedar.cr:441-447)
+            const bool take = hdr || m;                             // state := the entry's target
+            const bool viaroot = !take && (B == root || fr != 0 || bz);  // nid = fails[nid] = root, then probe there
+            const bool mr = !bz && S_::match(e0, b);                // b has a depth-1 state
+            const bool m0 = viaroot && mr;                          // goto from root
+            const bool consumed = m || viaroot;                     // at root a miss consumes the byte (ac.cr:188)
+            // fails[nid] of a deep state = the depth<=2 state of the last two bytes (s2), of a depth-2 state = the
+            // depth-1 state of the last byte (r1): continue there right away -- no header trip, and such states own
+            // no header slot at all (automaton.hpp, Placement::headerless).  All ranges are empty when off.
+            bool s2go = false;
+            slot_t e2 = e0, sx = e0;
+            if constexpr (!ALL_LDS) {
+              const bool s1go = !take && !viaroot && (B - A.s1_lo) < (A.s2_lo - A.s1_lo);
+              s2go = !take && !viaroot && (B - A.s2_lo) < (A.s2_hi - A.s2_lo);
+              e2 = lt[S_::base(r1) ^ b];                            // depth-1 rows are always LDS resident
+              sx = s1go ? r1 : s2;
+              s2go = s2go || s1go;
             }
-          }
-          ev = (m || m0) && S_::end(ex) && emit_ok;               // is_end? -> fetch later (ac.cr:183-185)
-          if constexpr (!ALL_LDS) {
+            hdr = !take && !viaroot && !s2go;                       // next trip loads fails[nid] (ac.cr:189)
+            const slot_t ex = s2go ? sx : (m0 ? e0 : en);
+            const bool land = take || m0 || s2go;
+            B = land ? S_::base(ex) : (viaroot ? root : B);
+            fr = land ? S_::failroot(ex) : (viaroot ? 0u : fr);
+            if constexpr (ALL_LDS) {
+              if (hdr) {  // follow the fail link in this trip instead of spending one on the header
+                B = S_::base(eh);
+                fr = S_::failroot(eh);
+                hdr = false;
+              }
+            }
+            ev = (m || m0) && S_::end(ex) && emit_ok;               // is_end? -> fetch later (ac.cr:183-185)
+            if constexpr (!ALL_LDS) {
+              // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
+              const bool m2 = !bz && S_::match(e2, b);
+              const slot_t s2n = m2 ? e2 : (mr ? e0 : slot_t{});
+              s2 = consumed ? s2n : s2;
+              r1 = consumed ? (mr ? e0 : slot_t{}) : r1;
+            }
+            if (CHARS) {
+              const uint32_t isl = (consumed && emit_ok && (b & 0xC0u) != 0x80u) ? 1u : 0u;
+              lc += isl;
+              lead_total += isl;
+            }
+            rel += consumed ? 1u : 0u;
+            en_keep = S_::payload(ex);
+          } else {
+            // Partial prefix: the trip with few mask operations.  A header trip is a probe with label 0 (the
+            // header slot is slot[B ^ 0] and carries label 0), so one compare serves goto and header alike;
+            // `hm` is 0xFF in a probe trip and 0 in a header trip.
+            const uint32_t b = inl[rel];
+            const uint32_t c = b & hm;
+            const uint32_t idx = B ^ c;
+            const slot_t e0 = lt[root ^ b];                         // root row: always LDS resident
+            const slot_t e2 = lt[S_::base(r1) ^ b];                 // depth-1 rows: always LDS resident
+            slot_t en;
+            if (idx < T)
+              en = lt[idx];
+            else
+              en = gt[idx];
+            const bool nz = b != 0;
+            const bool bzp = !nz && hm != 0;                        // NUL contract: state := root, byte consumed
+            const bool t = S_::match(en, c) && !bzp;                // goto (cedar.cr:441-447), or the header itself
+            const bool atroot = B == root || fr != 0 || bzp;        // fails[nid] = root: probe the root row now
+            const bool mr = nz && S_::match(e0, b);                 // b has a depth-1 state
+            // fails[nid] of a state in [s1_lo, s2_hi) follows from the last bytes (r1 / s2): continue there
+            const bool sgo = !t && !atroot && (B - A.s1_lo) < (A.s2_hi - A.s1_lo);
+            const slot_t sx = B < A.s2_lo ? r1 : s2;
+            const slot_t ex = t ? en : (sgo ? sx : (mr ? e0 : slot_t{}));
+            const bool land = t || atroot || sgo;                   // else: the next trip loads fails[nid] (ac.cr:189)
+            const bool consumed = t ? hm != 0 : atroot;             // at root a miss consumes the byte (ac.cr:188)
+            B = land ? S_::base(ex) : B;
+            fr = land ? S_::failroot(ex) : fr;
+            hm = land ? 0xFFu : 0u;
+            ev = consumed && S_::end(ex) && emit_ok;                // is_end? -> fetch later (ac.cr:183-185)
             // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
-            const bool m2 = !bz && S_::match(e2, b);
-            const slot_t s2n = m2 ? e2 : (mr ? e0 : slot_t{});
+            const slot_t r1n = mr ? e0 : slot_t{};
+            const slot_t s2n = (nz && S_::match(e2, b)) ? e2 : r1n;
             s2 = consumed ? s2n : s2;
-            r1 = consumed ? (mr ? e0 : slot_t{}) : r1;
+            r1 = consumed ? r1n : r1;
+            if (CHARS) {
+              const uint32_t isl = (consumed && emit_ok && (b & 0xC0u) != 0x80u) ? 1u : 0u;
+              lc += isl;
+              lead_total += isl;
+            }
+            rel += consumed ? 1u : 0u;
+            en_keep = S_::payload(ex);
           }
-          if (CHARS) {
-            const uint32_t isl = (consumed && emit_ok && (b & 0xC0u) != 0x80u) ? 1u : 0u;
-            lc += isl;
-            lead_total += isl;
-          }
-          rel += consumed ? 1u : 0u;
-          en_keep = S_::payload(ex);
         }
         if (__any(ev)) {
           if (M.direct) {

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             else
               en = gt[idx];
             const bool nz = b != 0;
-            const bool bzp = !nz && hm != 0;                        // NUL contract: state := root, byte consumed
+            const bool probe = hm != 0;
+            const bool bzp = !nz && probe;                          // NUL contract: state := root, byte consumed
             const bool t = S_::match(en, c) && !bzp;                // goto (cedar.cr:441-447), or the header itself
             const bool atroot = B == root || fr != 0 || bzp;        // fails[nid] = root: probe the root row now
             const bool mr = nz && S_::match(e0, b);                 // b has a depth-1 state
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             const slot_t sx = B < A.s2_lo ? r1 : s2;
             const slot_t ex = t ? en : (sgo ? sx : (mr ? e0 : slot_t{}));
             const bool land = t || atroot || sgo;                   // else: the next trip loads fails[nid] (ac.cr:189)
-            const bool consumed = t ? hm != 0 : atroot;             // at root a miss consumes the byte (ac.cr:188)
+            const bool consumed = (t && probe) || (!t && atroot);   // at root a miss consumes the byte (ac.cr:188)
             B = land ? S_::base(ex) : B;
             fr = land ? S_::failroot(ex) : fr;
             hm = land ? 0xFFu : 0u;

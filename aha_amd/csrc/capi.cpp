@@ -50,6 +50,7 @@ struct aha_ac {
   uint32_t direct_div = 4;         // plain mode: a chunk's event region holds S / direct_div events; set to 1 (one
                                    // event per input byte: cannot overflow) once a region overflowed (hit-dense input)
   bool direct_overflowed = false;  // event regions not usable (temp too large): keep to the slab pipeline
+  bool dense_hits = true;          // more than one hit per 4 input bytes in the last call (unknown: assume so)
   bool sparse_hits = false;        // the last call produced < 16 hits per chunk: the slab pipeline (cost ~ events)
                                    // beats the region pipeline (cost ~ chunks) on such input
   struct Buf {
@@ -281,6 +282,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
                 !ac->direct_overflowed && !ac->sparse_hits;
   const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
   M.direct = direct ? 1 : 0;
+  M.dense_hits = ac->dense_hits ? 1 : 0;
   M.ev_stride = (uint32_t)std::max<uint64_t>(16, S / ac->direct_div);
   if (direct && M.n_chunks * (uint64_t)M.ev_stride * 12 > (48ull << 30)) {  // regions + offsets beyond 48 GiB of temp
     direct = false;
@@ -362,6 +364,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   if (ac->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = ac->h_v2[2];
   if (!M.chars && !M.sep) ac->sparse_hits = *n_hits < 16ull * M.n_chunks;
+  ac->dense_hits = *n_hits * 4 > N;
   if (prof) {
     aha_timing &t = ac->last;
     memset(&t, 0, sizeof(t));

@@ -103,6 +103,7 @@ struct V2Args {
   // direct event regions (plain mode): chunk c stores its events in order at evd[c * ev_stride + seq], so the
   // post passes need no sort: count (wave per chunk) -> scan -> expand (wave per chunk)
   int32_t direct;
+  int32_t dense_hits;        // the previous call produced more than one hit per 4 input bytes (or none is known)
   uint32_t ev_stride;        // events a chunk may store (S / 4); more -> overflow flag, slab pipeline instead
   uint2 *evd;                // [n_chunks * ev_stride] {state base (compact) or key id, end offset in the document}
   uint32_t *evoff;           // [n_chunks * ev_stride] hits of the chunk before this event

@@ -1110,8 +1110,9 @@ __global__ __launch_bounds__(256) void k2d_count(DevAut A, V2Args M) {
 
 // One wave (= one 64-thread workgroup) per chunk: in-wave scan of hits per event, chains
 // assembled in LDS and streamed out with coalesced stores.
-constexpr uint32_t kWaveStage = 1024;  // hits staged per batch of 64 events (12 KiB of LDS)
-
+// kWaveStage hits are staged per batch of 64 events: 1024 (12 KiB of LDS) for hit-dense input, 256 (3 KiB: more
+// workgroups per CU to hide the table gathers) otherwise; a batch with more hits takes the direct-store path.
+template <uint32_t kWaveStage>
 __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
   __shared__ uint32_t hbuf[kWaveStage * 3];
   if (M.cursor[1]) return;
@@ -1317,7 +1318,10 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
                      M.totals + 0, abortf);
   hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.chunk_hits, M.n_chunks, M.blk_a, M.hit_base);
   if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
-  hipLaunchKernelGGL(k2d_expand, dim3(grid_for(M.n_chunks, 1, 16384)), dim3(64), 0, s, A, M);
+  if (M.dense_hits)
+    hipLaunchKernelGGL(k2d_expand<1024>, dim3(grid_for(M.n_chunks, 1, 16384)), dim3(64), 0, s, A, M);
+  else
+    hipLaunchKernelGGL(k2d_expand<256>, dim3(grid_for(M.n_chunks, 1, 16384)), dim3(64), 0, s, A, M);
   if (M.doc_hit_off) {
     const uint64_t nd = M.n_docs + 1;
     hipLaunchKernelGGL(k2d_doc_offsets, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, M);

@@ -1096,11 +1096,10 @@ __global__ __launch_bounds__(256) void k2d_count(DevAut A, V2Args M) {
     uint32_t sum = 0;
     for (uint32_t i = lane; i < n; i += 64) {
       uint32_t key = reg[i].x;
-      if (COMPACT) {
-        key = (uint32_t)A.end_key[key];
-        reg[i].x = key;
-      }
-      sum += A.key_cnt[key];
+      if (COMPACT) key = (uint32_t)A.end_key[key];
+      const uint32_t cnt = A.key_cnt[key];
+      reg[i].x = key | (min(cnt, 255u) << 24);  // key ids fit 24 bits (encode_image); 255 = look the count up again
+      sum += cnt;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_down(sum, d, 64);
@@ -1131,7 +1130,9 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
       uint32_t cnt = 0;
       if (live) {
         rec = reg[i];
-        cnt = A.key_cnt[rec.x];
+        cnt = rec.x >> 24;  // packed by k2d_count
+        rec.x &= 0xFFFFFFu;
+        if (cnt == 255u) cnt = A.key_cnt[rec.x];
       }
       const uint32_t incl = wave_incl_scan(cnt);
       const uint32_t tot = __shfl(incl, 63, 64);

@@ -102,11 +102,18 @@ int32_t upload_image(aha_ac *ac, const Image &img) {
     if ((rc = upload(ac, img.narrow, &p))) return rc;
     d.slots = p;
     if ((rc = upload(ac, img.end_key, &d.end_key))) return rc;
+    std::vector<uint32_t> info(img.end_key.size(), 0xFFFFFFFFu);
+    for (size_t i = 0; i < info.size(); i++) {
+      const int32_t k = img.end_key[i];
+      if (k >= 0) info[i] = (uint32_t)k | (std::min<uint32_t>(a.key_cnt[k], 255u) << 24);
+    }
+    if ((rc = upload(ac, info, &d.end_info))) return rc;
   } else {
     const uint64_t *p = nullptr;
     if ((rc = upload(ac, img.wide, &p))) return rc;
     d.slots = p;
     d.end_key = nullptr;
+    d.end_info = nullptr;
   }
   std::vector<uint2> ln(a.n_keys);
   for (uint32_t k = 0; k < a.n_keys; k++) ln[k] = uint2{a.key_len[k], (uint32_t)a.key_next[k]};

@@ -11,6 +11,7 @@ namespace aha {
 struct DevAut {
   const void *slots;         // uint2[n_slots] (wide) or uint32[n_slots] (compact)
   const int32_t *end_key;    // compact only: key id at header slots of end states
+  const uint32_t *end_info;  // compact only: end_key | min(key_cnt, 255) << 24 (one gather in the count pass)
   const uint2 *key_ln;       // [K] {len, next}: ac.cr key_lens / output.next chain
   const uint32_t *key_cnt;   // [K] hits emitted when the key's state is reached
   const uint32_t *key_kc;    // [K] lead bytes in key[1..len)

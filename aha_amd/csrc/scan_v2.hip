@@ -1095,10 +1095,17 @@ __global__ __launch_bounds__(256) void k2d_count(DevAut A, V2Args M) {
     uint2 *reg = M.evd + c * M.ev_stride;
     uint32_t sum = 0;
     for (uint32_t i = lane; i < n; i += 64) {
-      uint32_t key = reg[i].x;
-      if (COMPACT) key = (uint32_t)A.end_key[key];
-      const uint32_t cnt = A.key_cnt[key];
-      reg[i].x = key | (min(cnt, 255u) << 24);  // key ids fit 24 bits (encode_image); 255 = look the count up again
+      // the event record gets the key and (8 bits, 255 = look it up) the chain length: key ids fit 24 bits
+      uint32_t x = reg[i].x, cnt;
+      if (COMPACT) {
+        x = A.end_info[x];
+        cnt = x >> 24;
+        if (cnt == 255u) cnt = A.key_cnt[x & 0xFFFFFFu];
+      } else {
+        cnt = A.key_cnt[x];
+        x |= min(cnt, 255u) << 24;
+      }
+      reg[i].x = x;
       sum += cnt;
     }
 #pragma unroll

@@ -1,0 +1,77 @@
+"""Differential fuzzing of the HIP path against the CPU oracle (test tooling, run on the GPU box):
+random automata (small alphabets -> deep fail links, UTF-8-like bytes, nested keys), random batches
+(ragged documents, NUL bytes), random image variants (compact/wide, capped LDS prefix, shadow fail
+links on/off, two-pass engine).  python tools/fuzz_gpu.py [seconds] [seed]"""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import pyoracle as orc
+from aha_amd import AC
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_end = time.time() + budget
+ALPHABETS = [b"ab", b"abc", b"abcd", b"ab\xe4\xb8\x80", b"abcdefgh", b"xyz\xd0\xb0\xd1\x8f\xe4\xb8\xad\xe5\x9b\xbd",
+             bytes(range(0x61, 0x7b)), bytes(range(1, 256))]
+n_cases = n_hits = 0
+seed = seed0
+while time.time() < t_end:
+    rng = random.Random(seed)
+    alpha = rng.choice(ALPHABETS)
+    nk = rng.choice([1, 3, 20, 200, 2000, 20000])
+    lo, hi = rng.choice([(1, 3), (1, 8), (2, 12), (1, 24)])
+    keys, seen = [], set()
+    tries = 0
+    while len(keys) < nk and tries < nk * 20:
+        tries += 1
+        if keys and rng.random() < 0.3:  # nested / overlapping keys: suffixes and extensions of existing ones
+            k = rng.choice(keys)
+            k = k[rng.randint(0, len(k) - 1):] if rng.random() < 0.5 else k + bytes([rng.choice(alpha)])
+        else:
+            k = bytes(rng.choice(alpha) for _ in range(rng.randint(lo, hi)))
+        if k and k not in seen and len(k) <= 64:
+            seen.add(k)
+            keys.append(k)
+    env = {"AHA_LDS_SLOTS": rng.choice([None, None, "512", "1024", "4096"]),
+           "AHA_SHADOW_FAIL": rng.choice([None, None, None, "0"]),
+           "AHA_ENGINE": rng.choice([None, None, None, "v1"]),
+           "AHA_DIRECT": rng.choice([None, None, "0"])}
+    for k, v in env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    wide = rng.random() < 0.25
+    ac = AC.compile(keys, force_wide=wide)
+    o = orc.AC.compile(keys)
+    for _ in range(rng.randint(1, 3)):
+        n = rng.choice([0, 1, 17, 1000, 20000, 300000])
+        parts = []
+        while sum(map(len, parts)) < n:
+            r = rng.random()
+            if r < 0.4 and keys:
+                parts.append(rng.choice(keys))
+            elif r < 0.45:
+                parts.append(b"\x00")
+            else:
+                parts.append(bytes(rng.choice(alpha) for _ in range(rng.randint(1, 9))))
+        text = np.frombuffer(b"".join(parts)[:n] if n else b"", dtype=np.uint8)
+        cuts = sorted(set([0, text.size] + [rng.randint(0, text.size) for _ in range(rng.choice([0, 1, 5, 60]))]))
+        if rng.random() < 0.3:
+            cuts = sorted(cuts + cuts[1:3])  # empty documents
+        doc = np.array(cuts, dtype=np.uint64)
+        chars = False
+        gh, gd = ac.match_batch(text, doc)
+        oh, od = o.match_batch(text, doc)
+        ok = len(gh) == len(oh) and np.array_equal(np.asarray(gh).view(np.int32), np.asarray(oh).view(np.int32)) and \
+            np.array_equal(np.asarray(gd, dtype=np.uint64), np.asarray(od, dtype=np.uint64))
+        if not ok:
+            print("MISMATCH seed", seed, "alphabet", alpha[:8], "keys", len(keys), "env", env, "wide", wide,
+                  "n", text.size, "docs", doc.size - 1, "hits gpu/oracle", len(gh), len(oh), flush=True)
+            sys.exit(1)
+        n_cases += 1
+        n_hits += len(gh)
+    seed += 1
+print(f"fuzz ok: {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")

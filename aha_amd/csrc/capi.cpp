@@ -285,7 +285,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   M.doc_hit_off = M1.doc_hit_off;
   // plain mode (byte offsets, no separator filter, no boundary filter): per-chunk event regions, no sort
   const char *de = getenv("AHA_DIRECT");
-  bool direct = !(de && strcmp(de, "0") == 0) && !M.chars && !M.sep && ac->flt.d0 == 0 && allow_direct &&
+  bool direct = !(de && strcmp(de, "0") == 0) && !M.sep && ac->flt.d0 == 0 && allow_direct &&
                 !ac->direct_overflowed && !ac->sparse_hits;
   const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
   M.direct = direct ? 1 : 0;
@@ -370,7 +370,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   }
   if (ac->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = ac->h_v2[2];
-  if (!M.chars && !M.sep) ac->sparse_hits = *n_hits < 16ull * M.n_chunks;
+  if (!M.sep) ac->sparse_hits = *n_hits < 16ull * M.n_chunks;
   ac->dense_hits = *n_hits * 4 > N;
   if (prof) {
     aha_timing &t = ac->last;

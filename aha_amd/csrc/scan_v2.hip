@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             // plain mode: the chunk's events go, in order, to its own region -- no compaction, no sort
             if (ev) {
               if (seq < ev_stride)
-                evreg[seq] = make_uint2(en_keep, (uint32_t)(docrel + (int32_t)rel));
+                evreg[seq] = make_uint2(en_keep, CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel));
               else
                 M.cursor[1] = 2ull;  // region full: the host repeats the call with the slab pipeline
               seq++;
@@ -1118,7 +1118,9 @@ __global__ __launch_bounds__(256) void k2d_count(DevAut A, V2Args M) {
 // assembled in LDS and streamed out with coalesced stores.
 // kWaveStage hits are staged per batch of 64 events: 1024 (12 KiB of LDS) for hit-dense input, 256 (3 KiB: more
 // workgroups per CU to hide the table gathers) otherwise; a batch with more hits takes the direct-store path.
-template <uint32_t kWaveStage>
+// CHARS (String overload, matcher.cr:34-39): the record's second word is the lead-byte count of the position
+// (<< 1 | "counted from the document start") instead of the byte offset; hits are char offsets.
+template <uint32_t kWaveStage, bool CHARS>
 __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
   __shared__ uint32_t hbuf[kWaveStage * 3];
   if (M.cursor[1]) return;
@@ -1130,6 +1132,12 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
     uint32_t *eoff = M.evoff + c * M.ev_stride;
     const uint64_t base = M.hit_base[c];
     uint32_t run = 0;
+    int32_t lead_adj = 0;  // CHARS: lead bytes between the start of the document that contains the chunk start and it
+    if (CHARS) {
+      const uint32_t d0 = M.chunk_doc0[c];
+      const uint64_t dchunk = M.doc_off[d0] / M.S;
+      lead_adj = (int32_t)(M.lead_base[c] - (M.lead_base[dchunk] + M.doc_lead_rank[d0]));
+    }
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
       const uint32_t i = i0 + lane;
       const bool live = i < n;
@@ -1140,6 +1148,7 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
         cnt = rec.x >> 24;  // packed by k2d_count
         rec.x &= 0xFFFFFFu;
         if (cnt == 255u) cnt = A.key_cnt[rec.x];
+        if (CHARS) rec.y = (rec.y >> 1) + ((rec.y & 1u) ? 0u : (uint32_t)lead_adj);  // end offset in chars
       }
       const uint32_t incl = wave_incl_scan(cnt);
       const uint32_t tot = __shfl(incl, 63, 64);
@@ -1151,7 +1160,8 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
           int32_t k = (int32_t)rec.x;
           do {  // fetch (ac.cr:265-278): own key, then the output chain
             const uint2 ln = A.key_ln[k];
-            hbuf[w] = rec.y - ln.x;  // Hit(idx-len+1, idx+1, value) ac.cr:271-273
+            // Hit(idx-len+1, idx+1, value) ac.cr:271-273; chars: Hit(char_of_byte[start], char_of_byte[end-1]+1)
+            hbuf[w] = CHARS ? rec.y - A.key_kc[k] - 1u : rec.y - ln.x;
             hbuf[w + 1] = rec.y;
             hbuf[w + 2] = (uint32_t)k;
             w += 3;
@@ -1172,7 +1182,7 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
           const uint2 ln = A.key_ln[k];
           if (idx < M.cap) {
             aha_hit h;
-            h.start = (int32_t)rec.y - (int32_t)ln.x;
+            h.start = CHARS ? (int32_t)rec.y - (int32_t)A.key_kc[k] - 1 : (int32_t)rec.y - (int32_t)ln.x;
             h.end = (int32_t)rec.y;
             h.value = k;
             M.out[idx] = h;
@@ -1326,10 +1336,23 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
                      M.totals + 0, abortf);
   hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.chunk_hits, M.n_chunks, M.blk_a, M.hit_base);
   if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
-  if (M.dense_hits)
-    hipLaunchKernelGGL(k2d_expand<1024>, dim3(grid_for(M.n_chunks, 1, 16384)), dim3(64), 0, s, A, M);
-  else
-    hipLaunchKernelGGL(k2d_expand<256>, dim3(grid_for(M.n_chunks, 1, 16384)), dim3(64), 0, s, A, M);
+  const dim3 ge(grid_for(M.n_chunks, 1, 16384));
+  if (M.chars) {
+    // lead bytes before every chunk (the traversal counted them per chunk)
+    hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.lead_cnt, (const uint64_t *)nullptr, M.n_chunks,
+                       M.blk_b, abortf);
+    hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_b, (const uint64_t *)nullptr, M.n_chunks,
+                       M.totals + 1, abortf);
+    hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.lead_cnt, M.n_chunks, M.blk_b, M.lead_base);
+    if (M.dense_hits)
+      hipLaunchKernelGGL((k2d_expand<1024, true>), ge, dim3(64), 0, s, A, M);
+    else
+      hipLaunchKernelGGL((k2d_expand<256, true>), ge, dim3(64), 0, s, A, M);
+  } else if (M.dense_hits) {
+    hipLaunchKernelGGL((k2d_expand<1024, false>), ge, dim3(64), 0, s, A, M);
+  } else {
+    hipLaunchKernelGGL((k2d_expand<256, false>), ge, dim3(64), 0, s, A, M);
+  }
   if (M.doc_hit_off) {
     const uint64_t nd = M.n_docs + 1;
     hipLaunchKernelGGL(k2d_doc_offsets, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, M);

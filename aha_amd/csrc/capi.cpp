@@ -291,7 +291,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   M.direct = direct ? 1 : 0;
   M.dense_hits = ac->dense_hits ? 1 : 0;
   M.ev_stride = (uint32_t)std::max<uint64_t>(16, S / ac->direct_div);
-  if (direct && M.n_chunks * (uint64_t)M.ev_stride * 12 > (48ull << 30)) {  // regions + offsets beyond 48 GiB of temp
+  if (direct && M.n_chunks * (uint64_t)M.ev_stride * 8 > (48ull << 30)) {  // regions beyond 48 GiB of temp
     direct = false;
     M.direct = 0;
   }
@@ -305,7 +305,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
                       n_blk * 8,          16 * 8,             M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
                       M.chars ? M.n_chunks * 4 : 0, M.chars ? M.n_chunks * 4 : 0, M.chars ? (M.n_docs + 1) * 4 : 0,
                       M.chars ? M.n_chunks * 8 : 0,
-                      n_reg * 8,          n_reg * 4,          direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
+                      n_reg * 8,          0,                  direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
                       0, 0, 0, 0};
   for (int i = 0; i < 24; i++)
     if (sizes[i] && (rc = v2_reserve(ac, i, sizes[i]))) return rc;
@@ -327,7 +327,6 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   M.doc_lead_rank = (uint32_t *)ac->v2buf[14].p;
   M.lead_base = (uint64_t *)ac->v2buf[15].p;
   M.evd = (uint2 *)ac->v2buf[16].p;
-  M.evoff = (uint32_t *)ac->v2buf[17].p;
   M.chunk_hits = (uint32_t *)ac->v2buf[18].p;
   M.hit_base = (uint64_t *)ac->v2buf[19].p;
   if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));

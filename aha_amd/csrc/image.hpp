@@ -107,7 +107,6 @@ struct V2Args {
   int32_t dense_hits;        // the previous call produced more than one hit per 4 input bytes (or none is known)
   uint32_t ev_stride;        // events a chunk may store (S / 4); more -> overflow flag, slab pipeline instead
   uint2 *evd;                // [n_chunks * ev_stride] {state base (compact) or key id, end offset in the document}
-  uint32_t *evoff;           // [n_chunks * ev_stride] hits of the chunk before this event
   uint32_t *chunk_hits;      // [n_chunks]
   uint64_t *hit_base;        // [n_chunks] exclusive scan of chunk_hits
   aha_hit *out;

@@ -1129,7 +1129,6 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
     const uint32_t n = M.ev_cnt[c];
     if (n == 0) continue;
     const uint2 *reg = M.evd + c * M.ev_stride;
-    uint32_t *eoff = M.evoff + c * M.ev_stride;
     const uint64_t base = M.hit_base[c];
     uint32_t run = 0;
     int32_t lead_adj = 0;  // CHARS: lead bytes between the start of the document that contains the chunk start and it
@@ -1153,7 +1152,6 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
       const uint32_t incl = wave_incl_scan(cnt);
       const uint32_t tot = __shfl(incl, 63, 64);
       const uint32_t off = incl - cnt;
-      if (live) eoff[i] = run + off;
       if (tot <= kWaveStage) {
         if (live) {
           uint32_t w = off * 3;
@@ -1196,7 +1194,9 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
   }
 }
 
-__global__ __launch_bounds__(256) void k2d_doc_offsets(V2Args M) {
+// doc_hit_off[d] = hits before the document's first event: the chunk's hit base + the chain lengths (carried by the
+// records since k2d_count) of the chunk's events before it.  One thread per document; a chunk holds few events.
+__global__ __launch_bounds__(256) void k2d_doc_offsets(DevAut A, V2Args M) {
   if (M.cursor[1] || !M.doc_hit_off) return;
   const uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (d > M.n_docs) return;
@@ -1205,7 +1205,18 @@ __global__ __launch_bounds__(256) void k2d_doc_offsets(V2Args M) {
   if (q < M.n_bytes) {
     const uint64_t c = q / M.S;
     const uint32_t rank = M.doc_ev_rank[d];
-    r = M.hit_base[c] + (rank < M.ev_cnt[c] ? M.evoff[c * M.ev_stride + rank] : M.chunk_hits[c]);
+    if (rank >= M.ev_cnt[c]) {
+      r = M.hit_base[c] + M.chunk_hits[c];
+    } else {
+      const uint2 *reg = M.evd + c * M.ev_stride;
+      uint64_t before = 0;
+      for (uint32_t i = 0; i < rank; i++) {
+        const uint32_t x = reg[i].x;
+        const uint32_t cnt = x >> 24;
+        before += cnt == 255u ? A.key_cnt[x & 0xFFFFFFu] : cnt;
+      }
+      r = M.hit_base[c] + before;
+    }
   }
   M.doc_hit_off[d] = r;
 }
@@ -1355,7 +1366,7 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
   }
   if (M.doc_hit_off) {
     const uint64_t nd = M.n_docs + 1;
-    hipLaunchKernelGGL(k2d_doc_offsets, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, M);
+    hipLaunchKernelGGL(k2d_doc_offsets, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, A, M);
   }
 }
 

@@ -314,6 +314,10 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             const uint32_t idx = B ^ c;
             const slot_t e0 = lt[root ^ b];                         // root row: always LDS resident
             const slot_t e2 = lt[S_::base(r1) ^ b];                 // depth-1 rows: always LDS resident
+            const slot_t sx = B < A.s2_lo ? r1 : s2;                // shadow fail target of B (if B has one)
+            const uint32_t i3 = S_::base(sx) ^ b;
+            const bool near3 = i3 < T;
+            const slot_t e3 = lt[near3 ? i3 : 0u];                  // sx's row (depth <= 2: mostly LDS resident)
             slot_t en;
             if (idx < T)
               en = lt[idx];
@@ -325,19 +329,25 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             const bool t = S_::match(en, c) && !bzp;                // goto (cedar.cr:441-447), or the header itself
             const bool atroot = B == root || fr != 0 || bzp;        // fails[nid] = root: probe the root row now
             const bool mr = nz && S_::match(e0, b);                 // b has a depth-1 state
-            // fails[nid] of a state in [s1_lo, s2_hi) follows from the last bytes (r1 / s2): continue there
+            // fails[nid] of a state in [s1_lo, s2_hi) follows from the last bytes: sx = r1 (depth-2 state) or s2.
+            // Its row, the row of ITS fail target (r1: e2) and the root row (e0) are probed in this same trip, so
+            // the whole rest of the fail chain is resolved here and the byte is consumed (1.19 -> 1.02 trips per
+            // byte); only when sx's row lies beyond the LDS prefix the walk continues in sx without consuming.
             const bool sgo = !t && !atroot && (B - A.s1_lo) < (A.s2_hi - A.s1_lo);
-            const slot_t sx = B < A.s2_lo ? r1 : s2;
-            const slot_t ex = t ? en : (sgo ? sx : (mr ? e0 : slot_t{}));
+            const bool sres = sgo && near3;
+            const bool m3 = nz && S_::match(e3, b);
+            const bool m2 = nz && S_::match(e2, b);
+            const slot_t chain = m3 ? e3 : (m2 ? e2 : (mr ? e0 : slot_t{}));   // first goto along sx -> r1 -> root
+            const slot_t ex = t ? en : (sgo ? (near3 ? chain : sx) : (mr ? e0 : slot_t{}));
             const bool land = t || atroot || sgo;                   // else: the next trip loads fails[nid] (ac.cr:189)
-            const bool consumed = (t && probe) || (!t && atroot);   // at root a miss consumes the byte (ac.cr:188)
+            const bool consumed = (t && probe) || (!t && atroot) || sres;  // at root a miss consumes (ac.cr:188)
             B = land ? S_::base(ex) : B;
             fr = land ? S_::failroot(ex) : fr;
             hm = land ? 0xFFu : 0u;
             ev = consumed && S_::end(ex) && emit_ok;                // is_end? -> fetch later (ac.cr:183-185)
             // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
             const slot_t r1n = mr ? e0 : slot_t{};
-            const slot_t s2n = (nz && S_::match(e2, b)) ? e2 : r1n;
+            const slot_t s2n = m2 ? e2 : r1n;
             s2 = consumed ? s2n : s2;
             r1 = consumed ? r1n : r1;
             if (CHARS) {

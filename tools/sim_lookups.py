@@ -37,6 +37,7 @@ while level.size:
 print("states per depth", counts[:8], "T", T, "slots", n, "fail ranges", S1, S2, HDR)
 
 NB = 1 << 21
+INTRIP = os.environ.get('INTRIP', '1') == '1'
 corpus, doc = synth.corpus(3, kb, ko, nf, n_bytes=NB)
 sl = slots.tolist()
 dep = depth.tolist()
@@ -69,10 +70,17 @@ while i < NB:
         if mr: B = (e0 >> 8) & 0x3FFFFF; fr = e0 & FR
         else: B = 0; fr = 0
         consumed = True
-    elif S1 <= B < S2:
-        B = (r1 >> 8) & 0x3FFFFF; fr = r1 & FR
-    elif S2 <= B < HDR:
-        B = (s2 >> 8) & 0x3FFFFF; fr = s2 & FR
+    elif S1 <= B < HDR:
+        sx = r1 if B < S2 else s2
+        i3 = ((sx >> 8) & 0x3FFFFF) ^ b
+        if INTRIP and i3 < T:  # resolve the rest of the fail chain in this trip (all rows in LDS)
+            e3 = sl[i3]
+            X = e3 if (e3 & 0xFF) == b else (e2 if (e2 & 0xFF) == b else (e0 if mr else 0))
+            B = (X >> 8) & 0x3FFFFF; fr = X & FR; consumed = True
+            cat[("intrip", "lds", dep[B], "")] += 1
+        else:
+            B = (sx >> 8) & 0x3FFFFF; fr = sx & FR
+            if INTRIP: cat[("e3far", "", 0, "")] += 1
     else:
         hdr = True
     if consumed:

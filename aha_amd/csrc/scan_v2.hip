@@ -238,6 +238,8 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
           }
         }
         const uint32_t lim2 = min(lim, nb_rel);  // lanes park at the next boundary: no boundary test per trip
+        uint32_t bcur = 0;
+        if constexpr (!ALL_LDS) bcur = inl[min(rel, (uint32_t)kV2Piece)];  // first byte of this run of trips
       for (;;) {
         const bool act = rel < lim2;
         if (!__any(act)) break;
@@ -309,7 +311,10 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             // Partial prefix: the trip with few mask operations.  A header trip is a probe with label 0 (the
             // header slot is slot[B ^ 0] and carries label 0), so one compare serves goto and header alike;
             // `hm` is 0xFF in a probe trip and 0 in a header trip.
-            const uint32_t b = inl[rel];
+            // the byte comes from a register: the next one was loaded during the previous trip (nearly every trip
+            // consumes), which takes the LDS round trip of the byte out of the dependent chain
+            const uint32_t b = bcur;
+            const uint32_t bnext = inl[rel + 1];                    // rows are padded: rel + 1 <= piece + 3
             const uint32_t c = b & hm;
             const uint32_t idx = B ^ c;
             const slot_t e0 = lt[root ^ b];                         // root row: always LDS resident
@@ -356,6 +361,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
               lead_total += isl;
             }
             rel += consumed ? 1u : 0u;
+            bcur = consumed ? bnext : bcur;
             en_keep = S_::payload(ex);
           }
         }

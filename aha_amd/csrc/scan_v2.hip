@@ -161,6 +161,10 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
     // in s2's state in the same trip: no header trip, no far header load.
     slot_t r1 = slot_t{}, s2 = slot_t{};
     uint32_t hm = 0xFFu;  // partial-prefix trip: 0xFF = probe trip, 0 = header trip (label 0)
+    uint4 half[kV2Piece / 16];    // second half of the current input line (see the staging code)
+#pragma unroll
+    for (int k = 0; k < kV2Piece / 16; k++) half[k] = make_uint4(0, 0, 0, 0);
+    int64_t half_pb = INT64_MIN;  // the piece `half` holds
     uint32_t lc = 0, lc_exact = 0, lead_total = 0;
     if (live) {
       dn = first_boundary(M.doc_off, D, (uint64_t)a);
@@ -182,22 +186,42 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
       if (!__any(need)) continue;
       uint32_t rel = kV2Piece, lim = 0;  // inactive: rel >= lim
       if (need) {
+        // A piece is half a 64-byte line.  The round that starts a line also loads its second half into
+        // registers for the next round, so both halves are requested while the line is in flight and every
+        // input line is fetched once (it would not survive a whole round in L2 beside the table lookups).
+        const bool line_start = (pb & 63) == 0;
+        uint4 v[kV2Piece / 16];
+        if (!line_start && half_pb == pb) {
+#pragma unroll
+          for (int k = 0; k < kV2Piece / 16; k++) v[k] = half[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < kV2Piece / 16; k++) {
+            const int64_t g = pb + k * 16;
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (g >= 0 && g + 16 <= N) {
+              v[k] = *reinterpret_cast<const uint4 *>(M.text + g);
+            } else if (g >= 0 && g < N) {
+              uint32_t w[4] = {0, 0, 0, 0};
+              for (int j = 0; j < 16 && g + j < N; j++) w[j >> 2] |= (uint32_t)M.text[g + j] << ((j & 3) * 8);
+              v[k] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+          }
+        }
+        half_pb = INT64_MIN;
+        if (line_start && pb >= 0 && pb + 2 * kV2Piece <= N && pb + kV2Piece < e) {
+#pragma unroll
+          for (int k = 0; k < kV2Piece / 16; k++)
+            half[k] = *reinterpret_cast<const uint4 *>(M.text + pb + kV2Piece + k * 16);
+          half_pb = pb + kV2Piece;
+        }
 #pragma unroll
         for (int k = 0; k < kV2Piece / 16; k++) {
-          const int64_t g = pb + k * 16;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (g >= 0 && g + 16 <= N) {
-            v = *reinterpret_cast<const uint4 *>(M.text + g);
-          } else if (g >= 0 && g < N) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (int j = 0; j < 16 && g + j < N; j++) w[j >> 2] |= (uint32_t)M.text[g + j] << ((j & 3) * 8);
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-          }
           uint32_t *dst = reinterpret_cast<uint32_t *>(inl + k * 16);
-          dst[0] = v.x;
-          dst[1] = v.y;
-          dst[2] = v.z;
-          dst[3] = v.w;
+          dst[0] = v[k].x;
+          dst[1] = v[k].y;
+          dst[2] = v[k].z;
+          dst[3] = v[k].w;
         }
         rel = (uint32_t)(pos - pb);
         lim = (uint32_t)(pend - pb);
@@ -370,7 +394,11 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             // plain mode: the chunk's events go, in order, to its own region -- no compaction, no sort
             if (ev) {
               if (seq < ev_stride)
-                evreg[seq] = make_uint2(en_keep, CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel));
+              {
+                typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+                const v2u rec = {en_keep, CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel)};
+                __builtin_nontemporal_store(rec, reinterpret_cast<v2u *>(evreg + seq));  // streamed: keep L2 for the image
+              }
               else
                 M.cursor[1] = 2ull;  // region full: the host repeats the call with the slab pipeline
               seq++;

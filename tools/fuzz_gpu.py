@@ -74,4 +74,6 @@ while time.time() < t_end:
         n_cases += 1
         n_hits += len(gh)
     seed += 1
+    if seed % 5 == 0:
+        print(f"[fuzz] {seed - seed0} automata, {n_cases} batches, {n_hits} hits ok", flush=True)
 print(f"fuzz ok: {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")

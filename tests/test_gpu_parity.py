@@ -338,6 +338,47 @@ def test_full_size_properties(cfg, engine):
         assert hits[offsets[d]:offsets[d + 1]].tobytes() == oh.tobytes()
 
 
+def test_corpus_beyond_4_gib(engine):
+    """Corpus-level offsets are 64-bit (SURVEY 8 b: per-document Int32, corpus uint64): a batch of 4 GiB + 1 MiB.
+    The documents on both sides of the 2^32 boundary and a sample of the others against the oracle; global
+    invariants over all hits."""
+    if engine != "v2":
+        pytest.skip("done once, on the default engine")
+    import torch
+
+    blob, offs, nf = synth.keys(3)
+    n_bytes = (1 << 32) + (1 << 20)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=n_bytes)
+    D = doc.size - 1
+    assert int(doc[-1]) == n_bytes > 0xFFFFFFFF
+    g = AC.compile_packed(blob, offs)
+    dc = torch.from_numpy(corpus).cuda()
+    dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+    dho = torch.zeros(D + 1, dtype=torch.int64, device="cuda")
+    try:
+        n = g.match_batch_device(dc, dd, torch.zeros((1, 3), dtype=torch.int32, device="cuda"), dho)
+    except AhaError as e:
+        assert e.code == N.AHA_E_CAPACITY
+        n = e.required
+    out = torch.zeros((n + 16, 3), dtype=torch.int32, device="cuda")
+    assert g.match_batch_device(dc, dd, out, dho) == n
+    del dc
+    offsets = dho.cpu().numpy()
+    assert offsets[0] == 0 and offsets[-1] == n and np.all(np.diff(offsets) >= 0)
+    hits = out[:n].cpu().numpy()
+    key_len = np.diff(offs.astype(np.int64))
+    assert np.array_equal(hits[:, 1] - hits[:, 0], key_len[hits[:, 2]])
+    doc_len = np.diff(doc.astype(np.int64))
+    doc_of_hit = np.repeat(np.arange(D), np.diff(offsets))
+    assert np.all(hits[:, 0] >= 0) and np.all(hits[:, 1].astype(np.int64) <= doc_len[doc_of_hit])
+    o = orc.AC.compile_packed(blob, offs)
+    cross = int(np.searchsorted(doc, 1 << 32, side="right")) - 1  # the document that contains byte 2^32
+    rng = np.random.default_rng(4)
+    for d in sorted(set([0, cross - 1, cross, min(cross + 1, D - 1), D - 1] + [int(x) for x in rng.integers(0, D, 4)])):
+        oh, _ = o.match_batch(corpus[int(doc[d]):int(doc[d + 1])], np.array([0, doc_len[d]], dtype=np.uint64))
+        assert hits[offsets[d]:offsets[d + 1]].tobytes() == oh.tobytes(), d
+
+
 def test_single_large_document_vs_oracle(engine):
     """SURVEY 8d single-document variant: one 256 MiB document, so every chunk
     but the first starts in the middle of a sequence (warm-up overlap at scale).

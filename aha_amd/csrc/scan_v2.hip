@@ -393,14 +393,18 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
           if (M.direct) {
             // plain mode: the chunk's events go, in order, to its own region -- no compaction, no sort
             if (ev) {
-              if (seq < ev_stride)
-              {
+              if (seq < ev_stride) {
                 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
                 const v2u rec = {en_keep, CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel)};
-                __builtin_nontemporal_store(rec, reinterpret_cast<v2u *>(evreg + seq));  // streamed: keep L2 for the image
+                // sparse events are streamed past L2 (it keeps the image); dense ones (the previous call had more
+                // than one hit per 4 bytes) fill whole lines quickly and are better merged in L2
+                if (M.dense_hits)
+                  *reinterpret_cast<v2u *>(evreg + seq) = rec;
+                else
+                  __builtin_nontemporal_store(rec, reinterpret_cast<v2u *>(evreg + seq));
+              } else {
+                M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
               }
-              else
-                M.cursor[1] = 2ull;  // region full: the host repeats the call with the slab pipeline
               seq++;
             }
           } else {
@@ -1391,7 +1395,7 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
                      M.totals + 0, abortf);
   hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.chunk_hits, M.n_chunks, M.blk_a, M.hit_base);
   if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
-  const dim3 ge(grid_for(M.n_chunks, 1, 16384));
+  const dim3 ge(grid_for(M.n_chunks, 1, 1u << 20));
   if (M.chars) {
     // lead bytes before every chunk (the traversal counted them per chunk)
     hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.lead_cnt, (const uint64_t *)nullptr, M.n_chunks,

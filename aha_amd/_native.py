@@ -27,6 +27,7 @@ AHA_E_TOO_LARGE = -11
 AHA_OPT_HOST_ONLY = 1
 AHA_OPT_FORCE_WIDE = 2
 AHA_IMG_SLOTS, AHA_IMG_END_KEY, AHA_IMG_KEY_LN, AHA_IMG_KEY_CNT, AHA_IMG_KEY_KC = 0, 1, 2, 3, 4
+AHA_IMG_PP_T2, AHA_IMG_PP_BLOOM = 7, 8
 
 
 class aha_options(C.Structure):
@@ -45,7 +46,9 @@ class aha_ac_info_t(C.Structure):
                 ("slot_bytes", C.c_uint32), ("lds_slots", C.c_uint32), ("device", C.c_int32),
                 ("filter_d0", C.c_uint32), ("filter_words", C.c_uint32), ("filter_entries", C.c_uint64),
                 ("boundary_end", C.c_uint32), ("reserved", C.c_uint32), ("fail_s1_lo", C.c_uint32),
-                ("fail_s2_lo", C.c_uint32), ("fail_hdr_lo", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("fail_s2_lo", C.c_uint32), ("fail_hdr_lo", C.c_uint32), ("reserved2", C.c_uint32),
+                ("pp_enabled", C.c_uint32), ("pp_bloom_words", C.c_uint32), ("pp_entries", C.c_uint64),
+                ("pp_fill_permille", C.c_uint32), ("reserved3", C.c_uint32)]
 
 
 class aha_timing(C.Structure):

@@ -14,6 +14,7 @@
 
 #include "automaton.hpp"
 #include "image.hpp"
+#include "pp.hpp"
 
 using namespace aha;
 
@@ -58,6 +59,11 @@ struct aha_ac {
     size_t bytes = 0;
   };
   Buf v2buf[24];
+  // position-parallel engine (scan_pp.hip)
+  PpTables pp;
+  bool pp_ok = false;
+  const uint32_t *d_pp_t2 = nullptr, *d_pp_bloom = nullptr;
+  uint32_t pp_grid = 0;
   Buf hostbuf[4];  // device staging of the host-buffer entry points (corpus, doc offsets, doc hit offsets, hits)
   unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
   std::string err;
@@ -244,6 +250,15 @@ void v2_setup(aha_ac *ac) {
   if (reserve < 0 || reserve >= cus) reserve = 0;
   ac->v2_grid = (uint32_t)(cus - reserve) * ac->v2_bpc;
   ac->v2_ok = true;
+  // position-parallel engine: default whenever the automaton meets its preconditions (pp.hpp);
+  // AHA_ENGINE=v2 keeps the single-traversal engine
+  if (ac->pp.ok && !(eng && strcmp(eng, "v2") == 0) && !filter) {
+    if (pp_prepare((uint32_t)ac->pp.bloom.size()) != 0) return;
+    if (upload(ac, ac->pp.t2, &ac->d_pp_t2) != AHA_OK) return;
+    if (upload(ac, ac->pp.bloom, &ac->d_pp_bloom) != AHA_OK) return;
+    ac->pp_grid = (uint32_t)(cus - reserve);
+    ac->pp_ok = true;
+  }
 }
 
 int32_t v2_reserve(aha_ac *ac, int i, size_t bytes) {
@@ -389,6 +404,86 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   return AHA_OK;
 }
 
+// Position-parallel engine (plain byte offsets only).  Returns AHA_OK, an error, or +1 when the caller must take
+// the single-traversal engine (an item list or an event region overflowed: hit-dense input).
+int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
+  const uint64_t N = M1.n_bytes;
+  if (reinterpret_cast<uintptr_t>(M1.text) % 16 != 0) return 1;
+  V2Args M{};
+  M.text = M1.text;
+  M.doc_off = M1.doc_off;
+  M.n_docs = M1.n_docs;
+  M.n_bytes = N;
+  M.S = kPpChunk;
+  M.n_chunks = (N + kPpChunk - 1) / kPpChunk;
+  if (M.n_chunks > 0xFFFFFFFFull) return 1;
+  M.out = M1.out;
+  M.cap = M1.cap;
+  M.doc_hit_off = M1.doc_hit_off;
+  M.direct = 1;
+  M.dense_hits = 0;
+  M.ev_stride = kPpEvStride;
+  const uint64_t n_blk = (M.n_chunks + 255) / 256 + 2;
+  int32_t rc;
+  const int idx[9] = {4, 5, 7, 9, 16, 18, 19, 20, 21};
+  const size_t sizes[9] = {M.n_chunks * 4,      (M.n_docs + 1) * 4, n_blk * 8,
+                           16 * 8,              M.n_chunks * (size_t)kPpEvStride * 8,
+                           M.n_chunks * 4,      M.n_chunks * 8,     M.n_chunks * (size_t)kPpItemCap * 2,
+                           M.n_chunks * 4};
+  for (int i = 0; i < 9; i++)
+    if ((rc = v2_reserve(ac, idx[i], sizes[i]))) return rc;
+  M.ev_cnt = (uint32_t *)ac->v2buf[4].p;
+  M.doc_ev_rank = (uint32_t *)ac->v2buf[5].p;
+  M.blk_a = (uint64_t *)ac->v2buf[7].p;
+  M.cursor = (unsigned long long *)ac->v2buf[9].p;
+  M.totals = (uint64_t *)ac->v2buf[9].p + 2;
+  M.evd = (uint2 *)ac->v2buf[16].p;
+  M.chunk_hits = (uint32_t *)ac->v2buf[18].p;
+  M.hit_base = (uint64_t *)ac->v2buf[19].p;
+  PpArgs P{};
+  P.text = M1.text;
+  P.n_bytes = N;
+  P.n_chunks = M.n_chunks;
+  P.t2 = ac->d_pp_t2;
+  P.bloom = ac->d_pp_bloom;
+  P.b_words = (uint32_t)ac->pp.bloom.size();
+  P.items = (uint16_t *)ac->v2buf[20].p;
+  P.item_cnt = (uint32_t *)ac->v2buf[21].p;
+  P.flags = M.cursor;
+  if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+  const bool prof = ac->profiling && ac->ev_ready;
+  HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 16 * 8, s));
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
+  const uint64_t waves = (M.n_chunks + 15) / 16;  // 16 waves (chunks) per filter workgroup
+  pp_launch_filter(P, (uint32_t)std::min<uint64_t>(ac->pp_grid, std::max<uint64_t>(waves, 1)), s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
+  pp_launch_resolve(ac->dev, M, P, s);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
+  v2_launch_direct_post(ac->dev, M, s, prof ? (void *)ac->ev[3] : nullptr);
+  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[4], s));
+  HIPCHK(ac, hipGetLastError());
+  HIPCHK(ac, hipMemcpyAsync(ac->h_v2, ac->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(ac, hipStreamSynchronize(s));
+  if (ac->h_v2[1]) return 1;
+  *n_hits = ac->h_v2[2];
+  if (prof) {
+    aha_timing &t = ac->last;
+    memset(&t, 0, sizeof(t));
+    t.struct_size = sizeof(t);
+    t.engine = 3;
+    t.chunk_bytes = kPpChunk;
+    t.n_kernels = 8;
+    (void)hipEventElapsedTime(&t.ms_total, ac->ev[0], ac->ev[4]);
+    (void)hipEventElapsedTime(&t.ms_count, ac->ev[0], ac->ev[1]);
+    (void)hipEventElapsedTime(&t.ms_scan, ac->ev[1], ac->ev[2]);
+    (void)hipEventElapsedTime(&t.ms_aux, ac->ev[2], ac->ev[3]);
+    (void)hipEventElapsedTime(&t.ms_write, ac->ev[3], ac->ev[4]);
+    t.n_chunks = M.n_chunks;
+    t.n_hits = *n_hits;
+  }
+  return AHA_OK;
+}
+
 struct DeviceGuard {
   int prev = -1;
   bool active = false;
@@ -483,6 +578,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   ac->s1_lo = shadow ? pl.seg_start[2] : 0;
   ac->s2_lo = shadow ? pl.seg_start[3] : 0;
   ac->s2_hi = shadow ? pl.deep_fail_start : 0;
+  build_pp(ac->aut, ac->compact, 0, ac->pp);
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     int n = aha_device_count();
     if (n <= 0) {
@@ -625,6 +721,10 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->fail_s1_lo = ac->s1_lo;
   info->fail_s2_lo = ac->s2_lo;
   info->fail_hdr_lo = ac->s2_hi;
+  info->pp_enabled = ac->pp.ok ? 1u : 0u;
+  info->pp_bloom_words = (uint32_t)ac->pp.bloom.size();
+  info->pp_entries = ac->pp.n_entries;
+  info->pp_fill_permille = (uint32_t)(ac->pp.fill * 1000.0 + 0.5);
   return AHA_OK;
 }
 
@@ -687,6 +787,14 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
       src = ac->flt.xset.data();
       bytes = ac->flt.xset.size() * 8;
       break;
+    case AHA_IMG_PP_T2:
+      src = ac->pp.t2.data();
+      bytes = ac->pp.t2.size() * 4;
+      break;
+    case AHA_IMG_PP_BLOOM:
+      src = ac->pp.bloom.data();
+      bytes = ac->pp.bloom.size() * 4;
+      break;
     default:
       return AHA_E_INVALID;
   }
@@ -746,6 +854,18 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
   M.out = d_out;
   M.cap = cap;
   M.doc_hit_off = d_doc_hit_offsets;
+  if (ac->pp_ok && !M.chars && !M.sep) {
+    rc = match_pp(ac, M, s, n_hits);
+    if (rc < 0) return rc;
+    if (rc == AHA_OK) {
+      if (*n_hits > cap) {
+        ac->err = "output buffer too small";
+        return AHA_E_CAPACITY;
+      }
+      return AHA_OK;
+    }
+    *n_hits = 0;  // rc == 1: hit-dense or unaligned input -> single-traversal engine
+  }
   if (ac->v2_ok) {
     rc = match_v2(ac, M, s, n_hits, true);
     if (rc == 2) rc = match_v2(ac, M, s, n_hits, true);   // hit-dense input: regions of one event per byte

@@ -114,6 +114,24 @@ struct V2Args {
   uint64_t *doc_hit_off;
 };
 
+// ---- position-parallel engine (scan_pp.hip, pp.hpp) ---------------------------
+struct PpArgs {
+  const uint8_t *text;       // 16-byte aligned
+  uint64_t n_bytes;
+  uint64_t n_chunks;         // chunks of kPpChunk bytes
+  const uint32_t *t2;        // [kPpT2Words]
+  const uint32_t *bloom;     // [b_words]
+  uint32_t b_words;
+  uint16_t *items;           // [n_chunks * kPpItemCap] position in the chunk | probe flags
+  uint32_t *item_cnt;        // [n_chunks]
+  unsigned long long *flags; // = V2Args::cursor; [1] = 3: an item list or an event region overflowed
+};
+size_t pp_filter_lds(uint32_t b_words);
+int pp_prepare(uint32_t b_words);  // raises the dynamic-LDS limit of the filter kernel; hipError_t as int
+void pp_launch_filter(const PpArgs &P, uint32_t grid, void *stream);
+// events of every chunk in position order -> M.evd / M.ev_cnt / M.doc_ev_rank (then v2_launch_direct_post)
+void pp_launch_resolve(const DevAut &A, const V2Args &M, const PpArgs &P, void *stream);
+
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact, uint32_t bloom_words);
 int v2_prepare(bool compact, bool filter, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
 void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream);

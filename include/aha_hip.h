@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AHA_ABI_VERSION 2
+#define AHA_ABI_VERSION 3
 
 /* Aha::Hit -- src/aha/matcher.cr:2-11.  Half-open [start,end) offsets
  * relative to the start of the sequence (document); value = key index in
@@ -95,6 +95,14 @@ typedef struct {
   uint32_t fail_s2_lo;
   uint32_t fail_hdr_lo;
   uint32_t reserved2;
+  /* Position-parallel engine (engine 3; aha_amd/csrc/pp.hpp): 1 when the automaton meets its preconditions (no
+   * 1-byte key, longest key <= 240 bytes, compact slots, Bloom filter at most half full).  Plain byte-offset
+   * matches then run: filter pass (every start position classified independently in LDS) -> exact resolve pass. */
+  uint32_t pp_enabled;
+  uint32_t pp_bloom_words;   /* 32-bit words of the LDS Bloom filter */
+  uint64_t pp_entries;       /* 3- and 4-byte keys + trie paths of depth 5 behind it */
+  uint32_t pp_fill_permille; /* bits set per 1000 */
+  uint32_t reserved3;
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded
@@ -103,13 +111,13 @@ typedef struct {
   uint32_t struct_size;
   uint32_t n_kernels;
   float ms_total;           /* first launch -> hits and offsets final in HBM */
-  float ms_count;           /* engine 2: the traversal kernel; engine 1: traversal pass 1 (count) */
-  float ms_scan;            /* scans of per-chunk counts */
-  float ms_write;           /* engine 2: chain expansion + doc offsets; engine 1: traversal pass 2 */
-  float ms_aux;             /* engine 2: event sort; engine 1: char-offset prefix pass */
+  float ms_count;           /* engine 3: the filter pass; engine 2: the traversal kernel; engine 1: traversal pass 1 */
+  float ms_scan;            /* engine 3: the resolve pass; engines 1, 2: scans of per-chunk counts */
+  float ms_write;           /* engines 2, 3: chain expansion + doc offsets; engine 1: traversal pass 2 */
+  float ms_aux;             /* engine 3: hits per chunk + scan; engine 2: event sort; engine 1: char-offset prefix pass */
   uint64_t n_chunks;
   uint64_t n_hits;
-  uint32_t engine;          /* 2 = single-traversal engine, 1 = two-pass engine */
+  uint32_t engine;          /* 3 = position-parallel engine, 2 = single-traversal engine, 1 = two-pass engine */
   uint32_t chunk_bytes;     /* bytes per lane chunk */
 } aha_timing;
 
@@ -181,7 +189,9 @@ enum {
   AHA_IMG_KEY_CNT = 3, /* uint32[K] */
   AHA_IMG_KEY_KC = 4,  /* uint32[K] */
   AHA_IMG_BLOOM = 5,   /* uint32[filter_words] (filter mode) */
-  AHA_IMG_XSET = 6     /* uint64[pow2] exact set behind the filter */
+  AHA_IMG_XSET = 6,    /* uint64[pow2] exact set behind the filter */
+  AHA_IMG_PP_T2 = 7,   /* uint32[4096]: 2-bit entries of the position-parallel engine's pair table */
+  AHA_IMG_PP_BLOOM = 8 /* uint32[pp_bloom_words] */
 };
 int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_bytes);
 

@@ -17,22 +17,25 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1", "v2f", "v2p"], autouse=True)
+@pytest.fixture(params=["pp", "v2", "v1", "v2p"], autouse=True)
 def engine(request, monkeypatch):
-    """Every parity test runs on the single-traversal engine (scan_v2.hip,
-    default), on the two-pass engine it falls back to (kernels.hip), on the
-    single-traversal engine with the opt-in boundary filter (k3_traverse; only
-    engages for automata larger than the LDS budget) and on the single-traversal
-    engine with its LDS prefix capped at 1024 slots ("v2p": small automata then
-    also take the partial-prefix kernel with the shadow fail links and the HBM
-    probe path).  The variables are read when a handle is compiled."""
-    monkeypatch.setenv("AHA_ENGINE", "v1" if request.param == "v1" else "v2")
-    monkeypatch.setenv("AHA_FILTER", "1" if request.param == "v2f" else "0")
+    """Every parity test runs on the default engine selection ("pp": the position-parallel engine scan_pp.hip
+    wherever the automaton meets its preconditions, else the single-traversal engine), on the single-traversal
+    engine (scan_v2.hip), on the two-pass engine it falls back to (kernels.hip) and on the single-traversal
+    engine with its LDS prefix capped at 1024 slots ("v2p": small automata then also take the partial-prefix
+    kernel with the shadow fail links and the HBM probe path).  The variables are read when a handle is
+    compiled."""
+    if request.param == "pp":
+        monkeypatch.delenv("AHA_ENGINE", raising=False)
+    else:
+        monkeypatch.setenv("AHA_ENGINE", "v1" if request.param == "v1" else "v2")
     if request.param == "v2p":
         monkeypatch.setenv("AHA_LDS_SLOTS", "1024")
     else:
         monkeypatch.delenv("AHA_LDS_SLOTS", raising=False)
     return request.param
+
+
 G = os.path.join(os.path.dirname(__file__), "golden")
 KATS = json.load(open(os.path.join(G, "reference_kats.json"), encoding="utf-8"))
 
@@ -248,10 +251,75 @@ def test_config_parity(cfg, K, nbytes, docb):
 
 
 def test_engine_selected(engine):
-    ac = AC.compile(["ab", "b"])
+    ac = AC.compile(["ab", "b"])  # a 1-byte key: outside the position-parallel engine's preconditions
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
     assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
+    ac = AC.compile(["ab", "ba"])
+    ac.set_profiling(True)
+    assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
+    assert ac.last_timing()["engine"] == {"pp": 3, "v1": 1}.get(engine, 2)
+    # char offsets and the separator filter stay on the single-traversal engine
+    assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
+    assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
+
+
+# ---- the position-parallel engine: keys of two bytes and more ---------------------
+
+def _keys_ge2(rng, n, alphabet, maxlen):
+    ks = set()
+    n = min(n, sum(len(alphabet) ** k for k in range(2, maxlen + 1)) // 2)
+    while len(ks) < n:
+        ks.add(bytes(rng.choice(alphabet) for _ in range(rng.randint(2, maxlen))))
+    return sorted(ks)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_pp_random_batches(seed):
+    """Random automata inside the position-parallel engine's preconditions, ragged batches: empty and one-byte
+    documents, documents that end inside a key, NUL bytes, matches across the 4 KiB chunk and 1 KiB tile
+    boundaries, runs of tiny documents (more boundaries per window than the resolve pass caches)."""
+    rng = random.Random(4000 + seed)
+    alphabet = [b"ab", b"abc", b"abcd\xe4\xb8\xad", bytes(range(0x61, 0x7B)), b"ab\xd0\xb0\xb1"][seed % 5]
+    keys = _keys_ge2(rng, rng.randint(1, 300), alphabet, [6, 12, 40][seed % 3])
+    g = AC.compile(keys)
+    assert g.info["pp_enabled"]
+    g.set_profiling(True)
+    o = orc.AC.compile(keys)
+    fill = alphabet + (b"\x00 " if seed % 2 else b" ")
+    lens = [0, 0, 1, 2, 3, 50, 255, 256, 257, 1000, 4095, 4096, 4097, 9000]
+    docs = [bytes(rng.choice(fill) for _ in range(rng.choice(lens))) for _ in range(40)]
+    docs += [bytes(rng.choice(alphabet) for _ in range(rng.randint(0, 5))) for _ in range(1500)]  # tiny documents
+    docs += [bytes(rng.choice(alphabet) for _ in range(20000))]
+    rng.shuffle(docs)
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+    corpus = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    gh, gd = g.match_batch(corpus, offs)
+    oh, od = o.match_batch(corpus, offs, cap=len(gh) + 16)
+    assert np.array_equal(gd, od)
+    assert gh.tobytes() == oh.tobytes()
+    if engine_is_default():  # hit-dense batches overflow the item lists and take the single-traversal engine
+        assert g.last_timing()["engine"] == (3 if len(gh) * 16 < corpus.size else g.last_timing()["engine"])
+
+
+def engine_is_default():
+    return "AHA_ENGINE" not in os.environ
+
+
+def test_pp_long_and_nested_keys():
+    """Keys up to the engine's 240-byte limit, a suffix-closed family (every suffix a key: output chains) and a
+    broken chain, in one document that is several chunks long."""
+    rng = random.Random(77)
+    w = bytes(rng.choice(b"abcdefgh") for _ in range(16))
+    keys = [w[j:] for j in range(15)] + [b"x" + w, bytes(rng.choice(b"ab") for _ in range(240)), b"ab" * 100]
+    v = bytes(rng.choice(b"ijklmnop") for _ in range(16))
+    keys += [v, v[1:], v[2:] + b"#"] + [v[j:] for j in range(3, 15)]
+    keys = list(dict.fromkeys(keys))
+    g = AC.compile(keys)
+    assert g.info["pp_enabled"]
+    o = orc.AC.compile(keys)
+    text = b"".join(rng.choice([w, v, b"x" + w, keys[16], keys[17], b"ab", b" ", v[2:] + b"#"]) for _ in range(600))
+    assert gpu_list(g.match_array(text)) == as_list(o.match(text))
 
 
 def test_device_resident_entry_point():
@@ -283,8 +351,8 @@ def test_full_size_properties(cfg, engine):
     properties instead of a full oracle run -- ordering, every hit spells its
     key, document independence (any split of the batch gives the same hits),
     engine agreement by checksum -- plus the oracle on a sample of documents."""
-    if engine == "v1":
-        pytest.skip("full-size run is done once on the default engine (v1 is compared by checksum inside)")
+    if engine not in ("pp", "v2"):
+        pytest.skip("full-size run: the default engine selection and the single-traversal engine")
     import hashlib
 
     import torch
@@ -342,7 +410,7 @@ def test_corpus_beyond_4_gib(engine):
     """Corpus-level offsets are 64-bit (SURVEY 8 b: per-document Int32, corpus uint64): a batch of 4 GiB + 1 MiB.
     The documents on both sides of the 2^32 boundary and a sample of the others against the oracle; global
     invariants over all hits."""
-    if engine != "v2":
+    if engine != "pp":
         pytest.skip("done once, on the default engine")
     import torch
 
@@ -383,8 +451,8 @@ def test_single_large_document_vs_oracle(engine):
     """SURVEY 8d single-document variant: one 256 MiB document, so every chunk
     but the first starts in the middle of a sequence (warm-up overlap at scale).
     Full comparison with the oracle."""
-    if engine == "v1":
-        pytest.skip("run on the single-traversal engines")
+    if engine not in ("pp", "v2"):
+        pytest.skip("run on the default engine selection and on the single-traversal engine")
     import torch
 
     blob, offs, nf = synth.keys(3)

@@ -64,6 +64,7 @@ struct aha_ac {
   bool pp_ok = false;
   const uint32_t *d_pp_t2 = nullptr, *d_pp_bloom = nullptr;
   uint32_t pp_grid = 0;
+  uint32_t pp_lds_slots = 0;
   Buf hostbuf[4];  // device staging of the host-buffer entry points (corpus, doc offsets, doc hit offsets, hits)
   unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
   std::string err;
@@ -253,7 +254,8 @@ void v2_setup(aha_ac *ac) {
   // position-parallel engine: default whenever the automaton meets its preconditions (pp.hpp);
   // AHA_ENGINE=v2 keeps the single-traversal engine
   if (ac->pp.ok && !(eng && strcmp(eng, "v2") == 0) && !filter) {
-    if (pp_prepare((uint32_t)ac->pp.bloom.size()) != 0) return;
+    ac->pp_lds_slots = std::min<uint32_t>(pp_resolve_max_slots(), ac->n_slots & ~3u);
+    if (pp_prepare((uint32_t)ac->pp.bloom.size(), ac->pp_lds_slots) != 0) return;
     if (upload(ac, ac->pp.t2, &ac->d_pp_t2) != AHA_OK) return;
     if (upload(ac, ac->pp.bloom, &ac->d_pp_bloom) != AHA_OK) return;
     ac->pp_grid = (uint32_t)(cus - reserve);
@@ -425,12 +427,13 @@ int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   M.ev_stride = kPpEvStride;
   const uint64_t n_blk = (M.n_chunks + 255) / 256 + 2;
   int32_t rc;
-  const int idx[9] = {4, 5, 7, 9, 16, 18, 19, 20, 21};
-  const size_t sizes[9] = {M.n_chunks * 4,      (M.n_docs + 1) * 4, n_blk * 8,
-                           16 * 8,              M.n_chunks * (size_t)kPpEvStride * 8,
-                           M.n_chunks * 4,      M.n_chunks * 8,     M.n_chunks * (size_t)kPpItemCap * 2,
-                           M.n_chunks * 4};
-  for (int i = 0; i < 9; i++)
+  if (M.n_docs >= 0xFFFFFFFFull) return 1;
+  const int idx[10] = {4, 5, 7, 9, 16, 18, 19, 20, 21, 22};
+  const size_t sizes[10] = {M.n_chunks * 4,      (M.n_docs + 1) * 4, n_blk * 8,
+                            16 * 8,              M.n_chunks * (size_t)kPpEvStride * 8,
+                            M.n_chunks * 4,      M.n_chunks * 8,     M.n_chunks * (size_t)kPpItemCap * 2,
+                            M.n_chunks * 8,      M.n_chunks * 8};
+  for (int i = 0; i < 10; i++)
     if ((rc = v2_reserve(ac, idx[i], sizes[i]))) return rc;
   M.ev_cnt = (uint32_t *)ac->v2buf[4].p;
   M.doc_ev_rank = (uint32_t *)ac->v2buf[5].p;
@@ -448,7 +451,9 @@ int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   P.bloom = ac->d_pp_bloom;
   P.b_words = (uint32_t)ac->pp.bloom.size();
   P.items = (uint16_t *)ac->v2buf[20].p;
-  P.item_cnt = (uint32_t *)ac->v2buf[21].p;
+  P.tile_end = (unsigned long long *)ac->v2buf[21].p;
+  P.chunk_doc = (uint32_t *)ac->v2buf[22].p;
+  P.lds_slots = ac->pp_lds_slots;
   P.flags = M.cursor;
   if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
   const bool prof = ac->profiling && ac->ev_ready;
@@ -457,7 +462,7 @@ int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   const uint64_t waves = (M.n_chunks + 15) / 16;  // 16 waves (chunks) per filter workgroup
   pp_launch_filter(P, (uint32_t)std::min<uint64_t>(ac->pp_grid, std::max<uint64_t>(waves, 1)), s);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
-  pp_launch_resolve(ac->dev, M, P, s);
+  pp_launch_resolve(ac->dev, M, P, ac->pp_grid, s);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
   v2_launch_direct_post(ac->dev, M, s, prof ? (void *)ac->ev[3] : nullptr);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[4], s));

@@ -123,14 +123,18 @@ struct PpArgs {
   const uint32_t *bloom;     // [b_words]
   uint32_t b_words;
   uint16_t *items;           // [n_chunks * kPpItemCap] position in the chunk | probe flags
-  uint32_t *item_cnt;        // [n_chunks]
+  unsigned long long *tile_end;  // [n_chunks] 4 x 16 bit: items of the chunk up to the end of each 1 KiB tile
+  uint32_t *chunk_doc;       // [2 * n_chunks] first document that starts at or after the chunk / after its halo
+  uint32_t lds_slots;        // slots of the image the resolve pass keeps in LDS
   unsigned long long *flags; // = V2Args::cursor; [1] = 3: an item list or an event region overflowed
 };
 size_t pp_filter_lds(uint32_t b_words);
-int pp_prepare(uint32_t b_words);  // raises the dynamic-LDS limit of the filter kernel; hipError_t as int
+uint32_t pp_resolve_max_slots();
+// raises the dynamic-LDS limits of the two kernels; hipError_t as int
+int pp_prepare(uint32_t b_words, uint32_t lds_slots);
 void pp_launch_filter(const PpArgs &P, uint32_t grid, void *stream);
 // events of every chunk in position order -> M.evd / M.ev_cnt / M.doc_ev_rank (then v2_launch_direct_post)
-void pp_launch_resolve(const DevAut &A, const V2Args &M, const PpArgs &P, void *stream);
+void pp_launch_resolve(const DevAut &A, const V2Args &M, const PpArgs &P, uint32_t grid, void *stream);
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact, uint32_t bloom_words);
 int v2_prepare(bool compact, bool filter, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int

@@ -257,8 +257,11 @@ def test_engine_selected(engine):
     assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
     ac = AC.compile(["ab", "ba"])
     ac.set_profiling(True)
-    assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
+    assert gpu_list(ac.match_array(b"ab ba " * 60))[:3] == [(0, 2, 0), (3, 5, 1), (6, 8, 0)]
     assert ac.last_timing()["engine"] == {"pp": 3, "v1": 1}.get(engine, 2)
+    # an item at every position overflows the per-tile lists: the call is repeated on the single-traversal engine
+    assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
+    assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
     # char offsets and the separator filter stay on the single-traversal engine
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
     assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)

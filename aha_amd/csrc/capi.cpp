@@ -65,6 +65,7 @@ struct aha_ac {
   const uint32_t *d_pp_t2 = nullptr, *d_pp_bloom = nullptr;
   uint32_t pp_grid = 0;
   uint32_t pp_lds_slots = 0;
+  uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
   Buf hostbuf[4];  // device staging of the host-buffer entry points (corpus, doc offsets, doc hit offsets, hits)
   unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
   std::string err;
@@ -251,10 +252,11 @@ void v2_setup(aha_ac *ac) {
   if (reserve < 0 || reserve >= cus) reserve = 0;
   ac->v2_grid = (uint32_t)(cus - reserve) * ac->v2_bpc;
   ac->v2_ok = true;
-  // position-parallel engine: default whenever the automaton meets its preconditions (pp.hpp);
-  // AHA_ENGINE=v2 keeps the single-traversal engine
-  if (ac->pp.ok && !(eng && strcmp(eng, "v2") == 0) && !filter) {
-    ac->pp_lds_slots = std::min<uint32_t>(pp_resolve_max_slots(), ac->n_slots & ~3u);
+  // position-parallel engine (pp.hpp): bit-exact, but on the BASELINE shapes still slower than the single-traversal
+  // engine (DESIGN.md section 4.5 has the measured budget), so it is opt-in: AHA_ENGINE=pp
+  if (ac->pp.ok && eng && strcmp(eng, "pp") == 0 && !filter) {
+    ac->pp_lds_slots = std::min<uint32_t>(pp_walk_max_slots(), ac->n_slots & ~3u);
+    if (ac->seg2 > ac->pp_lds_slots) return;  // the walk kernel reads the first two levels from LDS unconditionally
     if (pp_prepare((uint32_t)ac->pp.bloom.size(), ac->pp_lds_slots) != 0) return;
     if (upload(ac, ac->pp.t2, &ac->d_pp_t2) != AHA_OK) return;
     if (upload(ac, ac->pp.bloom, &ac->d_pp_bloom) != AHA_OK) return;
@@ -428,12 +430,15 @@ int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   const uint64_t n_blk = (M.n_chunks + 255) / 256 + 2;
   int32_t rc;
   if (M.n_docs >= 0xFFFFFFFFull) return 1;
-  const int idx[10] = {4, 5, 7, 9, 16, 18, 19, 20, 21, 22};
-  const size_t sizes[10] = {M.n_chunks * 4,      (M.n_docs + 1) * 4, n_blk * 8,
+  const uint32_t walk_grid = (uint32_t)std::min<uint64_t>(ac->pp_grid, std::max<uint64_t>((M.n_chunks + 15) / 16, 1));
+  const int idx[14] = {4, 5, 7, 9, 16, 18, 19, 20, 21, 22, 23, 0, 1, 2};
+  const size_t sizes[14] = {M.n_chunks * 4,      (M.n_docs + 1) * 4, n_blk * 8,
                             16 * 8,              M.n_chunks * (size_t)kPpEvStride * 8,
                             M.n_chunks * 4,      M.n_chunks * 8,     M.n_chunks * (size_t)kPpItemCap * 2,
-                            M.n_chunks * 8,      M.n_chunks * 8};
-  for (int i = 0; i < 10; i++)
+                            M.n_chunks * 8,      M.n_chunks * 8,     M.n_chunks * 4,
+                            M.n_chunks * (size_t)kPpDeepCap * 8, M.n_chunks * (size_t)kPpLongCap * 4,
+                            M.n_chunks * 4};
+  for (int i = 0; i < 14; i++)
     if ((rc = v2_reserve(ac, idx[i], sizes[i]))) return rc;
   M.ev_cnt = (uint32_t *)ac->v2buf[4].p;
   M.doc_ev_rank = (uint32_t *)ac->v2buf[5].p;
@@ -454,15 +459,22 @@ int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   P.tile_end = (unsigned long long *)ac->v2buf[21].p;
   P.chunk_doc = (uint32_t *)ac->v2buf[22].p;
   P.lds_slots = ac->pp_lds_slots;
+  P.long_cnt = (uint32_t *)ac->v2buf[23].p;
+  P.deep = (uint2 *)ac->v2buf[0].p;
+  P.longs = (uint32_t *)ac->v2buf[1].p;
+  P.deep_cnt = (uint32_t *)ac->v2buf[2].p;
   P.flags = M.cursor;
   if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
   const bool prof = ac->profiling && ac->ev_ready;
-  HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 16 * 8, s));
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
+  HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 16 * 8, s));
+  HIPCHK(ac, hipMemsetAsync(M.ev_cnt, 0, M.n_chunks * 4, s));       // raw candidate counts, then event counts
+  HIPCHK(ac, hipMemsetAsync(P.long_cnt, 0, M.n_chunks * 4, s));
+  HIPCHK(ac, hipMemsetAsync(P.deep_cnt, 0, M.n_chunks * 4, s));
   const uint64_t waves = (M.n_chunks + 15) / 16;  // 16 waves (chunks) per filter workgroup
   pp_launch_filter(P, (uint32_t)std::min<uint64_t>(ac->pp_grid, std::max<uint64_t>(waves, 1)), s);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
-  pp_launch_resolve(ac->dev, M, P, ac->pp_grid, s);
+  pp_launch_resolve(ac->dev, M, P, walk_grid, s);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
   v2_launch_direct_post(ac->dev, M, s, prof ? (void *)ac->ev[3] : nullptr);
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[4], s));
@@ -580,6 +592,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     if (!shadow || pl.seg_start[2] <= ac->v2_lds_slots) break;
     shadow = false;
   }
+  ac->seg2 = pl.seg_start[2];
   ac->s1_lo = shadow ? pl.seg_start[2] : 0;
   ac->s2_lo = shadow ? pl.seg_start[3] : 0;
   ac->s2_hi = shadow ? pl.deep_fail_start : 0;

@@ -125,11 +125,15 @@ struct PpArgs {
   uint16_t *items;           // [n_chunks * kPpItemCap] position in the chunk | probe flags
   unsigned long long *tile_end;  // [n_chunks] 4 x 16 bit: items of the chunk up to the end of each 1 KiB tile
   uint32_t *chunk_doc;       // [2 * n_chunks] first document that starts at or after the chunk / after its halo
-  uint32_t lds_slots;        // slots of the image the resolve pass keeps in LDS
+  uint32_t lds_slots;        // slots of the image the walk kernel keeps in LDS
+  uint2 *deep;               // [n_chunks * kPpDeepCap] walks alive at depth kPpGuard: {pos | limit << 16, state}
+  uint32_t *deep_cnt;        // [n_chunks]
+  uint32_t *longs;           // [n_chunks * kPpLongCap] start (+ kPpHalo, chunk relative) | reach << 16
+  uint32_t *long_cnt;        // [n_chunks]
   unsigned long long *flags; // = V2Args::cursor; [1] = 3: an item list or an event region overflowed
 };
 size_t pp_filter_lds(uint32_t b_words);
-uint32_t pp_resolve_max_slots();
+uint32_t pp_walk_max_slots();
 // raises the dynamic-LDS limits of the two kernels; hipError_t as int
 int pp_prepare(uint32_t b_words, uint32_t lds_slots);
 void pp_launch_filter(const PpArgs &P, uint32_t grid, void *stream);

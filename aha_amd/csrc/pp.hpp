@@ -38,6 +38,9 @@ namespace aha {
 constexpr uint32_t kPpChunk = 4096;          // bytes per chunk (item list / event region)
 constexpr uint32_t kPpItemCap = kPpChunk / 8;  // items per chunk
 constexpr uint32_t kPpEvStride = kPpChunk / 8; // events per chunk region
+constexpr uint32_t kPpHalo = 256;             // a start reaches at most this far: kPpMaxKeyLen < kPpHalo
+constexpr uint32_t kPpDeepCap = 64;           // starts whose walk is alive at depth kPpGuard, per chunk
+constexpr uint32_t kPpLongCap = 64;           // starts with walks of kPpGuard bytes and more, per chunk
 constexpr uint32_t kPpMaxKeyLen = 240;       // reaches are bytes; the halo in front of a chunk is 256 bytes
 constexpr uint32_t kPpGuard = 5;             // P-probe depth; boring starts have L < kPpGuard
 constexpr uint32_t kPpT2Words = 4096;        // 64 Ki entries x 2 bit

@@ -44,8 +44,7 @@ class aha_ac_info_t(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_keys", C.c_uint32), ("n_states", C.c_uint64),
                 ("n_slots", C.c_uint64), ("image_bytes", C.c_uint64), ("max_key_len", C.c_uint32),
                 ("slot_bytes", C.c_uint32), ("lds_slots", C.c_uint32), ("device", C.c_int32),
-                ("filter_d0", C.c_uint32), ("filter_words", C.c_uint32), ("filter_entries", C.c_uint64),
-                ("boundary_end", C.c_uint32), ("reserved", C.c_uint32), ("fail_s1_lo", C.c_uint32),
+                ("reserved0", C.c_uint32 * 5), ("reserved", C.c_uint32), ("fail_s1_lo", C.c_uint32),
                 ("fail_s2_lo", C.c_uint32), ("fail_hdr_lo", C.c_uint32), ("reserved2", C.c_uint32),
                 ("pp_enabled", C.c_uint32), ("pp_bloom_words", C.c_uint32), ("pp_entries", C.c_uint64),
                 ("pp_fill_permille", C.c_uint32), ("reserved3", C.c_uint32)]

@@ -427,52 +427,6 @@ void place_states(const Automaton &a, Placement &p, bool defer_deep_fail, bool h
   for (uint32_t d = cur_depth + 1; d < kSegDepth + 2; d++) p.seg_start[d] = p.n_slots;
 }
 
-void build_filter(const Automaton &a, const Placement &p, uint32_t d0, uint32_t words, Filter &f) {
-  f = Filter();
-  f.d0 = d0;
-  f.t_rows = p.seg_start[d0];
-  f.t_bend = p.seg_start[d0 + 1];
-  f.bloom.assign(words, 0u);
-  std::vector<uint64_t> keys;
-  auto sprime_ends = [&](uint32_t t) {  // does the depth<=d0 fail ancestor of t end a key?
-    while (a.depth[t] > d0) t = a.fail[t];
-    return a.key_of[t] >= 0;
-  };
-  auto add = [&](uint32_t B, uint32_t w) {
-    uint32_t h = filter_hash(B, w);
-    f.bloom[filter_word(h, words)] |= filter_mask(h);
-    keys.push_back(((uint64_t)B << 32) | w);
-  };
-  for (uint32_t u = 0; u < a.n_states; u++) {
-    if (a.depth[u] < d0) continue;
-    if (a.depth[u] > d0) break;  // BFS order
-    const uint32_t B = p.base[u];
-    for (uint32_t i = 0; i < a.n_child[u]; i++) {
-      const uint32_t t1 = a.first_child[u] + i;
-      const uint32_t x1 = a.in_label[t1];
-      if (a.key_of[t1] >= 0 || sprime_ends(t1)) add(B, filter_key(1, x1, 0, 0));
-      for (uint32_t j = 0; j < a.n_child[t1]; j++) {
-        const uint32_t t2 = a.first_child[t1] + j;
-        const uint32_t x2 = a.in_label[t2];
-        if (a.key_of[t2] >= 0 || sprime_ends(t2)) add(B, filter_key(2, x1, x2, 0));
-        for (uint32_t k = 0; k < a.n_child[t2]; k++) {
-          const uint32_t t3 = a.first_child[t2] + k;
-          add(B, filter_key(3, x1, x2, a.in_label[t3]));
-        }
-      }
-    }
-  }
-  f.n_entries = keys.size();
-  uint64_t cap = 64;
-  while (cap < 2 * keys.size() + 2) cap <<= 1;
-  f.xset.assign(cap, 0ull);
-  for (uint64_t k : keys) {
-    uint64_t i = filter_hash((uint32_t)(k >> 32), (uint32_t)k) & (cap - 1);
-    while (f.xset[i] != 0 && f.xset[i] != k) i = (i + 1) & (cap - 1);
-    f.xset[i] = k;
-  }
-}
-
 bool encode_image(const Automaton &a, const Placement &p, bool force_wide, Image &img) {
   img = Image();
   img.n_slots = p.n_slots;

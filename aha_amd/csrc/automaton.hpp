@@ -120,40 +120,4 @@ struct Image {
 // Returns false if the automaton does not fit the format limits.
 bool encode_image(const Automaton &a, const Placement &p, bool force_wide, Image &img);
 
-// ---- boundary filter (scan_v2.hip, filter mode) ------------------------------
-// States of depth < d0 have their rows in LDS; states of depth d0 are
-// "boundary" states.  For a boundary state u and the next bytes x1 x2 x3 the
-// filter answers "may an excursion below u be observable or long?":
-//   n=1: u.x1 is a path and (it ends a key, or the depth<=d0 state the shallow
-//        automaton would be in at that position ends a key)
-//   n=2: the same for u.x1x2
-//   n=3: u.x1x2x3 is a path
-// `bloom` is a blocked Bloom filter (3 bits in one 32-bit word, no false
-// negatives); `xset` the exact set (open addressing, 0 = empty) used to
-// discard false positives before the exact re-walk.
-AHA_HD inline uint32_t filter_hash(uint32_t B, uint32_t w) {
-  uint32_t h = (B * 0x9E3779B1u) ^ (w * 0x85EBCA6Bu);
-  h ^= h >> 15;
-  h *= 0x2C1B3C6Du;
-  h ^= h >> 13;
-  return h;
-}
-AHA_HD inline uint32_t filter_mask(uint32_t h) {
-  uint32_t g = h * 0x297A2D39u;
-  return (1u << (g >> 27)) | (1u << ((g >> 22) & 31u)) | (1u << ((g >> 17) & 31u));
-}
-AHA_HD inline uint32_t filter_word(uint32_t h, uint32_t words) { return (uint32_t)(((uint64_t)h * words) >> 32); }
-AHA_HD inline uint32_t filter_key(uint32_t n, uint32_t x1, uint32_t x2, uint32_t x3) {
-  return (n << 24) | x1 | (x2 << 8) | (x3 << 16);
-}
-struct Filter {
-  uint32_t d0 = 0;
-  uint32_t t_rows = 0;   // slots [0, t_rows): rows + headers of states with depth < d0
-  uint32_t t_bend = 0;   // slots [t_rows, t_bend): boundary (depth d0) states
-  std::vector<uint32_t> bloom;  // [words]
-  std::vector<uint64_t> xset;   // [pow2] key = base << 32 | filter_key
-  uint64_t n_entries = 0;
-};
-void build_filter(const Automaton &a, const Placement &p, uint32_t d0, uint32_t words, Filter &f);
-
 }  // namespace aha

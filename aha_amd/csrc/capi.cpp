@@ -21,7 +21,6 @@ using namespace aha;
 struct aha_ac {
   Automaton aut;
   Image img;  // host copy of the device image (export / debugging)
-  Filter flt; // filter mode tables (d0 == 0: off)
   uint32_t n_slots = 0;
   uint32_t slot_bytes = 0;
   bool compact = false;
@@ -189,38 +188,20 @@ int32_t fill_params(aha_ac *ac, const aha_match_params *p, MatchArgs &M) {
 // ---- single-traversal engine: sizing, scratch, orchestration ----------------
 constexpr size_t kLdsPerCU = 160 * 1024;
 
-// Host-only plan: how much of the image the traversal kernel keeps in LDS and
-// whether the boundary filter is used (automaton.hpp, Filter).
+// Host-only plan: how much of the image the traversal kernel keeps in LDS.
 void plan_engine(aha_ac *ac, const Placement &pl) {
-  // LDS input window: 64 B rows of 16-byte columns in filter mode, padded rows otherwise
-  const size_t in_bytes = (size_t)(kV2Threads / 64) * 64 * (kV2Piece + 4);
+  (void)pl;
+  const size_t in_bytes = (size_t)(kV2Threads / 64) * 64 * (kV2Piece + 4);  // padded LDS input rows
   const size_t slot = ac->compact ? 4 : 8;
   // AHA_V2_BPC=2: two workgroups per CU (half the LDS each, twice the waves)
   const char *bpc = getenv("AHA_V2_BPC");
   ac->v2_bpc = (bpc && strcmp(bpc, "2") == 0) ? 2 : 1;
   const size_t budget = kLdsPerCU / ac->v2_bpc - in_bytes;
-  ac->flt = Filter();
   // AHA_LDS_SLOTS=n caps the prefix (tests: forces the partial-prefix kernel on small automata)
   const char *cap_s = getenv("AHA_LDS_SLOTS");
   const size_t cap_slots = cap_s ? (size_t)std::max(256, atoi(cap_s)) & ~(size_t)255 : SIZE_MAX;
   if ((size_t)ac->n_slots * slot <= budget && ac->n_slots <= cap_slots) {  // the whole automaton lives in LDS
     ac->v2_lds_slots = ac->n_slots;
-    return;
-  }
-  // Filter mode is bit-exact but not yet faster than the plain LDS-prefix walk
-  // (DESIGN.md 4.4), so it is opt-in: AHA_FILTER=1.
-  const char *fe = getenv("AHA_FILTER");
-  const bool want_filter = fe && strcmp(fe, "1") == 0;
-  uint32_t d0 = 0;
-  if (want_filter) {
-    for (uint32_t d = 2; d <= 4 && d + 1 <= kSegDepth + 1; d++) {
-      if ((size_t)pl.seg_start[d] * slot <= 32 * 1024 && pl.seg_start[d + 1] > pl.seg_start[d]) d0 = d;
-    }
-  }
-  if (d0) {
-    uint32_t words = (uint32_t)((budget - (size_t)pl.seg_start[d0] * slot) / 4) & ~3u;
-    build_filter(ac->aut, pl, d0, words, ac->flt);
-    ac->v2_lds_slots = pl.seg_start[d0];
     return;
   }
   ac->v2_lds_slots = (uint32_t)std::min<size_t>(std::min<size_t>(budget / slot, cap_slots), ac->n_slots) & ~3u;
@@ -232,19 +213,7 @@ void v2_setup(aha_ac *ac) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ac->device) != hipSuccess || cus <= 0)
     return;
-  const bool filter = ac->flt.d0 != 0;
-  const uint32_t words = filter ? (uint32_t)ac->flt.bloom.size() : 0;
-  if (v2_prepare(ac->compact, filter, v2_lds_bytes(ac->v2_lds_slots, ac->compact, words)) != 0) return;
-  if (filter) {
-    DevAut &d = ac->dev;
-    if (upload(ac, ac->flt.bloom, &d.bloom) != AHA_OK) return;
-    if (upload(ac, ac->flt.xset, &d.xset) != AHA_OK) return;
-    d.d0 = ac->flt.d0;
-    d.t_rows = ac->flt.t_rows;
-    d.t_bend = ac->flt.t_bend;
-    d.bloom_words = words;
-    d.xmask = (uint32_t)(ac->flt.xset.size() - 1);
-  }
+  if (v2_prepare(ac->compact, v2_lds_bytes(ac->v2_lds_slots, ac->compact)) != 0) return;
   // AHA_RESERVE_CUS=n: leave n CUs without a persistent traversal workgroup so that
   // collective (RCCL) kernels of an overlapped exchange can run beside it
   const char *rs = getenv("AHA_RESERVE_CUS");
@@ -254,7 +223,7 @@ void v2_setup(aha_ac *ac) {
   ac->v2_ok = true;
   // position-parallel engine (pp.hpp): bit-exact, but on the BASELINE shapes still slower than the single-traversal
   // engine (DESIGN.md section 4.5 has the measured budget), so it is opt-in: AHA_ENGINE=pp
-  if (ac->pp.ok && eng && strcmp(eng, "pp") == 0 && !filter) {
+  if (ac->pp.ok && eng && strcmp(eng, "pp") == 0) {
     ac->pp_lds_slots = std::min<uint32_t>(pp_walk_max_slots(), ac->n_slots & ~3u);
     if (ac->seg2 > ac->pp_lds_slots) return;  // the walk kernel reads the first two levels from LDS unconditionally
     if (pp_prepare((uint32_t)ac->pp.bloom.size(), ac->pp_lds_slots) != 0) return;
@@ -304,7 +273,7 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   M.doc_hit_off = M1.doc_hit_off;
   // plain mode (byte offsets, no separator filter, no boundary filter): per-chunk event regions, no sort
   const char *de = getenv("AHA_DIRECT");
-  bool direct = !(de && strcmp(de, "0") == 0) && !M.sep && ac->flt.d0 == 0 && allow_direct &&
+  bool direct = !(de && strcmp(de, "0") == 0) && !M.sep && allow_direct &&
                 !ac->direct_overflowed && !ac->sparse_hits;
   const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
   M.direct = direct ? 1 : 0;
@@ -352,8 +321,6 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
 
   const bool prof = ac->profiling && ac->ev_ready;
   HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 16 * 8, s));
-  const bool dbg = getenv("AHA_DEBUG_STATS") != nullptr;
-  M.dbg = dbg ? (unsigned long long *)ac->v2buf[9].p + 8 : nullptr;
   if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
   v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
@@ -372,13 +339,6 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   HIPCHK(ac, hipGetLastError());
   HIPCHK(ac, hipMemcpyAsync(ac->h_v2, ac->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(ac, hipStreamSynchronize(s));
-  if (dbg) {
-    unsigned long long d[8];
-    if (hipMemcpy(d, (unsigned long long *)ac->v2buf[9].p + 8, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess)
-      fprintf(stderr, "[aha stats] fast iters %llu (lanes/iter %.1f, cyc/iter %.0f) burst iters %llu (lanes/iter %.1f, cyc/iter %.0f)\n",
-              d[0], d[0] ? (double)d[1] / d[0] : 0.0, d[0] ? (double)d[4] / d[0] : 0.0, d[2],
-              d[2] ? (double)d[3] / d[2] : 0.0, d[2] ? (double)d[5] / d[2] : 0.0);
-  }
   if (ac->h_v2[1] == 2) {  // a chunk's event region overflowed (hit-dense input): full-size regions from now on
     if (ac->direct_div > 1)
       ac->direct_div = 1;
@@ -563,11 +523,10 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   Placement pl;
   Image &img = ac->img;
   // Shadow fail links (default): fail links of depth <= 2 targets are recomputed from the last two input bytes, so
-  // only the root and the deep-fail states keep a header slot (automaton.hpp, Placement::headerless).  The
-  // boundary-filter engine (AHA_FILTER=1) and AHA_SHADOW_FAIL=0 keep a header for every state.
-  const char *fe = getenv("AHA_FILTER");
+  // only the root and the deep-fail states keep a header slot (automaton.hpp, Placement::headerless).
+  // AHA_SHADOW_FAIL=0 keeps a header for every state.
   const char *sf = getenv("AHA_SHADOW_FAIL");
-  bool shadow = !(fe && strcmp(fe, "1") == 0) && !(sf && strcmp(sf, "0") == 0);
+  bool shadow = !(sf && strcmp(sf, "0") == 0);
   // A small automaton that fits LDS with a header for every state keeps them: its kernel (ALL_LDS) reads the
   // header beside the probe, which is cheaper than keeping the shadow state.
   bool try_headers_first = shadow && (size_t)ac->aut.n_states * 2 * 8 <= kLdsPerCU;
@@ -732,10 +691,6 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->slot_bytes = ac->slot_bytes;
   info->lds_slots = ac->v2_lds_slots;
   info->device = ac->device;
-  info->filter_d0 = ac->flt.d0;
-  info->filter_words = (uint32_t)ac->flt.bloom.size();
-  info->filter_entries = ac->flt.n_entries;
-  info->boundary_end = ac->flt.t_bend;
   info->fail_s1_lo = ac->s1_lo;
   info->fail_s2_lo = ac->s2_lo;
   info->fail_hdr_lo = ac->s2_hi;
@@ -796,14 +751,6 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
     case AHA_IMG_KEY_KC:
       src = a.key_kc.data();
       bytes = a.key_kc.size() * 4;
-      break;
-    case AHA_IMG_BLOOM:
-      src = ac->flt.bloom.data();
-      bytes = ac->flt.bloom.size() * 4;
-      break;
-    case AHA_IMG_XSET:
-      src = ac->flt.xset.data();
-      bytes = ac->flt.xset.size() * 8;
       break;
     case AHA_IMG_PP_T2:
       src = ac->pp.t2.data();

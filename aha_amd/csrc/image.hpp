@@ -24,15 +24,6 @@ struct DevAut {
   uint32_t s1_lo;            // [s1_lo, s2_lo): depth-2 states; their fail target is the depth-1 state of the last byte
   uint32_t s2_lo;
   uint32_t s2_hi;
-  // filter mode (0 = off): rows of states with depth < d0 live in LDS, states of
-  // depth d0 are guarded by the lookahead Bloom filter (automaton.hpp, Filter)
-  uint32_t d0;
-  uint32_t t_rows;
-  uint32_t t_bend;
-  uint32_t bloom_words;
-  const uint32_t *bloom;     // [bloom_words] copied into LDS by every workgroup
-  const uint64_t *xset;      // exact set in HBM (open addressing, 0 = empty)
-  uint32_t xmask;
 };
 
 struct MatchArgs {
@@ -100,7 +91,6 @@ struct V2Args {
   uint32_t *sorted_aux;      // [ev_cap]
   uint32_t *sorted_cnt;      // [ev_cap] hits per event
   uint64_t *totals;          // [0] hits [1] leads [2] events
-  unsigned long long *dbg;   // optional [8] traversal statistics (AHA_DEBUG_STATS=1)
   // direct event regions (plain mode): chunk c stores its events in order at evd[c * ev_stride + seq], so the
   // post passes need no sort: count (wave per chunk) -> scan -> expand (wave per chunk)
   int32_t direct;
@@ -140,8 +130,8 @@ void pp_launch_filter(const PpArgs &P, uint32_t grid, void *stream);
 // events of every chunk in position order -> M.evd / M.ev_cnt / M.doc_ev_rank (then v2_launch_direct_post)
 void pp_launch_resolve(const DevAut &A, const V2Args &M, const PpArgs &P, uint32_t grid, void *stream);
 
-size_t v2_lds_bytes(uint32_t lds_slots, bool compact, uint32_t bloom_words);
-int v2_prepare(bool compact, bool filter, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
+size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
+int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
 void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream);
 // scans ev_cnt (and lead_cnt) into ev_base / lead_base; totals[2] = events, totals[1] = leads
 void v2_launch_chunk_scan(const V2Args &M, void *stream);

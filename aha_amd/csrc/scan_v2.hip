@@ -17,9 +17,6 @@
 //                 16-byte "event" in registers and the wave flushes pending
 //                 events with ballot + mbcnt into a slab it reserved with one
 //                 atomic -- no key-table loads, no ordering work in the loop.
-//   k3_traverse   opt-in filter mode (AHA_FILTER=1): only rows of depth < d0
-//                 in LDS, boundary states guarded by a lookahead Bloom filter,
-//                 exact verification in batched bursts.
 //   k2_sort       scatters the records into final (position) order using the
 //                 exclusive scan of per-chunk event counts, resolves the key
 //                 and its output-chain length.
@@ -40,7 +37,6 @@ namespace aha {
 
 namespace {
 
-constexpr int kWaveIn = 64 * kV2Piece;  // LDS input bytes per wave in filter mode (16-byte columns)
 constexpr uint32_t kLastFlag = 0x8000u;
 
 template <bool COMPACT>
@@ -440,431 +436,6 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
     }
   }
   if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
-}
-
-// ------------------------------------------------- traverse, filter mode
-// Same contract as k2_traverse, but HBM probes are made rare instead of fast.
-// LDS holds only the rows of states with depth < d0 plus a lookahead Bloom
-// filter; a lane is in one of three modes:
-//   FAST   walks the depth<=d0 ("shallow") automaton entirely in LDS.  At a
-//          boundary state (depth d0) the filter is asked whether an excursion
-//          below it could be observable or longer than 2 bytes (automaton.hpp,
-//          Filter).  "No" (no false negatives) => the lane behaves as if the
-//          goto did not exist; its state then equals the true state whenever
-//          the true depth is <= d0, and every deeper true state in between is
-//          unobservable, so the events are exactly the reference's.
-//   PEND   the filter said "maybe": the lane parks (no probe) until the wave
-//          has a batch of parked lanes, then the exact set in HBM is consulted
-//          (false positives go back to FAST).
-//   EXACT  true positives re-derive the true state by replaying the last
-//          d0+2 consumed bytes from root (the true depth is <= d0+2 by
-//          induction) and walk the full automaton (LDS rows or HBM) until the
-//          state is shallow again.
-// Exact steps of a wave are batched ("bursts") so that one L2 round trip
-// serves many lanes and FAST trips never wait on memory.
-constexpr int kBurstHi = 40, kBurstLo = 8;
-
-__device__ __forceinline__ bool bloom_test(const uint32_t *flt, uint32_t words, uint32_t B, uint32_t w) {
-  const uint32_t h = filter_hash(B, w);
-  const uint32_t m = filter_mask(h);
-  return (flt[filter_word(h, words)] & m) == m;
-}
-__device__ __forceinline__ bool xset_has(const uint64_t *xs, uint32_t xmask, uint32_t B, uint32_t w) {
-  const uint64_t k = ((uint64_t)B << 32) | w;
-  uint32_t i = filter_hash(B, w) & xmask;
-  for (;;) {
-    const uint64_t v = xs[i];
-    if (v == k) return true;
-    if (v == 0) return false;
-    i = (i + 1) & xmask;
-  }
-}
-
-template <bool COMPACT>
-__global__ __launch_bounds__(kV2Threads) void k3_traverse(DevAut A, V2Args M) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  using S_ = Slot<COMPACT>;
-  using slot_t = typename S_::type;
-  slot_t *lt = reinterpret_cast<slot_t *>(smem);
-  const slot_t *gt = reinterpret_cast<const slot_t *>(A.slots);
-  const uint32_t T = A.t_rows, TB = A.t_bend, FW = A.bloom_words, d0 = A.d0;
-  uint32_t *flt = reinterpret_cast<uint32_t *>(smem + (size_t)T * sizeof(slot_t));
-  uint8_t *in_base = reinterpret_cast<uint8_t *>(flt + FW);
-  {
-    const uint4 *src = reinterpret_cast<const uint4 *>(gt);
-    uint4 *dst = reinterpret_cast<uint4 *>(lt);
-    const uint32_t nvec = (uint32_t)((size_t)T * sizeof(slot_t) / 16);
-    for (uint32_t i = threadIdx.x; i < nvec; i += kV2Threads) dst[i] = src[i];
-    const uint4 *fs = reinterpret_cast<const uint4 *>(A.bloom);
-    uint4 *fd = reinterpret_cast<uint4 *>(flt);
-    for (uint32_t i = threadIdx.x; i < FW / 4; i += kV2Threads) fd[i] = fs[i];
-  }
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint8_t *inl = in_base + wave * kWaveIn + lane * 16;
-  const uint32_t root = A.root;
-  const int64_t N = (int64_t)M.n_bytes;
-  const uint64_t D = M.n_docs;
-  const int64_t S = (int64_t)M.S;
-  const int rounds = (int)(M.S / kV2Piece);
-  const int warm = A.max_len > 1 ? (int)A.max_len - 1 : 0;
-  const int R = (warm + kV2Piece - 1) / kV2Piece;
-
-  uint64_t slab_pos = 0;
-  uint32_t slab_left = 0, slab_used_n = 0;
-  uint64_t slab_id = ~0ull;
-  unsigned long long st_fi = 0, st_fl = 0, st_bi = 0, st_bl = 0, st_ft = 0, st_bt = 0;
-
-  const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint64_t chunk = tile * kV2Threads + threadIdx.x;
-    const bool live = chunk < M.n_chunks;
-    const int64_t a = (int64_t)chunk * S;
-    const int64_t e = live ? min(a + S, N) : a;
-    uint64_t dn = 0;
-    int64_t nb = INT64_MAX, doc_start = a, pos = e;
-    uint32_t B = root, fr = 0, seq = 0;
-    uint32_t lc = 0, lc_exact = 0, lead_total = 0;
-    uint32_t mode = 2;        // 0 FAST, 1 PEND, 2 EXACT (the warm-up runs exact)
-    uint64_t hist = 0;        // last consumed bytes, newest in the low byte
-    uint32_t since = 0;       // bytes consumed since the lane / document started (saturates)
-    uint32_t replay = 0, skipf = 0;
-    bool in_burst = false;
-    if (live) {
-      dn = first_boundary(M.doc_off, D, (uint64_t)a);
-      nb = (int64_t)M.doc_off[dn];
-      pos = a;
-      if (nb != a) {
-        doc_start = (int64_t)M.doc_off[dn - 1];
-        pos = a - min<int64_t>(a - doc_start, warm);
-        if (M.chars) M.chunk_doc0[chunk] = (uint32_t)(dn - 1);
-      } else if (M.chars) {
-        M.chunk_doc0[chunk] = (uint32_t)dn;
-      }
-    }
-
-    for (int r = -R; r < rounds; r++) {
-      const int64_t pb = a + (int64_t)r * kV2Piece;
-      const int64_t pend = min(pb + kV2Piece, e);
-      const bool need = live && pos < pend;
-      if (!__any(need)) continue;
-      uint32_t la = 0;  // the 4 bytes after the piece (filter lookahead)
-      if (need) {
-#pragma unroll
-        for (int k = 0; k < kV2Piece / 16; k++) {
-          const int64_t g = pb + k * 16;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (g >= 0 && g + 16 <= N) {
-            v = *reinterpret_cast<const uint4 *>(M.text + g);
-          } else if (g >= 0 && g < N) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (int j = 0; j < 16 && g + j < N; j++) w[j >> 2] |= (uint32_t)M.text[g + j] << ((j & 3) * 8);
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-          }
-          *reinterpret_cast<uint4 *>(inl + k * 1024) = v;
-        }
-        const int64_t g = pb + kV2Piece;
-        if (g >= 0 && g + 4 <= N) {
-          la = *reinterpret_cast<const uint32_t *>(M.text + g);
-        } else if (g >= 0) {
-          for (int j = 0; j < 4 && g + j < N; j++) la |= (uint32_t)M.text[g + j] << (j * 8);
-        }
-      }
-      // Retire the staging loads here: inside the hot loop a pending load would
-      // make hipcc wait with vmcnt(0) at its first use, and on CDNA4 vmcnt also
-      // counts the event STORES of earlier trips (a full write round trip per trip).
-      asm volatile("" : "+v"(la));
-      auto byte_at = [&](int64_t q) -> uint32_t {
-        const uint32_t o = (uint32_t)(q - pb);
-        return o < (uint32_t)kV2Piece ? (uint32_t)inl[(o >> 4) * 1024 + (o & 15)] : (la >> ((o - kV2Piece) * 8)) & 0xFFu;
-      };
-
-      for (;;) {
-        const bool has = live && pos < pend;
-        const unsigned long long mf = __ballot(has && mode == 0);
-        const unsigned long long ms = __ballot(has && mode != 0);
-        if (!(mf | ms)) break;
-        bool do_fast;
-        if (!mf) {
-          do_fast = false;
-        } else if (!ms) {
-          do_fast = true;
-        } else {
-          const int c = __popcll(ms);
-          if (in_burst) {
-            if (c < kBurstLo) in_burst = false;
-          } else if (c >= kBurstHi) {
-            in_burst = true;
-          }
-          do_fast = !in_burst;
-        }
-        bool ev = false;
-        uint32_t ev_w = 0, ev_z = 0, ev_y = 0, ev_aux = 0;
-        const bool act = has && (do_fast ? mode == 0 : mode != 0);
-        long long t_begin = 0;
-        if (M.dbg) {
-          t_begin = clock64();
-          if (do_fast) {
-            st_fi++;
-            st_fl += __popcll(mf);
-          } else {
-            st_bi++;
-            st_bl += __popcll(ms);
-          }
-        }
-        if (act) {
-          if (pos == nb) {  // a document starts here (ac.cr:177: state is per sequence)
-            do {
-              M.doc_ev_rank[dn] = seq;
-              if (M.chars) M.doc_lead_rank[dn] = lead_total;
-              dn++;
-              nb = dn <= D ? (int64_t)M.doc_off[dn] : INT64_MAX;
-            } while (nb == pos);
-            asm volatile("" : "+v"(nb));  // retire the load here, not at the loop head (see staging note)
-            B = root;
-            fr = 0;
-            doc_start = pos;
-            lc = 0;
-            lc_exact = 1;
-            mode = do_fast ? 0u : 2u;  // an exact lane simply continues exact from root
-            replay = 0;
-            since = 0;
-            skipf = 0;
-          }
-          bool consumed = false;  // consumed a REAL byte (advances pos)
-          uint32_t b = 0;
-          if (do_fast) {
-            // ------------------------------------------------ FAST: LDS only
-            b = byte_at(pos);
-            if (b == 0) {
-              B = root;
-              fr = 0;
-              consumed = true;
-            } else if (B < T) {
-              const slot_t en = lt[B ^ b];
-              if (S_::match(en, b)) {
-                B = S_::base(en);
-                fr = S_::failroot(en);
-                consumed = true;
-                if (S_::end(en) && pos >= a) {
-                  ev = true;
-                  ev_w = S_::payload(en);
-                }
-              } else if (B == root) {
-                consumed = true;
-              } else if (fr) {
-                B = root;
-                fr = 0;
-              } else {
-                const slot_t h = lt[B];
-                B = S_::base(h);
-                fr = S_::failroot(h);
-              }
-            } else {
-              // boundary state (depth d0): ask the filter about the next <= 3 bytes
-              bool suspect = false;
-              if (!skipf) {
-                const int64_t room = nb - pos;  // bytes left in the document (>= 1)
-                const uint32_t x1 = b;
-                suspect = bloom_test(flt, FW, B, filter_key(1, x1, 0, 0));
-                if (room >= 2) {
-                  const uint32_t x2 = byte_at(pos + 1);
-                  suspect = suspect || bloom_test(flt, FW, B, filter_key(2, x1, x2, 0));
-                  if (room >= 3) {
-                    const uint32_t x3 = byte_at(pos + 2);
-                    suspect = suspect || bloom_test(flt, FW, B, filter_key(3, x1, x2, x3));
-                  }
-                }
-              }
-              if (suspect) {
-                mode = 1;  // park; nothing consumed
-              } else {
-                skipf = 0;
-                // behave as a miss: fail(B) is the longest proper suffix (of the
-                // last d0 consumed bytes) that is a path -- walk it in LDS
-                if (fr) {
-                  B = root;
-                  fr = 0;
-                } else {
-                  uint32_t nbse = root, nfr = 0;
-                  for (uint32_t L = d0 - 1; L >= 1; L--) {
-                    uint32_t sB = root, sfr = 0;
-                    bool ok = true;
-                    for (uint32_t j = L; j >= 1 && ok; j--) {
-                      const uint32_t hb = (uint32_t)(hist >> (8 * (j - 1))) & 0xFFu;
-                      const slot_t en = lt[sB ^ hb];
-                      if (S_::match(en, hb)) {
-                        sB = S_::base(en);
-                        sfr = S_::failroot(en);
-                      } else {
-                        ok = false;
-                      }
-                    }
-                    if (ok) {
-                      nbse = sB;
-                      nfr = sfr;
-                      break;
-                    }
-                  }
-                  B = nbse;
-                  fr = nfr;
-                }
-              }
-            }
-          } else if (mode == 1) {
-            // ------------------------------------------------ PEND: exact-set check
-            const int64_t room = nb - pos;
-            const uint32_t x1 = byte_at(pos);
-            // the three keys are looked up together (independent loads in flight)
-            const uint32_t x2 = room >= 2 ? byte_at(pos + 1) : 0u;
-            const uint32_t x3 = room >= 3 ? byte_at(pos + 2) : 0u;
-            const uint32_t w1 = filter_key(1, x1, 0, 0), w2 = filter_key(2, x1, x2, 0), w3 = filter_key(3, x1, x2, x3);
-            uint32_t i1 = filter_hash(B, w1) & A.xmask, i2 = filter_hash(B, w2) & A.xmask,
-                     i3 = filter_hash(B, w3) & A.xmask;
-            const uint64_t k1 = ((uint64_t)B << 32) | w1, k2 = ((uint64_t)B << 32) | w2, k3 = ((uint64_t)B << 32) | w3;
-            bool real = false, open1 = true, open2 = room >= 2, open3 = room >= 3;
-            while (open1 || open2 || open3) {
-              uint64_t v1 = open1 ? A.xset[i1] : 0ull;
-              uint64_t v2 = open2 ? A.xset[i2] : 0ull;
-              uint64_t v3 = open3 ? A.xset[i3] : 0ull;
-              asm volatile("" : "+v"(v1), "+v"(v2), "+v"(v3));  // all three loads retire here (no pending load leaves this block)
-              if (open1) { if (v1 == k1) real = true; if (v1 == k1 || v1 == 0) open1 = false; else i1 = (i1 + 1) & A.xmask; }
-              if (open2) { if (v2 == k2) real = true; if (v2 == k2 || v2 == 0) open2 = false; else i2 = (i2 + 1) & A.xmask; }
-              if (open3) { if (v3 == k3) real = true; if (v3 == k3 || v3 == 0) open3 = false; else i3 = (i3 + 1) & A.xmask; }
-              if (real) break;
-            }
-            if (!real) {
-              mode = 0;  // false positive: continue FAST, skipping the filter once
-              skipf = 1;
-            } else {
-              mode = 2;
-              replay = min(since, d0 + 2);
-              B = root;
-              fr = 0;
-            }
-          } else {
-            // ------------------------------------------------ EXACT: full automaton
-            b = replay ? (uint32_t)(hist >> (8 * (replay - 1))) & 0xFFu : byte_at(pos);
-            bool took = false;
-            if (b == 0) {
-              B = root;
-              fr = 0;
-              took = true;
-            } else {
-              const uint32_t idx = B ^ b;
-              slot_t en;
-              if (idx < T)
-                en = lt[idx];
-              else
-                en = gt[idx];
-              if (S_::match(en, b)) {
-                B = S_::base(en);
-                fr = S_::failroot(en);
-                took = true;
-                if (S_::end(en) && !replay && pos >= a) {
-                  ev = true;
-                  ev_w = S_::payload(en);
-                }
-              } else if (B == root) {
-                took = true;
-              } else if (fr) {
-                B = root;
-                fr = 0;
-              } else {
-                slot_t h;
-                if (B < T)
-                  h = lt[B];
-                else
-                  h = gt[B];
-                B = S_::base(h);
-                fr = S_::failroot(h);
-              }
-            }
-            if (took) {
-              if (replay) {
-                replay--;
-              } else {
-                consumed = true;
-                if (B < TB) mode = 0;  // depth <= d0 again: the shallow walk is exact from here
-              }
-            }
-          }
-          if (consumed) {
-            hist = (hist << 8) | b;
-            since = min(since + 1u, 15u);
-            if (M.chars && pos >= a) {
-              const uint32_t isl = (b & 0xC0u) != 0x80u;
-              lc += isl;
-              lead_total += isl;
-            }
-            if (ev) {
-              const uint32_t last = (pos + 1 == nb) ? kLastFlag : 0u;
-              ev_y = (seq << 16) | last | (uint32_t)(pos - a);
-              ev_z = (uint32_t)(pos - doc_start) + 1u;
-              ev_aux = (lc << 1) | lc_exact;
-              seq++;
-            }
-            pos++;
-          }
-        }
-        const unsigned long long mask = __ballot(ev);
-        if (mask) {
-          const uint32_t n = (uint32_t)__popcll(mask);
-          if (slab_left < n) {
-            if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(M.cursor, (unsigned long long)kV2Slab);
-            base = __shfl(base, 0, 64);
-            slab_pos = base;
-            slab_left = kV2Slab;
-            slab_used_n = 0;
-            slab_id = base / kV2Slab;
-            if (base + kV2Slab > M.ev_cap) {
-              if (lane == 0) M.cursor[1] = 1ull;
-              slab_id = ~0ull;
-            }
-          }
-          if (ev && slab_id != ~0ull) {
-            const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            M.ev[slab_pos + my] = make_uint4((uint32_t)chunk, ev_y, ev_z, ev_w);
-            if (M.chars) M.ev_aux[slab_pos + my] = ev_aux;
-          }
-          slab_pos += n;
-          slab_left -= n;
-          slab_used_n += n;
-        }
-        if (M.dbg) {
-          const long long dt = clock64() - t_begin;
-          if (do_fast)
-            st_ft += dt;
-          else
-            st_bt += dt;
-        }
-      }
-    }
-    if (live) {
-      M.ev_cnt[chunk] = seq;
-      if (M.chars) M.lead_cnt[chunk] = lead_total;
-      if (e == N) {
-        while (dn <= D) {
-          M.doc_ev_rank[dn] = seq;
-          if (M.chars) M.doc_lead_rank[dn] = lead_total;
-          dn++;
-        }
-      }
-    }
-  }
-  if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
-  if (M.dbg && lane == 0) {
-    atomicAdd(M.dbg + 0, st_fi);
-    atomicAdd(M.dbg + 1, st_fl);
-    atomicAdd(M.dbg + 2, st_bi);
-    atomicAdd(M.dbg + 3, st_bl);
-    atomicAdd(M.dbg + 4, st_ft);
-    atomicAdd(M.dbg + 5, st_bt);
-  }
 }
 
 // ---------------------------------------------------------------- scans
@@ -1270,15 +841,11 @@ __global__ __launch_bounds__(256) void k2d_doc_offsets(DevAut A, V2Args M) {
 }
 
 // ---------------------------------------------------------------- launchers
-size_t v2_lds_bytes(uint32_t lds_slots, bool compact, uint32_t bloom_words) {
-  // filter mode (bloom_words != 0) keeps the 16-byte-column window, the plain walk the padded rows
-  return (size_t)lds_slots * (compact ? 4 : 8) + (size_t)bloom_words * 4 +
-         (size_t)(kV2Threads / 64) * (bloom_words ? kWaveIn : kWaveIn2);
+size_t v2_lds_bytes(uint32_t lds_slots, bool compact) {
+  return (size_t)lds_slots * (compact ? 4 : 8) + (size_t)(kV2Threads / 64) * kWaveIn2;
 }
 
-int v2_prepare(bool compact, bool filter, size_t lds_bytes) {
-  const void *f = compact ? (const void *)k3_traverse<true> : (const void *)k3_traverse<false>;
-  if (filter) return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+int v2_prepare(bool compact, size_t lds_bytes) {
   const void *fs[8] = {(const void *)k2_traverse<false, false, false>, (const void *)k2_traverse<false, true, false>,
                        (const void *)k2_traverse<false, false, true>,  (const void *)k2_traverse<false, true, true>,
                        (const void *)k2_traverse<true, false, false>,  (const void *)k2_traverse<true, true, false>,
@@ -1294,13 +861,8 @@ int v2_prepare(bool compact, bool filter, size_t lds_bytes) {
 
 void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = v2_lds_bytes(M.lds_slots, A.compact != 0, A.d0 ? A.bloom_words : 0);
-  if (A.d0) {
-    if (A.compact)
-      hipLaunchKernelGGL(k3_traverse<true>, dim3(grid), dim3(kV2Threads), lds, s, A, M);
-    else
-      hipLaunchKernelGGL(k3_traverse<false>, dim3(grid), dim3(kV2Threads), lds, s, A, M);
-  } else {
+  const size_t lds = v2_lds_bytes(M.lds_slots, A.compact != 0);
+  {
     const bool all = M.lds_slots >= A.n_slots && A.s2_hi == 0;  // whole image in LDS and a header for every state
 #define AHA_LAUNCH_K2(C, H, L) \
   hipLaunchKernelGGL((k2_traverse<C, H, L>), dim3(grid), dim3(kV2Threads), lds, s, A, M)

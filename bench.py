@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--chars", action="store_true", help="String overload (char offsets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
+    ap.add_argument("--parity-bytes", type=int, default=32 << 20,
+                    help="bytes of the first documents compared with the oracle on every run (the parity gate)")
     ap.add_argument("--exchange", default="packed", choices=["packed", "triples"],
                     help="N>1 payload of the all-gatherv: {end,value} pairs (8 B per hit, triples rebuilt on arrival; "
                          "default) or the 12-byte Hit triples themselves")
@@ -59,6 +61,40 @@ def parse():
                     help="N>1 collective backend; gloo (hits staged through host memory) only to rehearse the "
                          "multi-rank flow on a 1-GPU box together with AHA_BENCH_ONE_DEVICE=1")
     return ap.parse_args()
+
+
+def lib_fingerprint():
+    """sha256 over the sources libaha_hip.so is built from: PMC traffic files are only valid for the build they were
+    measured on (a rebuilt binary need not be bit-identical, its sources are)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "aha_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "aha_hip.h")])
+    for f in files:
+        if os.path.isfile(f) and not f.endswith((".o", ".so")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def parity_sample(blob, offs, corpus, doc, gpu_hits, gpu_dho, chars, max_bytes, log):
+    """Compares the GPU hits and per-document offsets of the first documents (up to max_bytes) with the oracle.
+    Returns "bit-exact" / "MISMATCH".  The oracle is the checker here, never the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc
+
+    o = orc.AC.compile_packed(blob, offs)
+    D = doc.size - 1
+    d1 = max(1, int(np.searchsorted(doc, max_bytes, side="right")) - 1)
+    d1 = min(d1, D)
+    sub = doc[:d1 + 1] - doc[0]
+    seg = corpus[:int(doc[d1])]
+    oh, od = o.match_batch(seg, sub, cap=max(1024, seg.size // 4), chars=chars)  # grows on demand
+    b = int(gpu_dho[d1])
+    ok = b == len(oh) and gpu_hits[:b].tobytes() == oh.tobytes() and np.array_equal(gpu_dho[:d1 + 1], od)
+    log(f"parity sample: {d1} documents, {seg.size} bytes, {len(oh)} hits: {'bit-exact' if ok else 'MISMATCH'}")
+    return "bit-exact" if ok else "MISMATCH"
 
 
 def cpu_baseline(blob, offs, corpus, doc, gpu_hits, gpu_dho, seconds, log):
@@ -272,36 +308,50 @@ def main():
         dom, dom_ms = "k_count", avg["ms_count"]
         alg_bytes = n_bytes + 8 * (D + 1) + A
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    try:  # PMC HBM bytes per launch, measured in separate rocprofv3 --pmc passes (profiles/)
+    traffic, traffic_src = None, None
+    try:  # PMC HBM bytes per launch, measured in separate rocprofv3 --pmc passes of THIS build (tools/collect_profiles.sh)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-        if pmc.get("config") == cfg and pmc.get("bytes_per_gpu") == n_bytes:
+        if pmc.get("config") == cfg and pmc.get("bytes_per_gpu") == n_bytes and pmc.get("lib_sha256") == lib_fingerprint():
             traffic = pmc["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_src = {"file": "profiles/pmc_traffic_latest.json", "git_head": pmc.get("git_head"),
+                           "lib_sha256": pmc.get("lib_sha256")[:16]}
+        else:
+            log("profiles/pmc_traffic_latest.json was not measured on this build/config: roofline.traffic = null")
     except Exception:
         pass
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "traffic_source": traffic_src,
         "alg_bytes_per_launch": int(alg_bytes), "avg_ms": round(dom_ms, 4), "engine": engine,
         "whole_path_frac": round((n_bytes + 12 * n_hits + 16 * (D + 1) + A) / (avg["ms_total"] * 1e-3) / 1e9
                                  / HBM_PEAK_GBS, 4),
         "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
     }
 
+    # ---- parity gate: no throughput figure without a bit-exact comparison on this run's hits.
+    # Rank 0 checks its own shard once, outside the timed region, on every run (N > 1 and profiler runs included).
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    parity = "unchecked"
+    if rank == 0:
         hits_h = d_out[:n_hits].cpu().numpy().view(np.dtype([("start", "<i4"), ("end", "<i4"), ("value", "<i4")])).reshape(-1)
         dho_h = d_dho.cpu().numpy().astype(np.uint64)
-        if args.chars:
-            hits_h = None
-        cpu, exact = cpu_baseline(blob, offs, corpus, doc, hits_h, dho_h, args.cpu_seconds, log)
-        if not exact:
-            log("PARITY MISMATCH against the oracle on the sampled documents")
+        parity = parity_sample(blob, offs, corpus, doc, hits_h, dho_h, args.chars, args.parity_bytes, log)
+        if world == 1 and not args.no_cpu_baseline and parity == "bit-exact":
+            cpu, exact = cpu_baseline(blob, offs, corpus, doc, None if args.chars else hits_h, dho_h, args.cpu_seconds, log)
+            if args.chars:
+                cpu["parity_on_sample"] = "unchecked (the timed CPU leg is the Bytes overload)"
+            if not exact:
+                parity = "MISMATCH"
+        if parity != "bit-exact":
+            log("PARITY MISMATCH against the oracle: no throughput is reported")
 
     if rank == 0:
+        ok = parity == "bit-exact"
         line = {
             "metric": "input GB/s scanned + M-hits/s, 100k-pattern AC over 1 GiB UTF-8 corpus",
-            "value": round(gbs, 3), "unit": "GB/s", "m_hits_per_s": round(mhits, 2),
+            "value": round(gbs, 3) if ok else None, "unit": "GB/s", "m_hits_per_s": round(mhits, 2) if ok else None,
+            "parity": parity,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
@@ -320,6 +370,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and parity != "bit-exact":
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -82,10 +82,7 @@ typedef struct {
   uint32_t slot_bytes;      /* 4 (compact) or 8 (wide) */
   uint32_t lds_slots;       /* slots of the image cached in LDS by the match kernel */
   int32_t device;           /* device the image lives on, -1 if host only */
-  uint32_t filter_d0;       /* filter mode: boundary depth (0 = filter off) */
-  uint32_t filter_words;    /* 32-bit words of the LDS Bloom filter */
-  uint64_t filter_entries;  /* entries of the exact set behind it */
-  uint32_t boundary_end;    /* slots below this belong to states of depth <= filter_d0 */
+  uint32_t reserved0[5];    /* (fields of the removed boundary-filter mode) */
   uint32_t reserved;
   /* Shadow fail links (all 0 = every state has a fail header at slot[base]).  Otherwise only the root and the
    * states with base >= fail_hdr_lo own one; for the others the fail target follows from the last input bytes:
@@ -188,8 +185,6 @@ enum {
   AHA_IMG_KEY_LN = 2,  /* {uint32 len, int32 next}[K] */
   AHA_IMG_KEY_CNT = 3, /* uint32[K] */
   AHA_IMG_KEY_KC = 4,  /* uint32[K] */
-  AHA_IMG_BLOOM = 5,   /* uint32[filter_words] (filter mode) */
-  AHA_IMG_XSET = 6,    /* uint64[pow2] exact set behind the filter */
   AHA_IMG_PP_T2 = 7,   /* uint32[4096]: 2-bit entries of the position-parallel engine's pair table */
   AHA_IMG_PP_BLOOM = 8 /* uint32[pp_bloom_words] */
 };

@@ -165,108 +165,6 @@ def test_synth_generators_deterministic():
     orc.AC.compile_packed(b5, o5)
 
 
-# ---- filter mode (k3_traverse) logic on the CPU --------------------------------
-from imgsim import FilterSim  # noqa: E402
-
-
-@pytest.fixture
-def filter_opt_in(monkeypatch):
-    # filter mode is opt-in (AHA_FILTER is read when a handle is compiled)
-    monkeypatch.setenv("AHA_FILTER", "1")
-
-
-def _filter_ac(keys, wide=False):
-    ac = AC.compile(keys, host_only=True, force_wide=wide)
-    return ac
-
-
-@pytest.mark.parametrize("wide", [False, True])
-@pytest.mark.parametrize("seed", range(6))
-def test_filter_mode_matches_oracle(seed, wide, filter_opt_in):
-    # automata too large for the LDS budget switch to filter mode; the CPU twin
-    # of the FAST/PEND/EXACT lane logic must reproduce the oracle bit for bit
-    rng = random.Random(300 + seed)
-    if seed % 2 == 0:
-        alphabet = bytes(range(1, 256))
-        keys = rand_keys(rng, 14000, alphabet, 1, 9)
-    else:  # UTF-8-like mix with heavy shallow sharing and nested keys
-        alphabet = b"abcdefghijklmnop\xe4\xe5\xb8\xad\x80\x81"
-        keys = rand_keys(rng, 30000, alphabet, 1, 8)
-    ac = _filter_ac(keys, wide)
-    info = ac.info
-    if info["filter_d0"] == 0:
-        pytest.skip("automaton fits LDS: filter off")
-    pieces = []
-    for _ in range(600):
-        r = rng.random()
-        if r < 0.4:
-            pieces.append(rng.choice(keys))
-        elif r < 0.5:
-            k = rng.choice(keys)
-            pieces.append(k[: rng.randint(1, len(k))])  # broken-off prefixes: deep excursions that fail
-        else:
-            pieces.append(bytes(rng.choice(alphabet + b"\x00") for _ in range(rng.randint(1, 6))))
-    text = b"".join(pieces)
-    sim = FilterSim(ac)
-    got = sim.match(text)
-    assert got == as_list(orc.AC.compile(keys).match(text))
-    assert sim.stats["fast"] > 0 and sim.stats["exact"] > 0
-
-
-def test_filter_mode_on_headline_shape(filter_opt_in):
-    from aha_amd import synth
-
-    blob, offs, nf = synth.keys(3)
-    ac = AC.compile_packed(blob, offs, host_only=True)
-    assert ac.info["filter_d0"] >= 2
-    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 17, doc_bytes=1 << 17)
-    sim = FilterSim(ac)
-    got = sim.match(corpus.tobytes())
-    oh, _ = orc.AC.compile_packed(blob, offs).match_batch(corpus, doc)
-    assert got == as_list(oh)
-    s = sim.stats
-    # the point of the filter: HBM probes per byte drop by an order of magnitude
-    assert s["global"] / corpus.size < 0.25, s
-
-
-# ---- save / load (src/aha/ac.cr:45-60; own container) -----------------
-def test_save_load_round_trip_keeps_ids_and_image(tmp_path):
-    keys = ["我", "我是", "是中", "abc", "bcd", "c"]
-    a = AC.compile(keys, host_only=True)
-    data = a.to_bytes()
-    assert data[:8] == b"AHAHIP01"
-    b = AC.from_bytes(data, host_only=True)
-    assert b.info["n_keys"] == len(keys)
-    for i, k in enumerate(keys):
-        assert b[i] == k and b[k] == i
-    for which, dt in ((0, np.uint32), (1, np.int32), (2, np.uint32), (3, np.uint32)):
-        assert np.array_equal(a.export(which, dt), b.export(which, dt))
-    path = tmp_path / "ac.bin"
-    a.save(str(path))
-    c = AC.load(str(path), host_only=True)
-    assert c.to_bytes() == data
-    with open(path, "rb") as f:
-        assert AC.load(f, host_only=True).to_bytes() == data
-
-
-def test_load_rejects_corrupt_or_truncated_input():
-    data = bytearray(AC.compile(["ab", "bc"], host_only=True).to_bytes())
-    for bad in (bytes(data[:-1]), bytes(data[:10]), b"", b"NOTAHA00" + bytes(data[8:])):
-        with pytest.raises(AhaError) as e:
-            AC.from_bytes(bad, host_only=True)
-        assert e.value.code == N.AHA_E_INVALID
-    data[30] ^= 0x40  # flip one bit of the payload: the checksum must catch it
-    with pytest.raises(AhaError) as e:
-        AC.from_bytes(bytes(data), host_only=True)
-    assert e.value.code == N.AHA_E_INVALID
-
-
-def test_save_load_empty_key_set():
-    a = AC.compile([], host_only=True)
-    b = AC.from_bytes(a.to_bytes(), host_only=True)
-    assert b.info["n_keys"] == 0
-
-
 # ---- C ABI misuse: every entry point answers a bad argument with a status, never a crash -------
 def test_c_abi_rejects_bad_arguments():
     L = N.lib()

@@ -7,11 +7,20 @@ note = ("rocprofv3 --pmc, separate passes with --kernel-trace only, over `python
         "--no-cpu-baseline` (cfg3: 100k keys, 1 GiB); averages per launch. FETCH_SIZE/WRITE_SIZE raw units are KB; "
         "gfx950 FETCH_SIZE can under-report wide coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM) -- "
         "per-lane 16 B strided loads are uncalibrated, so raw values are quoted. SQ_* cycle counters are quad-cycles.")
-out = {"_note": note, "config": 3, "bytes_per_gpu": 1 << 30, "kernels": {}}
+sys.path.insert(0, os.getcwd())
+import subprocess
+
+from bench import lib_fingerprint  # the sources the profiled library was built from
+
+head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "aha_amd/csrc", "include"], capture_output=True,
+                            text=True).stdout.strip())
+out = {"_note": note, "config": 3, "bytes_per_gpu": 1 << 30, "git_head": head + ("+dirty" if dirty else ""),
+       "lib_sha256": lib_fingerprint(), "kernels": {}}
 
 
 def short(k):
-    m = re.search(r"(k2?d?_[a-z_]+)", k)
+    m = re.search(r"(k2?d?_[a-z_]+|k_pp_[a-z_]+)", k)
     return m.group(1) if m else None
 
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "aha_ac_hits_unpack_device": (_i32, [_vp, _vp, _u64, _i32, _vp, _vp]),
     "aha_ac_save": (C.c_int64, [_vp, _vp, _u64]),
     "aha_ac_load": (_i32, [_vp, _u64, C.POINTER(aha_options), C.POINTER(_vp)]),
+    "aha_ac_release_scratch": (_i32, [_vp]),
     "aha_ac_set_profiling": (_i32, [_vp, _i32]),
     "aha_ac_last_timing": (_i32, [_vp, C.POINTER(aha_timing)]),
 }

@@ -309,6 +309,10 @@ class AC:
     def set_profiling(self, enabled=True):
         self._check(N.lib().aha_ac_set_profiling(self._h, 1 if enabled else 0))
 
+    def release_scratch(self):
+        """Frees the handle's grow-only device scratch."""
+        self._check(N.lib().aha_ac_release_scratch(self._h))
+
     def last_timing(self):
         t = N.aha_timing()
         self._check(N.lib().aha_ac_last_timing(self._h, C.byref(t)))

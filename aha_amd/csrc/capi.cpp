@@ -47,12 +47,6 @@ struct aha_ac {
   uint32_t v2_grid = 0;
   uint32_t v2_bpc = 1;
   uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
-  uint32_t direct_div = 4;         // plain mode: a chunk's event region holds S / direct_div events; set to 1 (one
-                                   // event per input byte: cannot overflow) once a region overflowed (hit-dense input)
-  bool direct_overflowed = false;  // event regions not usable (temp too large): keep to the slab pipeline
-  bool dense_hits = true;          // more than one hit per 4 input bytes in the last call (unknown: assume so)
-  bool sparse_hits = false;        // the last call produced < 16 hits per chunk: the slab pipeline (cost ~ events)
-                                   // beats the region pipeline (cost ~ chunks) on such input
   struct Buf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -246,13 +240,22 @@ int32_t v2_reserve(aha_ac *ac, int i, size_t bytes) {
   return AHA_OK;
 }
 
-// returns AHA_OK, an error, or +1 when the caller must fall back to the two-pass engine
-int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, bool allow_direct) {
+// Pipeline of one call, a function of the call alone (the handle keeps no history):
+//   kRegions      per-chunk event regions sized from the caller's capacity (a hit is an event or hangs on one, so the
+//                 batch has at most `cap` events the caller can take: twice the average per chunk, plus slack)
+//   kFullRegions  regions of one event per input byte (cannot overflow); taken at once when cap says the caller
+//                 expects more than one hit per 4 bytes, else after a region overflowed
+//   kSlabs        slab + sort pipeline: separator filter, fewer than 16 hits per chunk expected (its cost follows the
+//                 events, not the chunks), or regions beyond the temp bound
+enum V2Mode { kRegions = 0, kFullRegions = 1, kSlabs = 2 };
+constexpr uint64_t kV2MaxRegionBytes = 48ull << 30;
+
+// returns AHA_OK, an error, +1 when the caller must fall back to the two-pass engine, +2 when a region overflowed
+int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, V2Mode mode) {
   const uint64_t N = M1.n_bytes;
   const uint32_t Lmax = ac->aut.max_key_len;
   uint64_t s_min = std::max<uint64_t>(64, ((8ull * Lmax + 63) / 64) * 64);
   if (s_min > kV2MaxS) return 1;
-  if (reinterpret_cast<uintptr_t>(M1.text) % 16 != 0) return 1;
   uint64_t lanes = (uint64_t)ac->v2_grid * kV2Threads;
   uint64_t S = ((N + lanes - 1) / lanes + 63) / 64 * 64;
   S = std::min<uint64_t>(std::max<uint64_t>(S, s_min), kV2MaxS);
@@ -271,18 +274,21 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   M.out = M1.out;
   M.cap = M1.cap;
   M.doc_hit_off = M1.doc_hit_off;
-  // plain mode (byte offsets, no separator filter, no boundary filter): per-chunk event regions, no sort
+  // plain mode (byte offsets or char offsets, no separator filter): per-chunk event regions, no sort
   const char *de = getenv("AHA_DIRECT");
-  bool direct = !(de && strcmp(de, "0") == 0) && !M.sep && allow_direct &&
-                !ac->direct_overflowed && !ac->sparse_hits;
+  const bool dense = M1.cap / 4 > N / 16;          // more than one hit per 4 input bytes expected
+  const bool sparse = M1.cap < 16ull * M.n_chunks;  // fewer than 16 hits per chunk expected
+  if (de && strcmp(de, "0") == 0) mode = kSlabs;
+  if (M.sep || (mode == kRegions && sparse)) mode = kSlabs;
+  if (mode == kRegions && dense) mode = kFullRegions;
+  uint64_t stride = S;
+  if (mode == kRegions) stride = std::min<uint64_t>(S, std::max<uint64_t>(16, 2 * (M1.cap / M.n_chunks) + 64));
+  if (mode != kSlabs && M.n_chunks * stride * 8 > kV2MaxRegionBytes) mode = kSlabs;
+  const bool direct = mode != kSlabs;
   const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
   M.direct = direct ? 1 : 0;
-  M.dense_hits = ac->dense_hits ? 1 : 0;
-  M.ev_stride = (uint32_t)std::max<uint64_t>(16, S / ac->direct_div);
-  if (direct && M.n_chunks * (uint64_t)M.ev_stride * 8 > (48ull << 30)) {  // regions beyond 48 GiB of temp
-    direct = false;
-    M.direct = 0;
-  }
+  M.dense_hits = dense ? 1 : 0;
+  M.ev_stride = (uint32_t)stride;
   M.ev_cap = direct ? 0 : ((M1.cap + waves * kV2Slab + kV2Slab) / kV2Slab) * kV2Slab;
   const uint64_t n_slabs = M.ev_cap / kV2Slab + 2;
   const uint64_t n_blk = std::max<uint64_t>((M.n_chunks + 255) / 256, (M.ev_cap + 255) / 256) + 2;
@@ -339,17 +345,9 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
   HIPCHK(ac, hipGetLastError());
   HIPCHK(ac, hipMemcpyAsync(ac->h_v2, ac->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(ac, hipStreamSynchronize(s));
-  if (ac->h_v2[1] == 2) {  // a chunk's event region overflowed (hit-dense input): full-size regions from now on
-    if (ac->direct_div > 1)
-      ac->direct_div = 1;
-    else
-      ac->direct_overflowed = true;
-    return 2;
-  }
+  if (ac->h_v2[1] == 2) return 2;  // a chunk's event region overflowed: the caller repeats with full-size regions
   if (ac->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = ac->h_v2[2];
-  if (!M.sep) ac->sparse_hits = *n_hits < 16ull * M.n_chunks;
-  ac->dense_hits = *n_hits * 4 > N;
   if (prof) {
     aha_timing &t = ac->last;
     memset(&t, 0, sizeof(t));
@@ -372,7 +370,6 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, boo
 // the single-traversal engine (an item list or an event region overflowed: hit-dense input).
 int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   const uint64_t N = M1.n_bytes;
-  if (reinterpret_cast<uintptr_t>(M1.text) % 16 != 0) return 1;
   V2Args M{};
   M.text = M1.text;
   M.doc_off = M1.doc_off;
@@ -767,6 +764,30 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
   return (int64_t)bytes;
 }
 
+int32_t aha_ac_release_scratch(aha_ac *ac) {
+  if (!ac) return AHA_E_INVALID;
+  if (ac->device < 0) return AHA_OK;
+  std::lock_guard<std::mutex> lk(ac->mu);
+  std::lock_guard<std::mutex> lk2(ac->hmu);
+  DeviceGuard g(ac->device);
+  for (auto &b : ac->v2buf) {
+    if (b.p) (void)hipFree(b.p);
+    b = aha_ac::Buf();
+  }
+  for (auto &b : ac->hostbuf) {
+    if (b.p) (void)hipFree(b.p);
+    b = aha_ac::Buf();
+  }
+  void **scratch[] = {(void **)&ac->d_counts, (void **)&ac->d_leads, (void **)&ac->d_blk_hits, (void **)&ac->d_blk_leads,
+                      (void **)&ac->d_docg};
+  for (void **p : scratch) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  ac->cap_chunks = ac->cap_blocks = ac->cap_docs = 0;
+  return AHA_OK;
+}
+
 int32_t aha_ac_set_profiling(aha_ac *ac, int32_t enabled) {
   if (!ac) return AHA_E_INVALID;
   if (ac->device < 0) return AHA_E_NO_DEVICE;
@@ -812,6 +833,13 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
     return AHA_OK;
   }
   if (!d_corpus) return AHA_E_INVALID;
+  if (reinterpret_cast<uintptr_t>(d_corpus) % 16 != 0) {
+    // the kernels read the corpus in aligned 16-byte pieces: an unaligned view (a slice of a larger buffer) is copied
+    // once, device to device, into the handle's scratch (~0.7 ms per GiB: about a fifth of the match itself)
+    if ((rc = v2_reserve(ac, 17, n_bytes + 64))) return rc;
+    HIPCHK(ac, hipMemcpyAsync(ac->v2buf[17].p, d_corpus, n_bytes, hipMemcpyDeviceToDevice, s));
+    d_corpus = (const uint8_t *)ac->v2buf[17].p;
+  }
   M.text = d_corpus;
   M.doc_off = d_doc_offsets;
   M.n_docs = n_docs;
@@ -832,9 +860,9 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
     *n_hits = 0;  // rc == 1: hit-dense or unaligned input -> single-traversal engine
   }
   if (ac->v2_ok) {
-    rc = match_v2(ac, M, s, n_hits, true);
-    if (rc == 2) rc = match_v2(ac, M, s, n_hits, true);   // hit-dense input: regions of one event per byte
-    if (rc == 2) rc = match_v2(ac, M, s, n_hits, false);  // regions unusable: slab pipeline
+    rc = match_v2(ac, M, s, n_hits, kRegions);
+    if (rc == 2) rc = match_v2(ac, M, s, n_hits, kFullRegions);  // denser than cap said: regions of one event per byte
+    if (rc == 2) rc = match_v2(ac, M, s, n_hits, kSlabs);        // (not reached: full-size regions cannot overflow)
     if (rc < 0) return rc;
     if (rc == AHA_OK) {
       if (*n_hits > cap) {

@@ -10,8 +10,16 @@
  * Conventions: extern "C", plain pointers and sizes, no exceptions across the
  * boundary.  Every function returns an int32 status (AHA_OK = 0, <0 error)
  * unless stated.  The caller owns every buffer it passes; the library never
- * retains caller pointers past return.  A handle is immutable after compile;
- * concurrent match calls on one handle are serialised internally.
+ * retains caller pointers past return.  The AUTOMATON of a handle is immutable after compile and which pipeline a
+ * match call takes is a function of that call alone (its size, its params and its `cap`), never of earlier calls.
+ * What a handle does keep between calls is grow-only device scratch (aha_ac_release_scratch frees it); concurrent
+ * match calls on one handle are serialised internally on that scratch.
+ *
+ * Device scratch of one match call on N input bytes with output capacity `cap` hits (single-traversal engine): the
+ * event records, 8 bytes each -- per 4 KiB-class chunk min(chunk bytes, 2 * cap / n_chunks + 64) of them, i.e. about
+ * 16 bytes per hit the caller can take; one event per input byte (8 N bytes, bounded at 48 GiB) only when `cap`
+ * announces more than one hit per 4 input bytes or a chunk overflowed its region; plus ~20 bytes per chunk and
+ * 4 bytes per document.  A device corpus that is not 16-byte aligned is first copied into scratch (N bytes).
  */
 #ifndef AHA_HIP_H
 #define AHA_HIP_H
@@ -205,7 +213,12 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
 int64_t aha_ac_save(const aha_ac *ac, void *buf, uint64_t cap_bytes);
 int32_t aha_ac_load(const void *buf, uint64_t n_bytes, const aha_options *opts, aha_ac **out);
 
-/* Enable/disable HIP-event timing of device matches on this handle. */
+/* Frees the handle's device scratch (it grows with the largest batch seen and is otherwise kept for reuse). */
+int32_t aha_ac_release_scratch(aha_ac *ac);
+
+/* Enable/disable HIP-event timing of device matches on this handle.  aha_timing.engine tells which engine answered the
+ * last call: keys longer than 4096 bytes, a NULL-capacity sizing call and event-temp overflow take the two-pass
+ * engine (1), which is an order of magnitude slower than the single-traversal engine (2). */
 int32_t aha_ac_set_profiling(aha_ac *ac, int32_t enabled);
 int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t);
 

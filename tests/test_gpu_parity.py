@@ -250,6 +250,86 @@ def test_config_parity(cfg, K, nbytes, docb):
         assert gh.tobytes() == oh.tobytes() and np.array_equal(gd, od)
 
 
+def test_config5_at_full_key_count(engine):
+    """BASELINE config 5 at its real automaton size: 1 M keys -> 8-byte wide slots, an image far beyond L2, three
+    nested key families, 3.5 hits per byte.  A fresh handle, so the first call runs the event regions into their
+    overflow and is repeated with full-size regions (capi.cpp match_v2, rc 2); then a sparse call on the same
+    handle.  Hits and per-document offsets against the oracle, byte and char offsets."""
+    if engine != "v2":
+        pytest.skip("once, on the default engine (the two-pass engine runs the same automaton in test_config_parity)")
+    import torch
+
+    blob, offs, nf = synth.keys(5)
+    assert offs.size - 1 == 1_000_000 and nf > 0
+    corpus, doc = synth.corpus(5, blob, offs, nf, n_bytes=1 << 24, doc_bytes=1 << 20)
+    g = AC.compile_packed(blob, offs)
+    info = g.info
+    assert info["slot_bytes"] == 8 and info["image_bytes"] > (100 << 20)
+    g.set_profiling(True)
+    o = orc.AC.compile_packed(blob, offs)
+    dc = torch.from_numpy(corpus).cuda()
+    dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+    dho = torch.zeros(doc.size, dtype=torch.int64, device="cuda")
+    for chars in (False, True):
+        oh, od = o.match_batch(corpus, doc, chars=chars, cap=corpus.size * 4)
+        assert len(oh) > 3 * corpus.size  # hit-dense
+        out = torch.zeros((len(oh) + 16, 3), dtype=torch.int32, device="cuda")
+        n = g.match_batch_device(dc, dd, out, dho, chars=chars)
+        assert n == len(oh)
+        assert out[:n].cpu().numpy().tobytes() == oh.tobytes()
+        assert np.array_equal(dho.cpu().numpy().astype(np.uint64), od)
+        assert g.last_timing()["engine"] == 2
+        del out
+    # a sparse batch on the same handle (the keys' alphabet never occurs)
+    sparse = np.frombuffer(b"0123456789 " * 100_000, dtype=np.uint8)
+    sdoc = np.array([0, 300_000, sparse.size], dtype=np.uint64)
+    gh, gd = g.match_batch(sparse, sdoc)
+    oh, od = o.match_batch(sparse, sdoc)
+    assert gh.tobytes() == oh.tobytes() and np.array_equal(gd, od)
+    # and the dense batch again after it: the handle's pipeline choice must not depend on the call history
+    oh, od = o.match_batch(corpus[: 1 << 21], np.array([0, 1 << 21], dtype=np.uint64), cap=1 << 24)
+    gh, gd = g.match_batch(corpus[: 1 << 21], np.array([0, 1 << 21], dtype=np.uint64))
+    assert gh.tobytes() == oh.tobytes() and np.array_equal(gd, od)
+
+
+def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
+    """A device corpus that is not 16-byte aligned (a slice of a larger buffer) must not fall to the two-pass engine:
+    same hits, same engine, at least 80 % of the aligned rate (one device-to-device copy in front of the match)."""
+    if engine != "v2":
+        pytest.skip("once, on the default engine")
+    import torch
+
+    blob, offs, nf = synth.keys(3)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 28)
+    g = AC.compile_packed(blob, offs)
+    g.set_profiling(True)
+    big = torch.zeros(corpus.size + 64, dtype=torch.uint8, device="cuda")
+    dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+    res = {}
+    for shift in (0, 1):
+        view = big[shift:shift + corpus.size]
+        view.copy_(torch.from_numpy(corpus))
+        assert view.data_ptr() % 16 == shift
+        try:
+            n = g.match_batch_device(view, dd, torch.zeros((1, 3), dtype=torch.int32, device="cuda"))
+        except AhaError as e:
+            n = e.required
+        out = torch.zeros((n + 16, 3), dtype=torch.int32, device="cuda")
+        best = 1e9
+        for _ in range(4):
+            torch.cuda.synchronize()
+            import time
+            t0 = time.perf_counter()
+            assert g.match_batch_device(view, dd, out) == n
+            best = min(best, time.perf_counter() - t0)
+        assert g.last_timing()["engine"] == 2
+        res[shift] = (best, out[:n].cpu().numpy().tobytes())
+    assert res[0][1] == res[1][1]
+    assert res[0][0] / res[1][0] >= 0.8, (res[0][0], res[1][0])
+    g.release_scratch()
+    assert g.match_batch_device(big[1:1 + corpus.size], dd, out) == n  # scratch grows back
+
+
 def test_engine_selected(engine):
     ac = AC.compile(["ab", "b"])  # a 1-byte key: outside the position-parallel engine's preconditions
     ac.set_profiling(True)

@@ -57,6 +57,12 @@ class aha_timing(C.Structure):
                 ("chunk_bytes", C.c_uint32)]
 
 
+class aha_group_timing(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_devices", C.c_uint32), ("ms_match", C.c_float),
+                ("ms_match_max_shard", C.c_float), ("ms_exchange", C.c_float), ("ms_download", C.c_float),
+                ("n_hits", C.c_uint64), ("exchange", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 # every symbol include/aha_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
 SIGNATURES = {
@@ -80,6 +86,14 @@ SIGNATURES = {
     "aha_ac_save": (C.c_int64, [_vp, _vp, _u64]),
     "aha_ac_load": (_i32, [_vp, _u64, C.POINTER(aha_options), C.POINTER(_vp)]),
     "aha_ac_release_scratch": (_i32, [_vp]),
+    "aha_group_compile": (_i32, [_vp, _vp, _u32, _vp, _i32, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
+    "aha_group_free": (None, [_vp]),
+    "aha_group_size": (_i32, [_vp]),
+    "aha_group_last_error": (C.c_char_p, [_vp]),
+    "aha_group_partition": (_i32, [_vp, _u64, _i32, _vp]),
+    "aha_group_match_batch": (_i32, [_vp, _vp, _vp, _u64, C.POINTER(aha_match_params), _vp, _u64, _vp,
+                                     C.POINTER(_u64)]),
+    "aha_group_last_timing": (_i32, [_vp, C.POINTER(aha_group_timing)]),
     "aha_ac_set_profiling": (_i32, [_vp, _i32]),
     "aha_ac_last_timing": (_i32, [_vp, C.POINTER(aha_timing)]),
 }

@@ -199,6 +199,8 @@ class AC:
     def match_array(self, seq, sep=None, chars=None):
         """All hits of one sequence as a HIT_DTYPE array (reference order)."""
         if isinstance(seq, (list, tuple)) and (not seq or isinstance(seq[0], str)):
+            if sep is not None:
+                return self._match_chars_sep(list(seq), sep)
             # Array(Char) overload (ac.cr:288-295): chars re-encode to UTF-8
             seq = "".join(seq)
         if chars is None:
@@ -215,6 +217,36 @@ class AC:
                 continue
             self._check(rc)
             return out[: n.value]
+
+    def _match_chars_sep(self, chars, sep):
+        """match(seq : Array(Char) | Slice(Char), sep) -- src/aha/ac.cr:342-364.  Unlike the String overload
+        (matcher.cr:41-46, byte-level neighbours) this one tests the neighbouring CODE POINT: a hit is dropped when
+        `chr.ord < sep.size && !sep[chr.ord]`, so a neighbour whose code point is >= sep.size never blocks.  The GPU
+        yields the unfiltered byte-offset hits; the two neighbour tests and the char offsets are applied here."""
+        if sep.size > 256:
+            raise AhaError(N.AHA_E_SEP_SIZE, "sep BitArray size > 256 is not supported")
+        enc = [c.encode("utf-8") for c in chars]
+        t = b"".join(enc)
+        hits = self.match_array(t, None, False)
+        if not len(hits):
+            return hits
+        cps = np.array([ord(c) for c in chars], dtype=np.int64)
+        blens = np.array([len(e) for e in enc], dtype=np.int64)
+        char_of_byte = np.repeat(np.arange(len(chars), dtype=np.int64), blens)
+        ok_cp = np.array([not (i < sep.size and not sep[i]) for i in range(256)], dtype=bool)  # blocked(c) for c < 256
+        blocked = (cps < 256) & ~ok_cp[np.minimum(cps, 255)]
+        nchars = len(chars)
+        end_chr = char_of_byte[hits["end"].astype(np.int64) - 1]      # char that holds the last byte (ac.cr:346)
+        right = end_chr + 1
+        keep = ~((right < nchars) & blocked[np.minimum(right, nchars - 1)])
+        start_chr = char_of_byte[hits["start"].astype(np.int64)]
+        has_left = hits["start"] > 0                                    # ac.cr:354
+        keep &= ~(has_left & blocked[np.maximum(start_chr - 1, 0)])
+        out = np.zeros(int(keep.sum()), dtype=HIT_DTYPE)
+        out["start"] = start_chr[keep]
+        out["end"] = end_chr[keep] + 1
+        out["value"] = hits["value"][keep]
+        return out
 
     def match(self, seq, sep=None, chars=None):
         """Yields Aha::Hit like the reference's block form (ac.cr:280-286)."""
@@ -316,4 +348,76 @@ class AC:
     def last_timing(self):
         t = N.aha_timing()
         self._check(N.lib().aha_ac_last_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in t._fields_ if f != "struct_size"}
+
+
+class ACGroup:
+    """Several GPUs of one node behind one object (aha_group_*, include/aha_hip.h): contiguous byte-balanced
+    document ranges, one per device entry, all-gatherv of the hit buffers (RCCL between distinct devices)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                N.lib().aha_group_free(h)
+            except Exception:  # interpreter shutdown
+                pass
+
+    @classmethod
+    def compile(cls, keys, devices, host_only=False):
+        blob, offs = _pack_keys(keys)
+        return cls.compile_packed(blob, offs, devices, host_only)
+
+    @classmethod
+    def compile_packed(cls, blob, offs, devices, host_only=False):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        ek = C.c_uint32(0)
+        rc = N.lib().aha_group_compile(_ptr(blob), _ptr(offs), offs.size - 1, _ptr(dev), dev.size,
+                                       N.AHA_OPT_HOST_ONLY if host_only else 0, C.byref(h), C.byref(ek))
+        if rc != N.AHA_OK:
+            raise AhaError(rc, key_index=ek.value)
+        return cls(h)
+
+    @staticmethod
+    def partition(doc_offsets, n_parts):
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        bounds = np.zeros(n_parts + 1, dtype=np.uint64)
+        rc = N.lib().aha_group_partition(_ptr(doc_offsets), doc_offsets.size - 1, n_parts, _ptr(bounds))
+        if rc != N.AHA_OK:
+            raise AhaError(rc)
+        return bounds
+
+    def match_batch(self, corpus, doc_offsets, chars=False, cap=None):
+        if isinstance(corpus, (bytes, bytearray)):
+            corpus = np.frombuffer(bytes(corpus), dtype=np.uint8)
+        corpus = np.ascontiguousarray(corpus, dtype=np.uint8)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        D = doc_offsets.size - 1
+        p = _params(chars, None)
+        dho = np.zeros(D + 1, dtype=np.uint64)
+        if cap is None:
+            cap = max(64, corpus.size // 8)
+        while True:
+            out = np.zeros(cap, dtype=HIT_DTYPE)
+            n = C.c_uint64(0)
+            rc = N.lib().aha_group_match_batch(self._h, _ptr(corpus), _ptr(doc_offsets), D, C.byref(p), _ptr(out), cap,
+                                               _ptr(dho), C.byref(n))
+            if rc == N.AHA_E_CAPACITY:
+                cap = int(n.value)
+                continue
+            if rc != N.AHA_OK:
+                raise AhaError(rc, N.lib().aha_group_last_error(self._h).decode() or None)
+            return out[: n.value], dho
+
+    def last_timing(self):
+        t = N.aha_group_timing()
+        rc = N.lib().aha_group_last_timing(self._h, C.byref(t))
+        if rc != N.AHA_OK:
+            raise AhaError(rc)
         return {f: getattr(t, f) for f, _ in t._fields_ if f != "struct_size"}

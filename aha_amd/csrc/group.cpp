@@ -1,0 +1,355 @@
+// group.cpp -- aha_group_*: one batch over several GPUs of one node, behind the C ABI (include/aha_hip.h).
+//
+// SURVEY.md section 8 e: documents are independent (src/aha/ac.cr:177, the state is per sequence), so the batch is
+// cut into contiguous, byte-balanced document ranges, one per device (global hit order = range order: no merge);
+// the automaton is replicated; every device matches its range with the single-device path; the hit buffers are
+// exchanged with an all-gatherv so that every device ends up with the whole ordered hit stream.  Between distinct
+// devices the exchange is RCCL (ncclGroupStart / all-pairs ncclSend + ncclRecv / ncclGroupEnd: every device drives
+// its xGMI links at once -- a ring would be bound by one link); RCCL is loaded with dlopen on first use so that
+// single-GPU users do not pay for it.  Entries of the device list that name the SAME device (several shards on one
+// GPU, each with its own handle and stream) exchange with device-to-device copies instead: that is the form the
+// 1-GPU development box can execute.
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/aha_hip.h"
+
+namespace {
+
+// the few RCCL entry points used (rccl.h declares them; resolved at run time)
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+constexpr int kNcclInt32 = 2;  // ncclDataType_t::ncclInt32
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  bool load(std::string &err) {
+    if (lib) return true;
+    lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+      err = std::string("librccl.so: ") + dlerror();
+      return false;
+    }
+#define AHA_SYM(field, name)                                  \
+  field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); \
+  if (!field) {                                               \
+    err = std::string("librccl.so lacks ") + name;            \
+    return false;                                             \
+  }
+    AHA_SYM(CommInitAll, "ncclCommInitAll")
+    AHA_SYM(CommDestroy, "ncclCommDestroy")
+    AHA_SYM(GroupStart, "ncclGroupStart")
+    AHA_SYM(GroupEnd, "ncclGroupEnd")
+    AHA_SYM(Send, "ncclSend")
+    AHA_SYM(Recv, "ncclRecv")
+#undef AHA_SYM
+    return true;
+  }
+};
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  bool reserve(size_t n) {
+    if (bytes >= n) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    const size_t want = n + n / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) return false;
+    bytes = want;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+struct Shard {
+  aha_ac *ac = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevBuf corpus, doc, dho, out, all;
+  // per call
+  uint64_t d0 = 0, d1 = 0, n_hits = 0;
+  std::vector<uint64_t> h_dho;
+  int32_t rc = AHA_OK;
+  double ms_match = 0;
+};
+
+double ms_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+struct aha_group {
+  std::vector<Shard> shards;
+  bool distinct = true;  // no device named twice: the exchange is RCCL
+  Rccl rccl;
+  std::vector<ncclComm_t> comms;
+  aha_group_timing last{};
+  std::string err;
+};
+
+extern "C" {
+
+int32_t aha_group_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, uint32_t n_keys, const int32_t *devices,
+                          int32_t n_devices, uint32_t flags, aha_group **out, uint32_t *err_key) {
+  if (!out || !devices || n_devices <= 0 || n_devices > 64) return AHA_E_INVALID;
+  *out = nullptr;
+  aha_group *g = new aha_group();
+  g->shards.resize((size_t)n_devices);
+  for (int32_t r = 0; r < n_devices; r++) {
+    for (int32_t q = 0; q < r; q++)
+      if (devices[q] == devices[r]) g->distinct = false;
+    aha_options o{};
+    o.struct_size = sizeof(o);
+    o.device = devices[r];
+    o.flags = flags;
+    Shard &s = g->shards[(size_t)r];
+    s.device = devices[r];
+    int32_t rc = aha_ac_compile(key_bytes, key_offsets, n_keys, &o, &s.ac, err_key);  // the automaton is replicated
+    if (rc != AHA_OK) {
+      aha_group_free(g);
+      return rc;
+    }
+    if (!(flags & AHA_OPT_HOST_ONLY)) {
+      if (hipSetDevice(devices[r]) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
+        aha_group_free(g);
+        return AHA_E_HIP;
+      }
+    }
+  }
+  *out = g;
+  return AHA_OK;
+}
+
+void aha_group_free(aha_group *g) {
+  if (!g) return;
+  for (ncclComm_t c : g->comms)
+    if (c && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(c);
+  for (Shard &s : g->shards) {
+    if (s.stream || s.corpus.p || s.out.p || s.all.p) (void)hipSetDevice(s.device);
+    s.corpus.release();
+    s.doc.release();
+    s.dho.release();
+    s.out.release();
+    s.all.release();
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.ac) aha_ac_free(s.ac);
+  }
+  delete g;
+}
+
+int32_t aha_group_size(const aha_group *g) { return g ? (int32_t)g->shards.size() : AHA_E_INVALID; }
+const char *aha_group_last_error(const aha_group *g) { return g ? g->err.c_str() : ""; }
+
+int32_t aha_group_partition(const uint64_t *doc_offsets, uint64_t n_docs, int32_t n_parts, uint64_t *bounds) {
+  // contiguous document ranges balanced by bytes: bounds[r] = the document boundary nearest to r * N / n_parts
+  if (!doc_offsets || !bounds || n_parts <= 0) return AHA_E_INVALID;
+  const uint64_t N = doc_offsets[n_docs];
+  bounds[0] = 0;
+  for (int32_t r = 1; r < n_parts; r++) {
+    const uint64_t target = (uint64_t)(((__uint128_t)N * (uint64_t)r) / (uint64_t)n_parts);
+    const uint64_t *lo = std::lower_bound(doc_offsets, doc_offsets + n_docs + 1, target);
+    uint64_t d = (uint64_t)(lo - doc_offsets);
+    if (d > 0 && (d > n_docs || target - doc_offsets[d - 1] < doc_offsets[d] - target)) d--;
+    bounds[r] = std::min(std::max(d, bounds[r - 1]), n_docs);
+  }
+  bounds[n_parts] = n_docs;
+  return AHA_OK;
+}
+
+int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                              const aha_match_params *params, aha_hit *out, uint64_t cap, uint64_t *doc_hit_offsets,
+                              uint64_t *n_hits) {
+  if (!g || !doc_offsets || !n_hits) return AHA_E_INVALID;
+  if (doc_offsets[0] != 0) return AHA_E_INVALID;
+  for (uint64_t d = 0; d < n_docs; d++) {
+    if (doc_offsets[d + 1] < doc_offsets[d]) return AHA_E_INVALID;
+    if (doc_offsets[d + 1] - doc_offsets[d] >= 0x7FFFFFFFull) return AHA_E_TOO_LONG;
+  }
+  const uint64_t N = doc_offsets[n_docs];
+  if ((N && !corpus) || (cap && !out)) return AHA_E_INVALID;
+  const size_t n = g->shards.size();
+  *n_hits = 0;
+  std::vector<uint64_t> bounds(n + 1);
+  (void)aha_group_partition(doc_offsets, n_docs, (int32_t)n, bounds.data());
+  aha_group_timing &T = g->last;
+  memset(&T, 0, sizeof(T));
+  T.struct_size = sizeof(T);
+  T.n_devices = (uint32_t)n;
+
+  // ---- every shard: upload its range, match on its device (one host thread per shard: the calls block)
+  const auto t_all = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (size_t r = 0; r < n; r++) {
+    Shard &s = g->shards[r];
+    s.d0 = bounds[r];
+    s.d1 = bounds[r + 1];
+    th.emplace_back([&, r]() {
+      Shard &s = g->shards[r];
+      s.rc = AHA_OK;
+      s.n_hits = 0;
+      const uint64_t D = s.d1 - s.d0, b0 = doc_offsets[s.d0], nb = doc_offsets[s.d1] - b0;
+      s.h_dho.assign(D + 1, 0);
+      if (hipSetDevice(s.device) != hipSuccess) {
+        s.rc = AHA_E_HIP;
+        return;
+      }
+      std::vector<uint64_t> rel(D + 1);
+      for (uint64_t d = 0; d <= D; d++) rel[d] = doc_offsets[s.d0 + d] - b0;
+      uint64_t want = std::max<uint64_t>(1024, N ? (uint64_t)((__uint128_t)cap * nb / N) * 3 / 2 + 1024 : 1024);
+      if (!s.corpus.reserve(nb + 64) || !s.doc.reserve((D + 1) * 8) || !s.dho.reserve((D + 1) * 8) ||
+          !s.out.reserve(want * sizeof(aha_hit))) {
+        s.rc = AHA_E_HIP;
+        return;
+      }
+      if ((nb && hipMemcpyAsync(s.corpus.p, corpus + b0, nb, hipMemcpyHostToDevice, s.stream) != hipSuccess) ||
+          hipMemcpyAsync(s.doc.p, rel.data(), (D + 1) * 8, hipMemcpyHostToDevice, s.stream) != hipSuccess ||
+          hipStreamSynchronize(s.stream) != hipSuccess) {
+        s.rc = AHA_E_HIP;
+        return;
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int attempt = 0; attempt < 2; attempt++) {
+        uint64_t nh = 0;
+        s.rc = aha_ac_match_batch_device(s.ac, (const uint8_t *)s.corpus.p, (const uint64_t *)s.doc.p, D, nb, params,
+                                         (aha_hit *)s.out.p, s.out.bytes / sizeof(aha_hit), (uint64_t *)s.dho.p, &nh,
+                                         s.stream);
+        s.n_hits = nh;
+        if (s.rc != AHA_E_CAPACITY) break;
+        if (!s.out.reserve(nh * sizeof(aha_hit))) {  // the call told the exact count: once more with room
+          s.rc = AHA_E_HIP;
+          return;
+        }
+      }
+      s.ms_match = ms_since(t0);
+      if (s.rc != AHA_OK) return;
+      if (hipMemcpy(s.h_dho.data(), s.dho.p, (D + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) s.rc = AHA_E_HIP;
+    });
+  }
+  for (auto &t : th) t.join();
+  T.ms_match = (float)ms_since(t_all);
+  uint64_t total = 0;
+  std::vector<uint64_t> base(n + 1, 0);
+  for (size_t r = 0; r < n; r++) {
+    Shard &s = g->shards[r];
+    if (s.rc != AHA_OK) {
+      g->err = std::string("shard ") + std::to_string(r) + ": " + aha_last_error(s.ac);
+      return s.rc;
+    }
+    T.ms_match_max_shard = std::max(T.ms_match_max_shard, (float)s.ms_match);
+    base[r] = total;
+    total += s.n_hits;
+  }
+  base[n] = total;
+  *n_hits = total;
+  if (doc_hit_offsets) {
+    for (size_t r = 0; r < n; r++) {
+      const Shard &s = g->shards[r];
+      for (uint64_t d = s.d0; d < s.d1; d++) doc_hit_offsets[d] = base[r] + s.h_dho[d - s.d0];
+    }
+    doc_hit_offsets[n_docs] = total;
+  }
+
+  // ---- all-gatherv of the hit buffers: every device gets the whole ordered stream
+  const auto t_x = std::chrono::steady_clock::now();
+  for (size_t r = 0; r < n; r++) {
+    Shard &s = g->shards[r];
+    if (hipSetDevice(s.device) != hipSuccess || !s.all.reserve(std::max<uint64_t>(total, 1) * sizeof(aha_hit))) {
+      g->err = "hipMalloc failed for the gathered hits";
+      return AHA_E_HIP;
+    }
+  }
+  if (g->distinct && n > 1) {
+    if (g->comms.empty()) {
+      if (!g->rccl.load(g->err)) return AHA_E_HIP;
+      std::vector<int> devs;
+      for (const Shard &s : g->shards) devs.push_back(s.device);
+      g->comms.assign(n, nullptr);
+      if (g->rccl.CommInitAll(g->comms.data(), (int)n, devs.data()) != 0) {
+        g->comms.clear();
+        g->err = "ncclCommInitAll failed";
+        return AHA_E_HIP;
+      }
+    }
+    bool ok = g->rccl.GroupStart() == 0;
+    for (size_t r = 0; r < n && ok; r++) {
+      Shard &s = g->shards[r];
+      aha_hit *all = (aha_hit *)s.all.p;
+      for (size_t p = 0; p < n && ok; p++) {
+        if (p == r) continue;
+        if (s.n_hits) ok = ok && g->rccl.Send(s.out.p, s.n_hits * 3, kNcclInt32, (int)p, g->comms[r], s.stream) == 0;
+        if (g->shards[p].n_hits)
+          ok = ok && g->rccl.Recv(all + base[p], g->shards[p].n_hits * 3, kNcclInt32, (int)p, g->comms[r], s.stream) == 0;
+      }
+    }
+    ok = (g->rccl.GroupEnd() == 0) && ok;
+    if (!ok) {
+      g->err = "RCCL send/recv failed";
+      return AHA_E_HIP;
+    }
+    for (size_t r = 0; r < n; r++) {  // the own part
+      Shard &s = g->shards[r];
+      if (s.n_hits && (hipSetDevice(s.device) != hipSuccess ||
+                       hipMemcpyAsync((aha_hit *)s.all.p + base[r], s.out.p, s.n_hits * sizeof(aha_hit),
+                                      hipMemcpyDeviceToDevice, s.stream) != hipSuccess))
+        return AHA_E_HIP;
+    }
+  } else {
+    for (size_t r = 0; r < n; r++) {
+      Shard &s = g->shards[r];
+      if (hipSetDevice(s.device) != hipSuccess) return AHA_E_HIP;
+      for (size_t p = 0; p < n; p++) {
+        const Shard &q = g->shards[p];
+        if (q.n_hits && hipMemcpyAsync((aha_hit *)s.all.p + base[p], q.out.p, q.n_hits * sizeof(aha_hit),
+                                       hipMemcpyDeviceToDevice, s.stream) != hipSuccess)
+          return AHA_E_HIP;
+      }
+    }
+  }
+  for (size_t r = 0; r < n; r++) {
+    Shard &s = g->shards[r];
+    if (hipSetDevice(s.device) != hipSuccess || hipStreamSynchronize(s.stream) != hipSuccess) {
+      g->err = "exchange failed";
+      return AHA_E_HIP;
+    }
+  }
+  T.ms_exchange = (float)ms_since(t_x);
+  T.n_hits = total;
+  T.exchange = (g->distinct && n > 1) ? 1u : 0u;
+  if (total > cap) return AHA_E_CAPACITY;
+  const auto t_d = std::chrono::steady_clock::now();
+  Shard &s0 = g->shards[0];
+  if (total && (hipSetDevice(s0.device) != hipSuccess ||
+                hipMemcpy(out, s0.all.p, total * sizeof(aha_hit), hipMemcpyDeviceToHost) != hipSuccess))
+    return AHA_E_HIP;
+  T.ms_download = (float)ms_since(t_d);
+  return AHA_OK;
+}
+
+int32_t aha_group_last_timing(const aha_group *g, aha_group_timing *t) {
+  if (!g || !t) return AHA_E_INVALID;
+  *t = g->last;
+  t->struct_size = sizeof(*t);
+  return AHA_OK;
+}
+
+}  // extern "C"

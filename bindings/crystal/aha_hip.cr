@@ -7,8 +7,18 @@
 #   AC#match(seq : String, &block)   (src/aha/matcher.cr:34-39)
 #   AC#match(seq, sep : BitArray)    (src/aha/ac.cr:321-340, matcher.cr:41-46)
 #   AC#match(seq : Array(Char))      (src/aha/ac.cr:288-295)
+#   AC#match(Array(Char), sep)       (src/aha/ac.cr:342-364: the neighbour tests look at code points)
 #   AC#[](Int) / AC#[](String)       (src/aha/ac.cr:41-43)
 #   Aha::Hit                         (src/aha/matcher.cr:2-11, unchanged)
+# plus the batch surface the reference does not have (one sequence per call there):
+#   AC#match_batch(docs)             -> Array(Array(Aha::Hit)), one GPU round trip for all documents
+#   Aha::ACGroup                     the same over several GPUs of one node (aha_group_*)
+#
+# AC.compile(da : Cedar) (src/aha/ac.cr:71) is provided for tries built by `insert` only: the keys are read back in
+# id order (Cedar#[](id), cedar.cr:747-749) and compiled by the library; ids freed by Cedar#delete are rejected,
+# because the library numbers keys densely (Hit#value = index in compile order).
+#
+# Written for the Crystal the reference pins (shard.yml: 0.23.1): integer division is `/`.
 #
 # UNVERIFIED: no Crystal toolchain exists in the build container or on the GPU
 # box, so this file has never been compiled.  The same .so is exercised
@@ -55,6 +65,15 @@ lib LibAhaHip
   fun aha_ac_match_batch(ac : Ac, corpus : UInt8*, doc_offsets : UInt64*, n_docs : UInt64,
                          params : MatchParams*, out : Hit*, cap : UInt64,
                          doc_hit_offsets : UInt64*, n_hits : UInt64*) : Int32
+
+  type Group = Void*
+  fun aha_group_compile(key_bytes : UInt8*, key_offsets : UInt64*, n_keys : UInt32,
+                        devices : Int32*, n_devices : Int32, flags : UInt32,
+                        out : Group*, err_key : UInt32*) : Int32
+  fun aha_group_free(g : Group) : Void
+  fun aha_group_match_batch(g : Group, corpus : UInt8*, doc_offsets : UInt64*, n_docs : UInt64,
+                            params : MatchParams*, out : Hit*, cap : UInt64,
+                            doc_hit_offsets : UInt64*, n_hits : UInt64*) : Int32
 end
 
 module Aha
@@ -70,14 +89,7 @@ module Aha
     end
 
     def self.compile(keys : Array(String) | Array(Array(UInt8)) | Array(Bytes)) : self
-      blob = IO::Memory.new
-      offs = Array(UInt64).new(keys.size + 1)
-      offs << 0_u64
-      keys.each do |k|
-        bytes = k.is_a?(String) ? k.to_slice : (k.is_a?(Bytes) ? k : Slice.new(k.to_unsafe, k.size))
-        blob.write bytes
-        offs << blob.pos.to_u64
-      end
+      blob, offs = pack_keys(keys)
       opts = LibAhaHip::Options.new
       opts.struct_size = sizeof(LibAhaHip::Options).to_u32
       opts.device = -1
@@ -91,7 +103,28 @@ module Aha
       new(handle)
     end
 
-    private def run(seq : Bytes, chars : Bool, sep : BitArray?, &block)
+    # ACX.compile(da : Cedar) src/aha/ac.cr:71 -- see the header for the restriction
+    def self.compile(da : Cedar) : self
+      keys = Array(String).new
+      (0...da.size).each do |id|
+        keys << da[id]  # raises for an id freed by Cedar#delete
+      end
+      compile(keys)
+    end
+
+    protected def self.pack_keys(keys)
+      blob = IO::Memory.new
+      offs = Array(UInt64).new(keys.size + 1)
+      offs << 0_u64
+      keys.each do |k|
+        bytes = k.is_a?(String) ? k.to_slice : (k.is_a?(Bytes) ? k : Slice.new(k.to_unsafe, k.size))
+        blob.write bytes
+        offs << blob.pos.to_u64
+      end
+      {blob, offs}
+    end
+
+    protected def self.params(chars : Bool, sep : BitArray?) : LibAhaHip::MatchParams
       params = LibAhaHip::MatchParams.new
       params.struct_size = sizeof(LibAhaHip::MatchParams).to_u32
       params.char_offsets = chars ? 1 : 0
@@ -102,7 +135,45 @@ module Aha
         sep.each_with_index { |b, i| bits[i >> 3] |= (1_u8 << (i & 7)) if b }
         params.sep_bits = bits
       end
-      cap = (seq.size // 4 + 64).to_u64
+      params
+    end
+
+    # New: all documents in one call (the reference is one sequence per call).  Returns the hits of every document
+    # in the reference's order; `chars` selects the String overload's char offsets.
+    def match_batch(docs : Array(String) | Array(Bytes), chars : Bool = false, sep : BitArray? = nil) : Array(Array(Hit))
+      corpus = IO::Memory.new
+      offs = Array(UInt64).new(docs.size + 1)
+      offs << 0_u64
+      docs.each do |d|
+        corpus.write(d.is_a?(String) ? d.to_slice : d)
+        offs << corpus.pos.to_u64
+      end
+      params = AC.params(chars, sep)
+      dho = Array(UInt64).new(docs.size + 1, 0_u64)
+      cap = (corpus.pos / 4 + 64).to_u64
+      result = Array(Array(Hit)).new(docs.size)
+      loop do
+        out_buf = Pointer(LibAhaHip::Hit).malloc(cap)
+        rc = LibAhaHip.aha_ac_match_batch(@handle, corpus.to_slice.to_unsafe, offs.to_unsafe, docs.size.to_u64,
+          pointerof(params), out_buf, cap, dho.to_unsafe, out n)
+        if rc == E_CAPACITY
+          cap = n
+          next
+        end
+        raise String.new(LibAhaHip.aha_last_error(@handle)) if rc != 0
+        docs.size.times do |d|
+          hits = Array(Hit).new((dho[d + 1] - dho[d]).to_i32)
+          (dho[d]...dho[d + 1]).each { |i| hits << Hit.new(out_buf[i].start, out_buf[i].end_, out_buf[i].value) }
+          result << hits
+        end
+        break
+      end
+      result
+    end
+
+    private def run(seq : Bytes, chars : Bool, sep : BitArray?, &block)
+      params = AC.params(chars, sep)
+      cap = (seq.size / 4 + 64).to_u64
       loop do
         out_buf = Pointer(LibAhaHip::Hit).malloc(cap)
         rc = LibAhaHip.aha_ac_match_bytes(@handle, seq.to_unsafe, seq.size.to_u64, pointerof(params),
@@ -139,6 +210,27 @@ module Aha
       run(seq.to_slice, true, sep) { |hit| yield hit }
     end
 
+    # src/aha/ac.cr:342-364: unlike the String overload the neighbour tests look at the neighbouring CHAR's code
+    # point (`chr.ord < sep.size && !sep[chr.ord]`), so they are applied here to the unfiltered byte hits.
+    def match(seq : Array(Char) | Slice(Char), sep : BitArray, &block)
+      raise "sep BitArray size > 256 is not supported" if sep.size > 256
+      str = String.build { |s| seq.each { |c| s << c } }
+      char_of_byte = Array(Int32).new(str.bytesize)
+      seq.each_with_index { |c, i| c.bytesize.times { char_of_byte << i } }
+      run(str.to_slice, false, nil) do |hit|
+        chr_idx = char_of_byte[hit.end - 1]
+        if chr_idx + 1 < seq.size
+          chr = seq[chr_idx + 1]
+          next if chr.ord < sep.size && !sep[chr.ord]
+        end
+        if hit.start > 0
+          chr = seq[char_of_byte[hit.start] - 1]
+          next if chr.ord < sep.size && !sep[chr.ord]
+        end
+        yield Hit.new(char_of_byte[hit.start], char_of_byte[hit.end - 1] + 1, hit.value)
+      end
+    end
+
     # AC#to_io / AC.from_io (src/aha/ac.cr:45-60) on the library's own container
     def to_io(io : IO, format : IO::ByteFormat = IO::ByteFormat::LittleEndian)
       n = LibAhaHip.aha_ac_save(@handle, Pointer(Void).null, 0_u64)
@@ -167,6 +259,61 @@ module Aha
       r = LibAhaHip.aha_ac_id(@handle, key.to_unsafe, key.bytesize)
       raise IndexError.new if r < 0
       r
+    end
+  end
+
+  # Several GPUs of one node behind one object: the batch is cut into contiguous, byte-balanced document ranges (one
+  # per device), every device matches its range, the hit buffers are exchanged with an all-gatherv (RCCL over xGMI
+  # between distinct devices) and come back in document order -- the same hits as AC#match_batch.
+  class ACGroup
+    def initialize(@group : LibAhaHip::Group)
+    end
+
+    def finalize
+      LibAhaHip.aha_group_free(@group)
+    end
+
+    def self.compile(keys : Array(String) | Array(Bytes), devices : Array(Int32)) : self
+      blob, offs = AC.pack_keys(keys)
+      rc = LibAhaHip.aha_group_compile(blob.to_slice.to_unsafe, offs.to_unsafe, keys.size.to_u32,
+        devices.to_unsafe, devices.size, 0_u32, out group, out bad)
+      if rc == AC::E_DUP_KEY
+        raise "key:#{keys[bad]} appear twice."
+      elsif rc != 0
+        raise String.new(LibAhaHip.aha_strerror(rc))
+      end
+      new(group)
+    end
+
+    def match_batch(docs : Array(String) | Array(Bytes), chars : Bool = false) : Array(Array(Hit))
+      corpus = IO::Memory.new
+      offs = Array(UInt64).new(docs.size + 1)
+      offs << 0_u64
+      docs.each do |d|
+        corpus.write(d.is_a?(String) ? d.to_slice : d)
+        offs << corpus.pos.to_u64
+      end
+      params = AC.params(chars, nil)
+      dho = Array(UInt64).new(docs.size + 1, 0_u64)
+      cap = (corpus.pos / 4 + 64).to_u64
+      result = Array(Array(Hit)).new(docs.size)
+      loop do
+        out_buf = Pointer(LibAhaHip::Hit).malloc(cap)
+        rc = LibAhaHip.aha_group_match_batch(@group, corpus.to_slice.to_unsafe, offs.to_unsafe, docs.size.to_u64,
+          pointerof(params), out_buf, cap, dho.to_unsafe, out n)
+        if rc == AC::E_CAPACITY
+          cap = n
+          next
+        end
+        raise String.new(LibAhaHip.aha_strerror(rc)) if rc != 0
+        docs.size.times do |d|
+          hits = Array(Hit).new((dho[d + 1] - dho[d]).to_i32)
+          (dho[d]...dho[d + 1]).each { |i| hits << Hit.new(out_buf[i].start, out_buf[i].end_, out_buf[i].value) }
+          result << hits
+        end
+        break
+      end
+      result
     end
   end
 end

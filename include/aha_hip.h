@@ -222,6 +222,42 @@ int32_t aha_ac_release_scratch(aha_ac *ac);
 int32_t aha_ac_set_profiling(aha_ac *ac, int32_t enabled);
 int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t);
 
+/* ---- several GPUs of one node behind one handle (SURVEY.md section 8 b / e) -------------------------------------
+ * The batch is cut into contiguous, byte-balanced document ranges, one per entry of `devices` (documents are
+ * independent: src/aha/ac.cr:177; contiguous ranges make the global hit order the range order); the automaton is
+ * replicated; every device matches its range; the hit buffers are exchanged with an all-gatherv, so every device
+ * holds the whole ordered hit stream, and come back to the caller exactly as aha_ac_match_batch would return them.
+ * Between distinct devices the exchange is RCCL over xGMI (all-pairs ncclSend/ncclRecv in one group; librccl.so is
+ * loaded on first use); entries that name the same device twice -- several shards on one GPU, the form a 1-GPU box
+ * can run -- exchange with device-to-device copies.  Buffers are host memory; the calls block. */
+typedef struct aha_group aha_group;
+
+typedef struct {
+  uint32_t struct_size;
+  uint32_t n_devices;
+  float ms_match;            /* upload + match of all shards, wall clock (shards run concurrently) */
+  float ms_match_max_shard;  /* the slowest shard's device match alone */
+  float ms_exchange;         /* the all-gatherv of the hit buffers */
+  float ms_download;         /* gathered hits -> caller's buffer */
+  uint64_t n_hits;
+  uint32_t exchange;         /* 1 = RCCL between distinct devices, 0 = device-to-device copies on one device */
+  uint32_t reserved;
+} aha_group_timing;
+
+int32_t aha_group_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, uint32_t n_keys,
+                          const int32_t *devices, int32_t n_devices, uint32_t flags, aha_group **out,
+                          uint32_t *err_key);
+void aha_group_free(aha_group *g);
+int32_t aha_group_size(const aha_group *g);
+const char *aha_group_last_error(const aha_group *g);
+/* bounds[0..n_parts]: shard r holds documents bounds[r] .. bounds[r+1]-1 (the boundary nearest to r * N / n_parts). */
+int32_t aha_group_partition(const uint64_t *doc_offsets, uint64_t n_docs, int32_t n_parts, uint64_t *bounds);
+/* Same contract as aha_ac_match_batch (AHA_E_CAPACITY: *n_hits = required count, offsets valid). */
+int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                              const aha_match_params *params, aha_hit *out, uint64_t cap,
+                              uint64_t *doc_hit_offsets, uint64_t *n_hits);
+int32_t aha_group_last_timing(const aha_group *g, aha_group_timing *t);
+
 #ifdef __cplusplus
 }
 #endif

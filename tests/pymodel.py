@@ -108,6 +108,41 @@ class ModelAC:
             out = [(cmap[a], cmap[e - 1] + 1, v) for (a, e, v) in out]
         return out
 
+    def match_chars_sep(self, chars, sep):
+        """match(seq : Array(Char) | Slice(Char), sep) restated from src/aha/ac.cr:342-364: the neighbour tests look
+        at the neighbouring CHAR's code point (`chr.ord < sep.size && !sep[chr.ord]`), not at a byte.
+        sep = (size, set_bits).  Returns char-offset hits."""
+        size, bits = sep
+        bits = set(bits)
+
+        def blocked(cp):
+            return cp < size and cp not in bits
+
+        enc = [c.encode("utf-8") for c in chars]
+        t = b"".join(enc)
+        cmap = []
+        for ci, e in enumerate(enc):
+            cmap += [ci] * len(e)
+        out = []
+        s = 0
+        for i, b in enumerate(t):
+            s = self._step(s, b)
+            if self.key_of[s] < 0:
+                continue
+            chr_idx = cmap[i]
+            if chr_idx + 1 < len(chars) and blocked(ord(chars[chr_idx + 1])):
+                continue
+            u = s
+            while True:
+                k = self.key_of[u]
+                st = i + 1 - len(self.keys[k])
+                if not (st > 0 and blocked(ord(chars[cmap[st] - 1]))):
+                    out.append((cmap[st], cmap[i] + 1, k))
+                u = self.fail[u]
+                if self.key_of[u] < 0:
+                    break
+        return out
+
     def textbook(self, text):
         """All true occurrences (for showing the reference emits a subset)."""
         t = _b(text)

@@ -92,6 +92,26 @@ def test_reference_kats(kat):
     assert [[h.end, h.value] for h in ac.match(seq, sep)] == kat["expect_end_value"]
 
 
+def test_char_array_with_sep_tests_code_points():
+    """match(Array(Char), sep) (ac.cr:342-364) looks at the neighbour's CODE POINT, the String overload
+    (matcher.cr:41-46) at the neighbouring byte: they differ as soon as a neighbour is not ASCII."""
+    ac = AC.compile(["a"])
+    sep = BitArray(256)  # nothing is a separator
+    assert [tuple(h) for h in ac.match(list("中a中"), sep)] == [(1, 2, 0)]  # U+4E2D >= sep.size: never blocks
+    assert [tuple(h) for h in ac.match("中a中", sep)] == []                 # bytes 0xAD / 0xE4 < 256 and not set: blocked
+    rng = random.Random(9)
+    cps = [chr(c) for c in list(range(0x4E00, 0x4E10)) + list(range(97, 103)) + list(range(0x430, 0x436)) + [0xE9, 0xFF, 32]]
+    keys = sorted({"".join(rng.choice(cps[:-1]) for _ in range(rng.randint(1, 3))) for _ in range(120)})
+    g = AC.compile(keys)
+    m = ModelAC(keys)
+    for size, bits in ((256, [32, 0xE9]), (100, [32, 97]), (0xF0, [0xE9])):
+        sep = BitArray(size)
+        for b in bits:
+            sep[b] = True
+        text = [rng.choice(cps) for _ in range(3000)]
+        assert [tuple(h) for h in g.match(text, sep)] == m.match_chars_sep(text, (size, bits))
+
+
 def test_byte_level_triples():
     ac = AC.compile(["我", "我是", "是中"])
     assert list(ac.match("我是中国人".encode())) == [Hit(0, 3, 0), Hit(0, 6, 1), Hit(3, 9, 2)]
@@ -579,6 +599,35 @@ def test_exchange_pairs_round_trip(chars):
     torch.cuda.synchronize()
     assert torch.equal(out[:n], t) and bool((out[n:] == -7).all())
     assert np.array_equal(ac.key_lengths(chars)[hits["value"]], hits["end"] - hits["start"])
+
+
+def test_group_of_shards_on_one_device(engine):
+    """aha_group_match_batch with three shards on cuda:0 (device list [0, 0, 0]): partition, concurrent matches on
+    three handles / streams, all-gatherv by device-to-device copies -- the RCCL leg needs distinct devices and is
+    not executable on a 1-GPU box.  Same hits and offsets as the single handle and the oracle."""
+    if engine != "v2":
+        pytest.skip("once, on the default engine")
+    from aha_amd import ACGroup
+
+    blob, offs, nf = synth.keys(3, K=20_000)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 23, doc_bytes=1 << 16)
+    grp = ACGroup.compile_packed(blob, offs, [0, 0, 0])
+    o = orc.AC.compile_packed(blob, offs)
+    for chars in (False, True):
+        oh, od = o.match_batch(corpus, doc, chars=chars)
+        gh, gd = grp.match_batch(corpus, doc, chars=chars, cap=16)  # too small first: the capacity protocol
+        assert np.array_equal(gd, od) and gh.tobytes() == oh.tobytes()
+    t = grp.last_timing()
+    assert t["n_devices"] == 3 and t["exchange"] == 0 and t["n_hits"] == len(oh)
+    # ragged: fewer documents than shards, empty documents, an empty batch
+    g2 = ACGroup.compile(["ab", "b"], [0, 0, 0, 0])
+    o2 = orc.AC.compile(["ab", "b"])
+    for docs in ([b"abab"], [b"", b"ab", b""], [], [b"", b""]):
+        offs2 = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+        c2 = np.frombuffer(b"".join(docs), dtype=np.uint8)
+        gh, gd = g2.match_batch(c2, offs2)
+        oh, od = o2.match_batch(c2, offs2)
+        assert np.array_equal(gd, od) and gh.tobytes() == oh.tobytes()
 
 
 def test_concurrent_calls_on_one_handle():

@@ -165,6 +165,29 @@ def test_synth_generators_deterministic():
     orc.AC.compile_packed(b5, o5)
 
 
+def test_group_partition_is_contiguous_and_byte_balanced():
+    """aha_group_partition (the sharding of aha_group_match_batch) agrees with the torch.distributed mirror
+    (aha_amd/distributed.py partition_docs): same contiguous, byte-balanced document ranges."""
+    from aha_amd import ACGroup
+    from aha_amd.distributed import partition_docs
+
+    rng = random.Random(5)
+    for _ in range(30):
+        D = rng.randint(0, 200)
+        lens = [rng.choice([0, 0, 1, 5, 100, 1000, 100000]) for _ in range(D)]
+        offs = np.cumsum([0] + lens).astype(np.uint64)
+        for n in (1, 2, 3, 8):
+            b = ACGroup.partition(offs, n)
+            assert b[0] == 0 and b[-1] == D and np.all(np.diff(b.astype(np.int64)) >= 0)
+            parts = partition_docs(offs, n)
+            assert [int(x) for x in b] == [lo for lo, _ in parts] + [D]
+            if D and offs[-1]:
+                ideal = int(offs[-1]) / n
+                biggest = max(lens) if lens else 0
+                for r in range(n):
+                    assert abs(int(offs[b[r + 1]]) - int(offs[b[r]]) - ideal) <= 2 * biggest + 1
+
+
 # ---- C ABI misuse: every entry point answers a bad argument with a status, never a crash -------
 def test_c_abi_rejects_bad_arguments():
     L = N.lib()

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaha_hip.so")
+# AHA_HIP_LIB: another build of the same library (the CPU suite points it at the sanitizer build)
+LIB_PATH = os.environ.get("AHA_HIP_LIB") or os.path.join(_HERE, "libaha_hip.so")
 SYNTH_PATH = os.path.join(_HERE, "libaha_synth.so")
 
 AHA_OK = 0

@@ -1,0 +1,34 @@
+// kernel_stubs.cpp -- link-time stand-ins for the HIP kernel launchers, used ONLY by the sanitizer build of the
+// host side (aha_amd/csrc/Makefile, target asan): automaton.cpp, capi.cpp and group.cpp are compiled with
+// g++ -fsanitize=address,undefined and exercised under AHA_OPT_HOST_ONLY, where no launcher is ever reached.
+#include <cstdio>
+#include <cstdlib>
+
+#include <hip/hip_runtime_api.h>
+
+#include "../../aha_amd/csrc/image.hpp"
+
+namespace aha {
+[[noreturn]] static void no_gpu(const char *what) {
+  fprintf(stderr, "sanitizer build: %s reached (host-only library)\n", what);
+  abort();
+}
+size_t pp_filter_lds(uint32_t) { return 0; }
+uint32_t pp_walk_max_slots() { return 1u << 14; }
+int pp_prepare(uint32_t, uint32_t) { return 0; }
+void pp_launch_filter(const PpArgs &, uint32_t, void *) { no_gpu("pp_launch_filter"); }
+void pp_launch_resolve(const DevAut &, const V2Args &, const PpArgs &, uint32_t, void *) { no_gpu("pp_launch_resolve"); }
+size_t v2_lds_bytes(uint32_t, bool) { return 0; }
+int v2_prepare(bool, size_t) { return 0; }
+void v2_launch_traverse(const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("v2_launch_traverse"); }
+void v2_launch_chunk_scan(const V2Args &, void *) { no_gpu("v2_launch_chunk_scan"); }
+void v2_launch_sort(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("v2_launch_sort"); }
+void v2_launch_expand(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("v2_launch_expand"); }
+void v2_launch_direct_post(const DevAut &, const V2Args &, void *, void *) { no_gpu("v2_launch_direct_post"); }
+void launch_hits_pack(const int32_t *, uint64_t, int32_t *, void *) { no_gpu("launch_hits_pack"); }
+void launch_hits_unpack(const DevAut &, const int32_t *, uint64_t, int, int32_t *, void *) { no_gpu("launch_hits_unpack"); }
+void launch_count(const DevAut &, const MatchArgs &, void *) { no_gpu("launch_count"); }
+void launch_scan_blocks(const MatchArgs &, uint64_t, void *) { no_gpu("launch_scan_blocks"); }
+void launch_docg(const MatchArgs &, void *) { no_gpu("launch_docg"); }
+void launch_write(const DevAut &, const MatchArgs &, void *) { no_gpu("launch_write"); }
+}  // namespace aha

@@ -165,6 +165,44 @@ def test_synth_generators_deterministic():
     orc.AC.compile_packed(b5, o5)
 
 
+def test_load_survives_corrupt_buffers():
+    """aha_ac_load parses untrusted bytes: truncations, bit flips (checksum and all) and hostile headers must come
+    back as a status -- never a crash or an out-of-bounds read (this test also runs under ASan/UBSan)."""
+    import struct
+
+    rng = random.Random(17)
+    keys = rand_keys(rng, 60, b"abcd", 1, 9)
+    good = AC.compile(keys, host_only=True).to_bytes()
+    assert AC.from_bytes(good, host_only=True).info["n_keys"] == len(keys)
+    for _ in range(300):
+        b = bytearray(good)
+        kind = rng.randrange(4)
+        if kind == 0:
+            b = b[: rng.randrange(len(b))]
+        elif kind == 1:
+            for _ in range(rng.randint(1, 4)):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        elif kind == 2:  # hostile sizes in the header: K and blob_bytes
+            struct.pack_into("<I", b, 12, rng.choice([0, 1, 0x7FFFFFFF, 0xFFFFFFFF]))
+            struct.pack_into("<Q", b, 16, rng.choice([0, 1 << 40, 0xFFFFFFFFFFFFFFFF]))
+        else:
+            b += bytes(rng.randrange(256) for _ in range(rng.randint(1, 9)))
+        try:
+            AC.from_bytes(bytes(b), host_only=True)
+        except AhaError as e:
+            assert e.code in (N.AHA_E_INVALID, N.AHA_E_EMPTY_KEY, N.AHA_E_ZERO_BYTE, N.AHA_E_DUP_KEY)
+    # a valid checksum over hostile content: offsets that run backwards / past the blob
+    def forge(K, offs_list, blob):
+        body = b"AHAHIP01" + struct.pack("<IIQ", 1, K, len(blob)) + b"".join(struct.pack("<Q", o) for o in offs_list) + blob
+        h = 0xcbf29ce484222325
+        for x in body:
+            h = ((h ^ x) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        return body + struct.pack("<Q", h)
+    for offs_list in ([0, 5, 3], [0, 2, 99], [1, 2, 3], [0, 0, 3]):
+        with pytest.raises(AhaError):
+            AC.from_bytes(forge(2, offs_list, b"abc"), host_only=True)
+
+
 def test_group_partition_is_contiguous_and_byte_balanced():
     """aha_group_partition (the sharding of aha_group_match_batch) agrees with the torch.distributed mirror
     (aha_amd/distributed.py partition_docs): same contiguous, byte-balanced document ranges."""

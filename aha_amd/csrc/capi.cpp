@@ -301,8 +301,17 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, V2M
                       M.chars ? M.n_chunks * 8 : 0,
                       n_reg * 8,          0,                  direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
                       0, 0, 0, 0};
-  for (int i = 0; i < 24; i++)
-    if (sizes[i] && (rc = v2_reserve(ac, i, sizes[i]))) return rc;
+  for (int i = 0; i < 24; i++) {
+    if (!sizes[i]) continue;
+    if ((rc = v2_reserve(ac, i, sizes[i]))) {
+      // no room for the event regions (someone else holds the HBM): the slab pipeline needs far less temp
+      if (i == 16 && mode != kSlabs) {
+        (void)hipGetLastError();
+        return match_v2(ac, M1, s, n_hits, kSlabs);
+      }
+      return rc;
+    }
+  }
   M.ev = (uint4 *)ac->v2buf[0].p;
   M.sorted_ev = (uint4 *)ac->v2buf[1].p;
   M.sorted_cnt = (uint32_t *)ac->v2buf[2].p;
@@ -808,11 +817,24 @@ int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t) {
   return AHA_OK;
 }
 
+static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
+                                       uint64_t n_docs, uint64_t n_bytes, const aha_match_params *params,
+                                       aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets, uint64_t *n_hits,
+                                       void *stream, bool offsets_checked);
+
 int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
                                   const uint64_t *d_doc_offsets, uint64_t n_docs,
                                   uint64_t n_bytes, const aha_match_params *params,
                                   aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets,
                                   uint64_t *n_hits, void *stream) {
+  return match_batch_device_impl(ac, d_corpus, d_doc_offsets, n_docs, n_bytes, params, d_out, cap, d_doc_hit_offsets,
+                                 n_hits, stream, false);
+}
+
+static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
+                                       uint64_t n_docs, uint64_t n_bytes, const aha_match_params *params,
+                                       aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets, uint64_t *n_hits,
+                                       void *stream, bool offsets_checked) {
   if (!ac || !n_hits || !d_doc_offsets) return AHA_E_INVALID;
   if (ac->device < 0) {
     ac->err = aha_strerror(AHA_E_NO_DEVICE);
@@ -826,6 +848,25 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
   int32_t rc = fill_params(ac, params, M);
   if (rc) return rc;
   *n_hits = 0;
+  if (!offsets_checked) {
+    // the offsets live in HBM: one small kernel and an 4-byte read-back before anything indexes with them
+    if ((rc = v2_reserve(ac, 9, 16 * 8))) return rc;
+    if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+    uint32_t *flag = (uint32_t *)ac->v2buf[9].p + 30;
+    HIPCHK(ac, hipMemsetAsync(flag, 0, 4, s));
+    launch_check_docs(d_doc_offsets, n_docs, n_bytes, flag, s);
+    HIPCHK(ac, hipMemcpyAsync(ac->h_v2, flag, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ac, hipStreamSynchronize(s));
+    const uint32_t bad = (uint32_t)ac->h_v2[0];
+    if (bad & 1u) {
+      ac->err = "doc offsets: need doc_offsets[0] = 0, ascending, doc_offsets[n_docs] = n_bytes";
+      return AHA_E_INVALID;
+    }
+    if (bad & 2u) {
+      ac->err = aha_strerror(AHA_E_TOO_LONG);
+      return AHA_E_TOO_LONG;
+    }
+  }
   if (n_bytes == 0) {
     if (d_doc_hit_offsets)
       HIPCHK(ac, hipMemsetAsync(d_doc_hit_offsets, 0, (n_docs + 1) * sizeof(uint64_t), s));
@@ -976,8 +1017,8 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
   } while (0)
   if (n_bytes) HIPCHK2(hipMemcpy(d_corpus, corpus, n_bytes, hipMemcpyHostToDevice));
   HIPCHK2(hipMemcpy(d_doc, doc_offsets, (n_docs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-  rc = aha_ac_match_batch_device(ac, d_corpus, d_doc, n_docs, n_bytes, params, d_out, cap, d_dho,
-                                 n_hits, nullptr);
+  rc = match_batch_device_impl(ac, d_corpus, d_doc, n_docs, n_bytes, params, d_out, cap, d_dho, n_hits, nullptr,
+                               true);  // checked on the host above
   if (rc == AHA_OK || rc == AHA_E_CAPACITY) {
     uint64_t n = std::min<uint64_t>(*n_hits, cap);
     if (n) HIPCHK2(hipMemcpy(out, d_out, n * sizeof(aha_hit), hipMemcpyDeviceToHost));

@@ -144,6 +144,9 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
 void launch_hits_pack(const int32_t *hits, uint64_t n, int32_t *pairs, void *stream);
 void launch_hits_unpack(const DevAut &A, const int32_t *pairs, uint64_t n, int chars, int32_t *hits, void *stream);
 
+// flag[0] |= 1: not the offsets of n_docs documents over n_bytes; |= 2: a document of 2^31 bytes or more
+void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_bytes, uint32_t *flag, void *stream);
+
 // launchers (kernels.hip)
 void launch_count(const DevAut &A, const MatchArgs &M, void *stream);
 void launch_scan_blocks(const MatchArgs &M, uint64_t n_blocks, void *stream);

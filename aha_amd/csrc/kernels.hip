@@ -258,6 +258,30 @@ void launch_hits_unpack(const DevAut &A, const int32_t *pairs, uint64_t n, int c
                      hits);
 }
 
+// -------------------------------------------------- device-resident doc offsets
+// The device entry point cannot read its doc offsets on the host: flag[0] |= 1 when they are not the offsets of
+// n_docs documents over exactly n_bytes (doc_off[0] = 0, ascending, doc_off[D] = n_bytes), |= 2 when a document
+// is 2^31 bytes or longer (Int32 offsets, src/aha/matcher.cr:3-5).
+__global__ __launch_bounds__(256) void k_check_docs(const uint64_t *doc_off, uint64_t D, uint64_t N, uint32_t *flag) {
+  uint32_t bad = 0;
+  for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d <= D; d += (uint64_t)gridDim.x * 256) {
+    const uint64_t q = doc_off[d];
+    if (d == 0 && q != 0) bad |= 1u;
+    if (d == D && q != N) bad |= 1u;
+    if (d < D) {
+      const uint64_t q1 = doc_off[d + 1];
+      if (q1 < q) bad |= 1u;
+      else if (q1 - q >= 0x7FFFFFFFull) bad |= 2u;
+    }
+  }
+  if (bad) atomicOr(flag, bad);
+}
+
+void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_bytes, uint32_t *flag, void *stream) {
+  const uint32_t g = (uint32_t)std::min<uint64_t>((n_docs + 256) / 256, 1024);
+  hipLaunchKernelGGL(k_check_docs, dim3(g), dim3(256), 0, (hipStream_t)stream, doc_off, n_docs, n_bytes, flag);
+}
+
 // ---------------------------------------------------------------- launchers
 static inline uint32_t blocks_for(uint64_t n_chunks) {
   return (uint32_t)((n_chunks + kBlock - 1) / kBlock);

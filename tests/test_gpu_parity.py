@@ -659,6 +659,19 @@ def test_concurrent_calls_on_one_handle():
     assert got == want
 
 
+def test_device_entry_validates_its_offsets():
+    import torch
+
+    ac = AC.compile(["ab"])
+    t = torch.from_numpy(np.frombuffer(b"abab" * 64, dtype=np.uint8).copy()).cuda()
+    out = torch.zeros((256, 3), dtype=torch.int32, device="cuda")
+    assert ac.match_batch_device(t, torch.tensor([0, 100, 256], dtype=torch.int64).cuda(), out) == 128
+    for bad in ([1, 100, 256], [0, 100, 255], [0, 200, 100, 256], [0, 100, 300]):
+        with pytest.raises(AhaError) as e:
+            ac.match_batch_device(t, torch.tensor(bad, dtype=torch.int64).cuda(), out)
+        assert e.value.code == N.AHA_E_INVALID
+
+
 def test_sequence_longer_than_int32_is_rejected():
     import ctypes as C
 

@@ -231,3 +231,33 @@ class HitGatherer:
                 req.wait()
         out[-1] = base_hits[-1]
         return out
+
+
+def strong_scaling_pass(gatherer, match_fn, sub_corpus, sub_doc, timer=None):
+    """One strong-scaling step of a rank (bench.py --gpus N, and its gloo rehearsal in the CPU suite): match this
+    rank's contiguous document range, all-gatherv the hit buffers, gather the per-document offsets rebased to the
+    global hit index.  match_fn(sub_corpus, sub_doc) -> (hits [cap,3] int32 on gatherer.device, n, dho [D_r+1]
+    int64 on gatherer.device).  Returns (gathered hits [H,3], global offsets [D+1], seconds of (match, exchange))."""
+    import time
+
+    sync = timer or (lambda: None)
+    sync()
+    t0 = time.perf_counter()
+    hits, n, dho = match_fn(sub_corpus, sub_doc)
+    sync()
+    t1 = time.perf_counter()
+    allh, counts = gatherer.all_gatherv(hits, n)
+    alld = gatherer.gather_doc_hit_offsets(dho, counts)
+    sync()
+    t2 = time.perf_counter()
+    return allh, alld, (t1 - t0, t2 - t1)
+
+
+def stream_digest(hits, dho):
+    """sha256 over the ordered hit triples and the per-document offsets (host arrays / CPU tensors)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(np.asarray(hits, dtype=np.int32)).tobytes())
+    h.update(np.ascontiguousarray(np.asarray(dho, dtype=np.int64)).tobytes())
+    return h.hexdigest()

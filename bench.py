@@ -57,6 +57,8 @@ def parse():
                     help="N>1: wait for each step's all-gatherv before the next match (default: the exchange of "
                          "step i runs beside the match of step i+1, double-buffered)")
     ap.add_argument("--force-wide", action="store_true")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N>1: skip the strong-scaling leg (the cfg 3 corpus split over the ranks) after the timed run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 collective backend; gloo (hits staged through host memory) only to rehearse the "
                          "multi-rank flow on a 1-GPU box together with AHA_BENCH_ONE_DEVICE=1")
@@ -293,6 +295,80 @@ def main():
     gbs = float(tot_bytes.item()) * args.steps / elapsed / 1e9
     mhits = float(tot_hits.item()) * args.steps / elapsed / 1e6
 
+    # ---- N > 1: the parts of a step on their own (SURVEY.md section 8 d: "gather time broken out"), untimed extras
+    breakdown, strong = None, None
+    if gather is not None:
+        k2 = max(2, min(args.steps, 5))
+
+        def timed(fn):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                fn()
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item()) / k2 * 1e3
+
+        scan_ms = timed(lambda: ac.match_batch_device(d_corpus, d_doc, d_out, d_dho, chars=args.chars))
+        exch_ms = timed(lambda: gather.all_gatherv(d_out if cdev == dev else d_out[:n_hits].cpu(), n_hits))
+        breakdown = {"scan_only_ms": round(scan_ms, 4), "exchange_only_ms": round(exch_ms, 4),
+                     "step_ms": round(ms_per_step, 4), "overlapped": bool(overlap)}
+        log(f"breakdown: scan only {scan_ms:.3f} ms, exchange only {exch_ms:.3f} ms, step {ms_per_step:.3f} ms")
+    if gather is not None and not args.no_strong:
+        # ---- strong scaling: ONE corpus (rank 0's) cut into contiguous byte-balanced document ranges
+        from aha_amd.distributed import HitGatherer, local_shard, stream_digest, strong_scaling_pass
+
+        c0, doc0 = (corpus, doc) if rank == 0 else synth.corpus(cfg, blob, offs, nf, n_bytes=n_bytes, rank=0)
+        sub, sub_doc, _lo = local_shard(c0, doc0, rank, world)
+        s_corpus = torch.from_numpy(np.ascontiguousarray(sub)).to(dev)
+        s_doc = torch.from_numpy(sub_doc.astype(np.int64)).to(dev)
+        s_dho = torch.zeros(sub_doc.size, dtype=torch.int64, device=dev)
+        try:
+            sn = ac.match_batch_device(s_corpus, s_doc, torch.zeros((1, 3), dtype=torch.int32, device=dev), s_dho,
+                                       chars=args.chars)
+        except AhaError as e:
+            if e.code != N.AHA_E_CAPACITY:
+                raise
+            sn = e.required
+        s_out = torch.zeros((sn + 1024, 3), dtype=torch.int32, device=dev)
+        sg = HitGatherer(dist, cdev, ac=ac, packed=args.exchange == "packed", chars=args.chars)
+
+        def match_fn(c, d):
+            n = ac.match_batch_device(c, d, s_out, s_dho, chars=args.chars)
+            if cdev == dev:
+                return s_out, n, s_dho
+            return s_out[:n].cpu(), n, s_dho.cpu()
+
+        sync = torch.cuda.synchronize
+        allh, alld, _ = strong_scaling_pass(sg, match_fn, s_corpus, s_doc, sync)  # warm-up
+        fence()
+        t0 = time.perf_counter()
+        tm = tx = 0.0
+        for _ in range(k2):
+            allh, alld, (a, b) = strong_scaling_pass(sg, match_fn, s_corpus, s_doc, sync)
+            tm += a
+            tx += b
+        fence()
+        ts = torch.tensor([time.perf_counter() - t0, tm, tx], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        el, tm, tx = [float(x) for x in ts.tolist()]
+        verified = None
+        if rank == 0:  # the same corpus on one GPU: the gathered stream must be identical
+            f_corpus = torch.from_numpy(c0).to(dev)
+            f_doc = torch.from_numpy(doc0.astype(np.int64)).to(dev)
+            f_dho = torch.zeros(doc0.size, dtype=torch.int64, device=dev)
+            f_out = torch.zeros((int(allh.shape[0]) + 1024, 3), dtype=torch.int32, device=dev)
+            fn_ = ac.match_batch_device(f_corpus, f_doc, f_out, f_dho, chars=args.chars)
+            verified = stream_digest(f_out[:fn_].cpu().numpy(), f_dho.cpu().numpy()) == \
+                stream_digest(allh.cpu().numpy(), alld.cpu().numpy())
+            del f_corpus, f_out
+        strong = {"scaling": "strong", "bytes_total": int(n_bytes), "value": round(n_bytes * k2 / el / 1e9, 3), "unit": "GB/s",
+                  "ms_per_step": round(el / k2 * 1e3, 4), "scan_ms": round(tm / k2 * 1e3, 4),
+                  "exchange_ms": round(tx / k2 * 1e3, 4), "steps": k2, "hits_total": int(allh.shape[0]),
+                  "identical_to_one_gpu": verified}
+        log(f"strong scaling: {strong}")
+
     # roofline of the dominant kernel (HIP events inside the library, launch stream)
     avg = {k: float(np.mean(v)) for k, v in kern.items()}
     engine = ac.last_timing()["engine"]
@@ -364,6 +440,13 @@ def main():
                                       + (" (overlapped)" if overlap else "")},
             "roofline": roofline,
         }
+        if breakdown is not None:
+            line["breakdown"] = breakdown
+        if strong is not None:
+            line["strong_scaling"] = strong
+            if strong["identical_to_one_gpu"] is False:
+                parity = "MISMATCH"
+                line["parity"], line["value"], line["m_hits_per_s"] = parity, None, None
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line, ensure_ascii=False), flush=True)

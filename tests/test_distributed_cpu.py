@@ -52,6 +52,16 @@ def _worker(rank, world, port, keys_blob, keys_offs, corpus, doc, out_q):
             oh, oc = gp.finish(slot)
             assert oc == counts and torch.equal(oh, allh)
         alld = g.gather_doc_hit_offsets(torch.from_numpy(dho.astype(np.int64)), counts)
+        # the strong-scaling leg of bench.py, step for step (the matcher is the oracle here, the GPU there)
+        from aha_amd.distributed import stream_digest, strong_scaling_pass
+
+        def match_fn(c, d):
+            return t, len(hits), torch.from_numpy(dho.astype(np.int64))
+
+        sh, sd, secs = strong_scaling_pass(g, match_fn, sub, sub_doc)
+        assert torch.equal(sh, allh) and torch.equal(sd, alld) and len(secs) == 2
+        full_h, full_d = o.match_batch(corpus, doc)
+        assert stream_digest(sh.numpy(), sd.numpy()) == stream_digest(full_h.view(np.int32).reshape(-1, 3), full_d)
         out_q.put((rank, allh.numpy().copy(), alld.numpy().copy(), counts))
     finally:
         dist.destroy_process_group()

@@ -38,7 +38,7 @@ class aha_options(C.Structure):
 
 class aha_match_params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("char_offsets", C.c_int32), ("sep_size", C.c_int32),
-                ("sep_bits", C.c_uint8 * 32)]
+                ("sep_bits", C.c_uint8 * 32), ("longest", C.c_int32)]
 
 
 class aha_ac_info_t(C.Structure):

@@ -75,10 +75,11 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
 
 
-def _params(chars, sep):
+def _params(chars, sep, longest=0):
     p = N.aha_match_params()
     p.struct_size = C.sizeof(N.aha_match_params)
     p.char_offsets = 1 if chars else 0
+    p.longest = int(longest)
     p.sep_size = 0
     if sep is not None:
         p.sep_size = sep.size
@@ -196,7 +197,7 @@ class AC:
         return r
 
     # -- #match ---------------------------------------------------------------
-    def match_array(self, seq, sep=None, chars=None):
+    def match_array(self, seq, sep=None, chars=None, longest=0):
         """All hits of one sequence as a HIT_DTYPE array (reference order)."""
         if isinstance(seq, (list, tuple)) and (not seq or isinstance(seq[0], str)):
             if sep is not None:
@@ -206,7 +207,7 @@ class AC:
         if chars is None:
             chars = isinstance(seq, str)
         t = np.frombuffer(_b(seq), dtype=np.uint8)
-        p = _params(chars, sep)
+        p = _params(chars, sep, longest)
         cap = max(64, t.size // 4)
         while True:
             out = np.zeros(cap, dtype=HIT_DTYPE)
@@ -253,14 +254,20 @@ class AC:
         for s, e, v in self.match_array(seq, sep, chars).tolist():
             yield Hit(s, e, v)
 
-    def match_batch(self, corpus, doc_offsets, sep=None, chars=False, cap=None):
-        """D documents in one call: returns (hits, doc_hit_offsets)."""
+    def match_longest(self, seq, intersectable=False, chars=None):
+        """ACX#match_longest(seq, intersectable = false) -- src/aha/ac.cr:297-319."""
+        for s, e, v in self.match_array(seq, None, chars, longest=2 if intersectable else 1).tolist():
+            yield Hit(s, e, v)
+
+    def match_batch(self, corpus, doc_offsets, sep=None, chars=False, cap=None, longest=0):
+        """D documents in one call: returns (hits, doc_hit_offsets).  longest: 0 = #match, 1 / 2 = #match_longest
+        with intersectable false / true."""
         if isinstance(corpus, (bytes, bytearray)):
             corpus = np.frombuffer(bytes(corpus), dtype=np.uint8)
         corpus = np.ascontiguousarray(corpus, dtype=np.uint8)
         doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
         D = doc_offsets.size - 1
-        p = _params(chars, sep)
+        p = _params(chars, sep, longest)
         dho = np.zeros(D + 1, dtype=np.uint64)
         if cap is None:
             cap = max(64, corpus.size // 8)

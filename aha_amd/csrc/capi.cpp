@@ -160,11 +160,19 @@ int32_t ensure_scratch(aha_ac *ac, uint64_t n_chunks, uint64_t n_blocks, uint64_
   return AHA_OK;
 }
 
-int32_t fill_params(aha_ac *ac, const aha_match_params *p, MatchArgs &M) {
+int32_t fill_params(aha_ac *ac, const aha_match_params *p, MatchArgs &M, int *longest) {
   M.chars = 0;
   M.sep = 0;
+  *longest = 0;
   memset(M.sep_block, 0, sizeof(M.sep_block));
   if (!p) return AHA_OK;
+  if (p->struct_size >= offsetof(aha_match_params, longest) + sizeof(int32_t)) {
+    if (p->longest < 0 || p->longest > 2 || (p->longest && p->sep_size > 0)) {
+      ac->err = "match_longest: intersectable is 1 or 2, and there is no separator overload";
+      return AHA_E_INVALID;
+    }
+    *longest = p->longest;
+  }
   M.chars = p->char_offsets ? 1 : 0;
   if (p->sep_size > 256) {  // raise "sep BitArray size > 256 is not supported" ac.cr:322
     ac->err = "sep BitArray size > 256 is not supported";
@@ -845,7 +853,8 @@ static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, cons
   DeviceGuard g(ac->device);
   hipStream_t s = (hipStream_t)stream;
   MatchArgs M{};
-  int32_t rc = fill_params(ac, params, M);
+  int longest = 0;
+  int32_t rc = fill_params(ac, params, M, &longest);
   if (rc) return rc;
   *n_hits = 0;
   if (!offsets_checked) {
@@ -888,6 +897,37 @@ static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, cons
   M.out = d_out;
   M.cap = cap;
   M.doc_hit_off = d_doc_hit_offsets;
+  if (longest) {
+    // match_longest: count -> scan -> write, like the two-pass engine (kernels.hip)
+    const int mode = longest == 1 ? 1 : (M.chars ? 3 : 2);
+    M.chunk = 1024;
+    while (M.chunk < 16ull * ac->aut.max_key_len && M.chunk < (1u << 20)) M.chunk *= 2;  // the warm-up is 2 * Lmax
+    M.n_chunks = (n_bytes + M.chunk - 1) / M.chunk;
+    const uint64_t units = mode == 2 ? M.n_chunks : n_docs + 1;
+    const uint64_t n_blocks = (units + kBlock - 1) / kBlock;
+    if ((rc = ensure_scratch(ac, units, n_blocks, n_docs))) return rc;
+    M.counts = ac->d_counts;
+    M.leads = ac->d_leads;
+    M.blk_hits = ac->d_blk_hits;
+    M.blk_leads = ac->d_blk_leads;
+    M.docg = ac->d_docg;
+    M.totals = ac->d_totals;
+    const int chars = M.chars;
+    launch_longest(ac->dev, M, mode, false, s);
+    M.chars = 0;  // the block scan has no lead counts to scan here
+    launch_scan_blocks(M, n_blocks, s);
+    M.chars = chars;
+    launch_longest(ac->dev, M, mode, true, s);
+    HIPCHK(ac, hipGetLastError());
+    HIPCHK(ac, hipMemcpyAsync(ac->h_totals, ac->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(ac, hipStreamSynchronize(s));
+    *n_hits = ac->h_totals[0];
+    if (*n_hits > cap) {
+      ac->err = "output buffer too small";
+      return AHA_E_CAPACITY;
+    }
+    return AHA_OK;
+  }
   if (ac->pp_ok && !M.chars && !M.sep) {
     rc = match_pp(ac, M, s, n_hits);
     if (rc < 0) return rc;

@@ -152,5 +152,8 @@ void launch_count(const DevAut &A, const MatchArgs &M, void *stream);
 void launch_scan_blocks(const MatchArgs &M, uint64_t n_blocks, void *stream);
 void launch_docg(const MatchArgs &M, void *stream);
 void launch_write(const DevAut &A, const MatchArgs &M, void *stream);
+// match_longest (ac.cr:118-143): mode 1 = intersectable false (a thread per document), 2 = true (a thread per chunk,
+// byte offsets), 3 = true with a thread per document (char offsets)
+void launch_longest(const DevAut &A, const MatchArgs &M, int mode, bool write, void *stream);
 
 }  // namespace aha

@@ -216,6 +216,188 @@ __global__ __launch_bounds__(kBlock) void k_write(DevAut A, MatchArgs M) {
   }
 }
 
+// ------------------------------------------------------------ match_longest
+// ACX#match_longest (src/aha/ac.cr:118-143 match_longest_, :249-263 fetch_one, :297-303): the traversal keeps the
+// last position whose state ends a key (prev_i, prev_nid); when a byte finds no goto from the current state that
+// pending end is yielded (its own key: fetch_one stops at the first live chain entry), cleared, and -- unless
+// `intersectable` -- the state is reset to the root, where the byte is NOT tried again (ac.cr:131-136).  Whatever is
+// pending at the end of the sequence is yielded last.
+// is_end? here means "really ends a key".  The reference's END bit can be stale on a slot reused inside
+// Cedar's resolve (cedar.cr:642-648): such a node would overwrite the pending end with one that yields nothing.
+// That depends on Cedar's slot history, which this build does not reproduce (own placement): documents whose walk
+// crosses a stale node are outside the parity contract of match_longest.
+struct Pending {
+  int64_t p = -1;      // absolute position of the pending end (-1: none)
+  uint32_t key = 0;
+  uint32_t endc = 0;   // chars mode: lead bytes of the document up to and including p
+};
+
+// One byte of match_longest_.  Returns true when a pending end was yielded (into *out).
+template <bool COMPACT>
+__device__ __forceinline__ bool longest_step(const DevAut &A, uint32_t &B, const uint8_t *tp, int64_t p, uint32_t lc,
+                                             bool intersectable, Pending &pend, Pending *out) {
+  const uint32_t b = *tp;
+  bool yielded = false;
+  for (;;) {
+    uint32_t key = 0;
+    const int r = b ? Probe<COMPACT>::go(A, B, b, key) : 0;  // a NUL byte has no goto anywhere (keys hold none)
+    if (r) {
+      if (r == 2) {
+        pend.p = p;
+        pend.key = key;
+        pend.endc = lc;
+      }
+      break;
+    }
+    if (pend.p >= 0) {
+      *out = pend;
+      yielded = true;
+      pend.p = -1;
+      if (!intersectable) B = A.root;
+    }
+    if (B == A.root) break;
+    B = fail_of<COMPACT>(A, B, tp);
+  }
+  return yielded;
+}
+
+__device__ __forceinline__ void longest_emit(const DevAut &A, const MatchArgs &M, const Pending &h, uint64_t doc_start,
+                                             uint64_t &idx) {
+  if (idx < M.cap) {
+    aha_hit o;
+    if (M.chars) {  // Hit(char_of_byte[start], char_of_byte[end - 1] + 1) ac.cr:305-310
+      o.end = (int32_t)h.endc;
+      o.start = (int32_t)h.endc - (int32_t)A.key_kc[h.key] - 1;
+    } else {        // Hit(idx - len + 1, idx + 1) ac.cr:255-257
+      o.end = (int32_t)(h.p - (int64_t)doc_start) + 1;
+      o.start = o.end - (int32_t)A.key_ln[h.key].x;
+    }
+    o.value = (int32_t)h.key;
+    M.out[idx] = o;
+  }
+  idx++;
+}
+
+// One thread per DOCUMENT, the whole sequence in order: exact for both forms; the only form for intersectable =
+// false, whose state depends on every earlier yield of the document.  WRITE = false counts, true writes.
+template <bool COMPACT, bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_longest_docs(DevAut A, MatchArgs M, int intersectable) {
+  __shared__ uint64_t sm[kBlock / 64];
+  const uint64_t d = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = d < M.n_docs;
+  uint64_t idx = 0;
+  if (WRITE) idx = M.blk_hits[blockIdx.x] + block_excl_scan<uint64_t>(live ? M.counts[d] : 0u, sm, nullptr);
+  uint32_t hits = 0;
+  if (live) {
+    const uint64_t a = M.doc_off[d], e = M.doc_off[d + 1];
+    if (WRITE && M.doc_hit_off) M.doc_hit_off[d] = idx;
+    uint32_t B = A.root, lc = 0;
+    Pending pend, out;
+    for (uint64_t p = a; p < e; p++) {
+      if (M.chars) lc += (M.text[p] & 0xC0u) != 0x80u;
+      if (longest_step<COMPACT>(A, B, M.text + p, (int64_t)p, lc, intersectable != 0, pend, &out)) {
+        if (WRITE) longest_emit(A, M, out, a, idx);
+        hits++;
+      }
+    }
+    if (pend.p >= 0) {
+      if (WRITE) longest_emit(A, M, pend, a, idx);
+      hits++;
+    }
+    if (!WRITE) M.counts[d] = hits;
+  }
+  if (!WRITE) {
+    uint64_t tot;
+    block_excl_scan<uint64_t>(hits, sm, &tot);
+    if (threadIdx.x == 0) M.blk_hits[blockIdx.x] = tot;
+  } else if (d == M.n_docs && M.doc_hit_off) {
+    M.doc_hit_off[d] = M.totals[0];
+  }
+}
+
+// intersectable = true keeps the plain automaton state, so chunks are independent given a warm-up: a thread owns
+// the yields whose pending end lies in its chunk.  A run of direct gotos is shorter than Lmax, so the last miss in
+// front of the chunk is at most Lmax back and the state there needs Lmax more bytes to be exact: the thread starts
+// 2 * Lmax bytes early (clamped to the document) and walks on past its chunk until its last pending end is yielded
+// or replaced by one that belongs to the next chunk.
+template <bool COMPACT, bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_longest_chunks(DevAut A, MatchArgs M) {
+  __shared__ uint64_t sm[kBlock / 64];
+  const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = c < M.n_chunks;
+  uint64_t idx = 0;
+  if (WRITE) idx = M.blk_hits[blockIdx.x] + block_excl_scan<uint64_t>(live ? M.counts[c] : 0u, sm, nullptr);
+  uint32_t hits = 0;
+  if (live) {
+    const uint64_t N = M.n_bytes, D = M.n_docs;
+    const uint64_t a = c * M.chunk, e = min(a + M.chunk, N);
+    uint64_t dn = first_boundary(M.doc_off, D, a);  // first document that starts at or after a
+    uint64_t nb = M.doc_off[dn];
+    uint64_t doc_start = a;
+    uint64_t p = a;
+    if (nb != a) {
+      doc_start = M.doc_off[dn - 1];
+      p = a - min<uint64_t>(a - doc_start, 2ull * A.max_len);
+    }
+    uint32_t B = A.root;
+    const uint32_t lc = 0;  // byte offsets only: char offsets take the per-document kernel (launch_longest)
+    Pending pend, out;
+    auto mine = [&](const Pending &h) { return (uint64_t)h.p >= a && (uint64_t)h.p < e; };
+    for (;;) {
+      if (p == nb) {  // end of a document: its pending end is yielded, the next one starts at the root
+        if (pend.p >= 0 && mine(pend)) {
+          if (WRITE) longest_emit(A, M, pend, doc_start, idx);
+          hits++;
+        }
+        pend.p = -1;
+        if (p >= e) break;
+        do {
+          if (WRITE && M.doc_hit_off && p >= a) M.doc_hit_off[dn] = idx;
+          dn++;
+          nb = dn <= D ? M.doc_off[dn] : ~0ull;
+        } while (nb == p);
+        B = A.root;
+        doc_start = p;
+        if (p >= N) break;
+      }
+      if (p >= e && (pend.p < 0 || !mine(pend))) break;  // nothing of this chunk is pending any more
+      if (longest_step<COMPACT>(A, B, M.text + p, (int64_t)p, lc, true, pend, &out) && mine(out)) {
+        if (WRITE) longest_emit(A, M, out, doc_start, idx);
+        hits++;
+      }
+      p++;
+    }
+    if (!WRITE) M.counts[c] = hits;
+    if (WRITE && e == N && M.doc_hit_off) {  // documents that start at N (empty tail documents) and the final total
+      const uint64_t tot = M.totals[0];
+      for (uint64_t q = first_boundary(M.doc_off, D, N); q <= D; q++) M.doc_hit_off[q] = tot;
+    }
+  }
+  if (!WRITE) {
+    uint64_t tot;
+    block_excl_scan<uint64_t>(hits, sm, &tot);
+    if (threadIdx.x == 0) M.blk_hits[blockIdx.x] = tot;
+  }
+}
+
+void launch_longest(const DevAut &A, const MatchArgs &M, int mode, bool write, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (mode != 2) {  // 1: intersectable = false, 3: true -- one thread per document (+1 for the closing offset)
+    const uint32_t g = (uint32_t)((M.n_docs + 1 + kBlock - 1) / kBlock);
+    const int isect = mode == 3 ? 1 : 0;
+#define AHA_LD(C, W) hipLaunchKernelGGL((k_longest_docs<C, W>), dim3(g), dim3(kBlock), 0, s, A, M, isect)
+    if (A.compact) { if (write) AHA_LD(true, true); else AHA_LD(true, false); }
+    else           { if (write) AHA_LD(false, true); else AHA_LD(false, false); }
+#undef AHA_LD
+  } else {
+    const uint32_t g = (uint32_t)((M.n_chunks + kBlock - 1) / kBlock);
+#define AHA_LC(C, W) hipLaunchKernelGGL((k_longest_chunks<C, W>), dim3(g), dim3(kBlock), 0, s, A, M)
+    if (A.compact) { if (write) AHA_LC(true, true); else AHA_LC(true, false); }
+    else           { if (write) AHA_LC(false, true); else AHA_LC(false, false); }
+#undef AHA_LC
+  }
+}
+
 // ------------------------------------------------ exchange format (multi-GPU)
 // A hit's start is its end minus the key's length (ac.cr:270-272; in char
 // offsets: minus the key's UTF-8 lead bytes), so ranks exchange {end, value}

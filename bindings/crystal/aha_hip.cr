@@ -8,6 +8,7 @@
 #   AC#match(seq, sep : BitArray)    (src/aha/ac.cr:321-340, matcher.cr:41-46)
 #   AC#match(seq : Array(Char))      (src/aha/ac.cr:288-295)
 #   AC#match(Array(Char), sep)       (src/aha/ac.cr:342-364: the neighbour tests look at code points)
+#   AC#match_longest(seq, intersectable)   (src/aha/ac.cr:297-319)
 #   AC#[](Int) / AC#[](String)       (src/aha/ac.cr:41-43)
 #   Aha::Hit                         (src/aha/matcher.cr:2-11, unchanged)
 # plus the batch surface the reference does not have (one sequence per call there):
@@ -49,6 +50,7 @@ lib LibAhaHip
     char_offsets : Int32
     sep_size : Int32
     sep_bits : UInt8[32]
+    longest : Int32 # 0 = #match, 1 = #match_longest(intersectable: false), 2 = #match_longest(intersectable: true)
   end
 
   fun aha_strerror(code : Int32) : UInt8*
@@ -124,10 +126,11 @@ module Aha
       {blob, offs}
     end
 
-    protected def self.params(chars : Bool, sep : BitArray?) : LibAhaHip::MatchParams
+    protected def self.params(chars : Bool, sep : BitArray?, longest : Int32 = 0) : LibAhaHip::MatchParams
       params = LibAhaHip::MatchParams.new
       params.struct_size = sizeof(LibAhaHip::MatchParams).to_u32
       params.char_offsets = chars ? 1 : 0
+      params.longest = longest
       if sep
         raise "sep BitArray size > 256 is not supported" if sep.size > 256
         params.sep_size = sep.size
@@ -171,8 +174,8 @@ module Aha
       result
     end
 
-    private def run(seq : Bytes, chars : Bool, sep : BitArray?, &block)
-      params = AC.params(chars, sep)
+    private def run(seq : Bytes, chars : Bool, sep : BitArray?, longest : Int32 = 0, &block)
+      params = AC.params(chars, sep, longest)
       cap = (seq.size / 4 + 64).to_u64
       loop do
         out_buf = Pointer(LibAhaHip::Hit).malloc(cap)
@@ -208,6 +211,21 @@ module Aha
 
     def match(seq : String, sep : BitArray, &block)
       run(seq.to_slice, true, sep) { |hit| yield hit }
+    end
+
+    # ACX#match_longest src/aha/ac.cr:297-319 (stale END flags of Cedar slots, cedar.cr:642-648, are not reproduced:
+    # see aha_amd/csrc/kernels.hip)
+    def match_longest(seq : Bytes | Array(UInt8), intersectable = false, &block)
+      bytes = seq.is_a?(Bytes) ? seq : Slice.new(seq.to_unsafe, seq.size)
+      run(bytes, false, nil, intersectable ? 2 : 1) { |hit| yield hit }
+    end
+
+    def match_longest(seq : String, intersectable = false, &block)
+      run(seq.to_slice, true, nil, intersectable ? 2 : 1) { |hit| yield hit }
+    end
+
+    def match_longest(seq : Array(Char) | Slice(Char), intersectable = false, &block)
+      run(String.build { |s| seq.each { |c| s << c } }.to_slice, true, nil, intersectable ? 2 : 1) { |hit| yield hit }
     end
 
     # src/aha/ac.cr:342-364: unlike the String overload the neighbour tests look at the neighbouring CHAR's code

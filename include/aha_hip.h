@@ -78,6 +78,13 @@ typedef struct {
   int32_t char_offsets;
   int32_t sep_size;
   uint8_t sep_bits[32];
+  /* match_longest(seq, intersectable) -- src/aha/ac.cr:118-143, 249-263, 297-319: 0 = plain match (default; also when
+   * struct_size stops before this field), 1 = match_longest with intersectable = false, 2 = with intersectable = true.
+   * Not combinable with a separator filter (the reference has no such overload): AHA_E_INVALID.
+   * intersectable = true is chunk-parallel (a 2 * Lmax warm-up makes the pending-end register exact);
+   * intersectable = false resets the state after every yield, so a document is walked in order by one thread
+   * (documents in parallel) -- correct at any size, fast only for batches of many documents. */
+  int32_t longest;
 } aha_match_params;
 
 typedef struct {

@@ -783,6 +783,20 @@ static inline void fetch_one(const orc_ac *a, int64_t idx, int32_t nid, const in
   }
 }
 
+/* Nodes the compile BFS reached whose is_end? is true although they hold no key: stale END flags of slots reused
+ * inside resolve (cedar.cr:642-648).  Unobservable through match; observable through match_longest (a stale node
+ * replaces the pending end by one that yields nothing).  Test infrastructure: lets the parity tests tell documents
+ * inside the GPU path's match_longest contract from those outside it. */
+int32_t orc_ac_stale_ends(const orc_ac *a) {
+  int32_t n = 0;
+  for (int32_t id = 0; id < a->da->array_size; id++) {
+    if (id != 0 && a->fails[id] < 0) continue; /* never visited */
+    if (a->da->array[id].check < 0 && id != 0) continue;
+    if (cedar_is_end(a->da, id) && a->output[id].value < 0) n++;
+  }
+  return n;
+}
+
 /* match_longest_ ac.cr:118-143 + match_longest :297-310 */
 int64_t orc_ac_match_longest(const orc_ac *a, const uint8_t *text, int64_t n, int intersectable,
                              int char_offsets, orc_hit *out, int64_t cap) {

@@ -55,6 +55,7 @@ def lib():
         "orc_ac_id": (i32, [vp, vp, i32]),
         "orc_ac_match": (i64, [vp, vp, i64, C.c_int, vp, i32, vp, i64]),
         "orc_ac_match_longest": (i64, [vp, vp, i64, C.c_int, C.c_int, vp, i64]),
+        "orc_ac_stale_ends": (i32, [vp]),
         "orc_ac_match_batch": (i64, [vp, vp, vp, u64, C.c_int, vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
@@ -208,6 +209,10 @@ class AC:
             if n <= cap:
                 return out[:n]
             cap = int(n)
+
+    def stale_ends(self):
+        """Nodes with a stale END flag (cedar.cr:642-648): only match_longest can observe them."""
+        return int(lib().orc_ac_stale_ends(self._h))
 
     def match_longest(self, text, intersectable=False, chars=None):
         if chars is None:

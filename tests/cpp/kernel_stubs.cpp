@@ -32,4 +32,5 @@ void launch_count(const DevAut &, const MatchArgs &, void *) { no_gpu("launch_co
 void launch_scan_blocks(const MatchArgs &, uint64_t, void *) { no_gpu("launch_scan_blocks"); }
 void launch_docg(const MatchArgs &, void *) { no_gpu("launch_docg"); }
 void launch_write(const DevAut &, const MatchArgs &, void *) { no_gpu("launch_write"); }
+void launch_longest(const DevAut &, const MatchArgs &, int, bool, void *) { no_gpu("launch_longest"); }
 }  // namespace aha

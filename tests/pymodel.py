@@ -108,6 +108,46 @@ class ModelAC:
             out = [(cmap[a], cmap[e - 1] + 1, v) for (a, e, v) in out]
         return out
 
+    def match_longest(self, text, intersectable=False, chars=None):
+        """match_longest_ / fetch_one restated from src/aha/ac.cr:118-143, 249-263 with is_end? = "really ends a
+        key" (no stale END flags: cedar.cr:642-648 is a property of Cedar's slot history, not of the key set)."""
+        if chars is None:
+            chars = isinstance(text, str)
+        t = _b(text)
+        out = []
+        nid, prev_i, prev_nid = 0, -1, -1
+
+        def fetch_one(i, n):
+            k = self.key_of[n]
+            out.append((i - len(self.keys[k]) + 1, i + 1, k))
+
+        for i, b in enumerate(t):
+            while True:
+                nxt = self.children[nid].get(b) if b else None
+                if nxt is not None:
+                    nid = nxt
+                    if self.key_of[nid] >= 0:
+                        prev_i, prev_nid = i, nid
+                    break
+                if prev_i != -1:
+                    fetch_one(prev_i, prev_nid)
+                    prev_i = -1
+                    if not intersectable:
+                        nid = 0
+                if nid == 0:
+                    break
+                nid = self.fail[nid]
+        if prev_i != -1:
+            fetch_one(prev_i, prev_nid)
+        if chars:
+            cmap, ci = [], -1
+            for b in t:
+                if (b & 0xC0) != 0x80:
+                    ci += 1
+                cmap.append(ci)
+            out = [(cmap[a], cmap[e - 1] + 1, v) for (a, e, v) in out]
+        return out
+
     def match_chars_sep(self, chars, sep):
         """match(seq : Array(Char) | Slice(Char), sep) restated from src/aha/ac.cr:342-364: the neighbour tests look
         at the neighbouring CHAR's code point (`chr.ord < sep.size && !sep[chr.ord]`), not at a byte.

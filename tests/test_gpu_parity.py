@@ -112,6 +112,57 @@ def test_char_array_with_sep_tests_code_points():
         assert [tuple(h) for h in g.match(text, sep)] == m.match_chars_sep(text, (size, bits))
 
 
+# ---- match_longest (src/aha/ac.cr:118-143, 297-319; spec/ac_longest_match_spec.cr) -----------------------------
+
+@pytest.mark.parametrize("kat", KATS["ac_match_longest"], ids=lambda k: k["cite"][-5:])
+def test_reference_match_longest_kats(kat):  # spec/ac_longest_match_spec.cr:5-63 (String and Array(Char) forms)
+    ac = AC.compile(kat["keys"])
+    for seq in (kat["text"], list(kat["text"]), kat["text"].encode()):
+        got = [[h.start, h.end, kat["keys"][h.value]] for h in ac.match_longest(seq, kat["intersectable"])]
+        assert got == kat["expect"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_match_longest_random(seed):
+    """Random automata and ragged batches, both forms, byte and char offsets (three device paths: a thread per
+    document for intersectable = false and for char offsets, a thread per chunk with a 2 * Lmax warm-up for
+    intersectable = true), against the independent model; against the oracle too where its Cedar image has no
+    stale END flag (cedar.cr:642-648 -- outside the GPU path's contract, see kernels.hip)."""
+    rng = random.Random(600 + seed)
+    alphabet = [b"ab", b"abc", "abж中".encode(), bytes(range(0x61, 0x6B))][seed % 4]
+    keys = rand_keys(rng, rng.randint(1, 80), alphabet, 1, [4, 9, 30][seed % 3])
+    g = AC.compile(keys)
+    m = ModelAC(keys)
+    o = orc.AC.compile(keys)
+    docs = [bytes(rng.choice(alphabet + b" ") for _ in range(rng.choice([0, 1, 2, 7, 100, 1023, 1024, 1025, 5000])))
+            for _ in range(40)] + [bytes(rng.choice(alphabet) for _ in range(40000))]
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+    corpus = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    for inter in (False, True):
+        for chars in (False, True):
+            if chars:
+                try:
+                    [d.decode("utf-8") for d in docs]
+                except UnicodeDecodeError:
+                    continue  # char offsets are defined for valid UTF-8 only
+            want, want_off = [], [0]
+            for d in docs:
+                want += m.match_longest(d, inter, chars=chars)
+                want_off.append(len(want))
+            gh, gd = g.match_batch(corpus, offs, chars=chars, longest=2 if inter else 1)
+            assert gpu_list(gh) == want, (inter, chars)
+            assert gd.tolist() == want_off
+            if o.stale_ends() == 0:
+                assert want == [t for d in docs for t in as_list(o.match_longest(d, inter, chars=chars))]
+    # the single-sequence entry and the capacity protocol
+    t = docs[-1]
+    assert [tuple(h) for h in g.match_longest(t, True)] == m.match_longest(t, True)
+    with pytest.raises(AhaError) as e:  # no separator overload of match_longest in the reference
+        sep = BitArray(256)
+        g.match_array(t, sep, longest=1)
+    assert e.value.code == N.AHA_E_INVALID
+
+
 def test_byte_level_triples():
     ac = AC.compile(["我", "我是", "是中"])
     assert list(ac.match("我是中国人".encode())) == [Hit(0, 3, 0), Hit(0, 6, 1), Hit(3, 9, 2)]

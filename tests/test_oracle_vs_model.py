@@ -9,6 +9,7 @@ from pymodel import ModelAC
 
 
 def rand_keys(rng, n, alphabet, lo, hi):
+    n = min(n, max(1, sum(len(set(alphabet)) ** k for k in range(lo, hi + 1)) // 2))  # never ask for more than exist
     seen = set()
     keys = []
     while len(keys) < n:
@@ -106,3 +107,23 @@ def test_batch_matches_per_doc():
         eoff.append(len(exp))
     assert as_list(hits) == exp
     assert dho.tolist() == eoff
+
+
+def test_match_longest_model_agrees_with_oracle_without_stale_flags():
+    """The independent restatement of match_longest (tests/pymodel.py) against the oracle's Cedar-based one, on
+    automata whose Cedar image holds no stale END flag (cedar.cr:642-648): with stale flags the two legitimately
+    differ, and the GPU path follows the model."""
+    rng = random.Random(99)
+    checked = 0
+    for _ in range(400):
+        keys = rand_keys(rng, rng.randint(1, 14), b"abc", 1, 5)
+        o = orc.AC.compile(keys)
+        if o.stale_ends():
+            continue
+        m = ModelAC(keys)
+        for _ in range(6):
+            text = bytes(rng.choice(b"abc ") for _ in range(rng.randint(0, 60)))
+            for inter in (False, True):
+                assert as_list(o.match_longest(text, inter)) == m.match_longest(text, inter), (keys, text, inter)
+        checked += 1
+    assert checked >= 20

@@ -377,6 +377,11 @@ def main():
         # k2_traverse: corpus + doc offsets + automaton image in; its event records are scratch
         dom, dom_ms = "k2_traverse", avg["ms_count"]
         alg_bytes = n_bytes + 8 * (D + 1) + A
+    elif engine == 3:
+        # position-parallel engine: ms_count = k_pp_filter (one coalesced pass over the corpus + its two tables);
+        # ms_scan = the exact pass (k_pp_walk + k_pp_deep + k_pp_order) is longer but is not one kernel
+        dom, dom_ms = "k_pp_filter", avg["ms_count"]
+        alg_bytes = n_bytes + 8 * (D + 1) + A
     elif avg["ms_write"] >= avg["ms_count"]:  # two-pass engine: ordered-write pass
         dom, dom_ms = "k_write", avg["ms_write"]
         alg_bytes = n_bytes + 12 * n_hits + 16 * (D + 1) + A

@@ -352,6 +352,10 @@ class AC:
         """Frees the handle's grow-only device scratch."""
         self._check(N.lib().aha_ac_release_scratch(self._h))
 
+    def scratch_bytes(self):
+        """Device bytes the handle currently holds as scratch (all scratch sets)."""
+        return int(N.lib().aha_ac_scratch_bytes(self._h))
+
     def last_timing(self):
         t = N.aha_timing()
         self._check(N.lib().aha_ac_last_timing(self._h, C.byref(t)))

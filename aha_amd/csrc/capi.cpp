@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -17,6 +19,29 @@
 #include "pp.hpp"
 
 using namespace aha;
+
+namespace {
+struct Buf {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+// Device scratch of ONE match call (grow-only, reused by later calls that lease the same set).
+struct Scratch {
+  std::mutex mu;  // held by the call that leased the set
+  uint32_t *d_counts = nullptr, *d_leads = nullptr;
+  uint64_t *d_blk_hits = nullptr, *d_blk_leads = nullptr, *d_docg = nullptr, *d_totals = nullptr;
+  uint64_t cap_chunks = 0, cap_blocks = 0, cap_docs = 0;
+  uint64_t *h_totals = nullptr;  // pinned
+  hipEvent_t ev[6] = {};
+  bool ev_ready = false;
+  Buf v2buf[24];
+  Buf hostbuf[4];  // device staging of the host-buffer entry points (corpus, doc offsets, doc hit offsets, hits)
+  unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
+};
+constexpr size_t kMaxScratch = 8;
+// last error text of the calling thread (aha_last_error): calls on one handle may run concurrently
+thread_local std::string tls_err;
+}  // namespace
 
 struct aha_ac {
   Automaton aut;
@@ -28,17 +53,13 @@ struct aha_ac {
   int device = -1;
   DevAut dev{};
   std::vector<void *> dev_allocs;
-  // scratch (grow-only, guarded by mu)
-  std::mutex mu;
-  std::mutex hmu;  // host-buffer entry points (staging buffers)
-  uint32_t *d_counts = nullptr, *d_leads = nullptr;
-  uint64_t *d_blk_hits = nullptr, *d_blk_leads = nullptr, *d_docg = nullptr, *d_totals = nullptr;
-  uint64_t cap_chunks = 0, cap_blocks = 0, cap_docs = 0;
-  uint64_t *h_totals = nullptr;  // pinned
+  // per-call scratch sets: a match call leases one for its duration (Lease below); concurrent calls on one handle
+  // get different sets, up to kMaxScratch of them, then wait
+  std::mutex pool_mu;
+  std::vector<std::unique_ptr<Scratch>> pool;
   // profiling
-  bool profiling = false;
-  hipEvent_t ev[6] = {};
-  bool ev_ready = false;
+  std::atomic<bool> profiling{false};
+  std::mutex last_mu;
   aha_timing last{};
   uint32_t chunk = 256;
   // single-traversal engine (scan_v2.hip)
@@ -47,11 +68,6 @@ struct aha_ac {
   uint32_t v2_grid = 0;
   uint32_t v2_bpc = 1;
   uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
-  struct Buf {
-    void *p = nullptr;
-    size_t bytes = 0;
-  };
-  Buf v2buf[24];
   // position-parallel engine (scan_pp.hip)
   PpTables pp;
   bool pp_ok = false;
@@ -59,9 +75,6 @@ struct aha_ac {
   uint32_t pp_grid = 0;
   uint32_t pp_lds_slots = 0;
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
-  Buf hostbuf[4];  // device staging of the host-buffer entry points (corpus, doc offsets, doc hit offsets, hits)
-  unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
-  std::string err;
 };
 
 namespace {
@@ -70,10 +83,85 @@ namespace {
   do {                                                                                \
     hipError_t e_ = (call);                                                           \
     if (e_ != hipSuccess) {                                                           \
-      (ac)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+      tls_err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
       return AHA_E_HIP;                                                               \
     }                                                                                 \
   } while (0)
+
+// Leases one scratch set for the duration of a call: a free one if there is any, a new one while the handle has fewer
+// than kMaxScratch, else it waits for the first.
+class Lease {
+ public:
+  explicit Lease(aha_ac *ac) {
+    {
+      std::lock_guard<std::mutex> lk(ac->pool_mu);
+      for (auto &u : ac->pool)
+        if (u->mu.try_lock()) {
+          sc_ = u.get();
+          break;
+        }
+      if (!sc_ && ac->pool.size() < kMaxScratch) {
+        ac->pool.emplace_back(new Scratch());
+        sc_ = ac->pool.back().get();
+        sc_->mu.lock();
+      }
+      if (!sc_) wait_ = ac->pool[0].get();
+    }
+    if (!sc_) {
+      wait_->mu.lock();
+      sc_ = wait_;
+    }
+  }
+  ~Lease() { sc_->mu.unlock(); }
+  Lease(const Lease &) = delete;
+  Lease &operator=(const Lease &) = delete;
+  Scratch *get() const { return sc_; }
+
+ private:
+  Scratch *sc_ = nullptr;
+  Scratch *wait_ = nullptr;
+};
+
+void free_scratch(Scratch *sc, bool all) {
+  for (auto &b : sc->v2buf) {
+    if (b.p) (void)hipFree(b.p);
+    b = Buf();
+  }
+  for (auto &b : sc->hostbuf) {
+    if (b.p) (void)hipFree(b.p);
+    b = Buf();
+  }
+  void **scratch[] = {(void **)&sc->d_counts, (void **)&sc->d_leads, (void **)&sc->d_blk_hits, (void **)&sc->d_blk_leads,
+                      (void **)&sc->d_docg};
+  for (void **p : scratch) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  sc->cap_chunks = sc->cap_blocks = sc->cap_docs = 0;
+  if (!all) return;
+  if (sc->d_totals) (void)hipFree(sc->d_totals);
+  if (sc->h_totals) (void)hipHostFree(sc->h_totals);
+  if (sc->h_v2) (void)hipHostFree(sc->h_v2);
+  sc->d_totals = nullptr;
+  sc->h_totals = nullptr;
+  sc->h_v2 = nullptr;
+  if (sc->ev_ready)
+    for (auto &e : sc->ev) (void)hipEventDestroy(e);
+  sc->ev_ready = false;
+}
+
+uint64_t scratch_bytes(const Scratch *sc) {
+  uint64_t n = 0;
+  for (auto &b : sc->v2buf) n += b.bytes;
+  for (auto &b : sc->hostbuf) n += b.bytes;
+  n += sc->cap_chunks * 8 + sc->cap_blocks * 16 + sc->cap_docs * 8;
+  return n;
+}
+
+void publish_timing(aha_ac *ac, const aha_timing &t) {
+  std::lock_guard<std::mutex> lk(ac->last_mu);
+  ac->last = t;
+}
 
 template <typename T>
 int32_t upload(aha_ac *ac, const std::vector<T> &v, const T **out) {
@@ -124,38 +212,38 @@ int32_t upload_image(aha_ac *ac, const Image &img) {
   return AHA_OK;
 }
 
-int32_t ensure_scratch(aha_ac *ac, uint64_t n_chunks, uint64_t n_blocks, uint64_t n_docs) {
-  if (n_chunks > ac->cap_chunks) {
-    if (ac->d_counts) (void)hipFree(ac->d_counts);
-    if (ac->d_leads) (void)hipFree(ac->d_leads);
-    ac->d_counts = ac->d_leads = nullptr;
-    ac->cap_chunks = 0;
+int32_t ensure_scratch(aha_ac *ac, Scratch *sc, uint64_t n_chunks, uint64_t n_blocks, uint64_t n_docs) {
+  if (n_chunks > sc->cap_chunks) {
+    if (sc->d_counts) (void)hipFree(sc->d_counts);
+    if (sc->d_leads) (void)hipFree(sc->d_leads);
+    sc->d_counts = sc->d_leads = nullptr;
+    sc->cap_chunks = 0;
     uint64_t n = n_chunks + n_chunks / 8 + 1024;
-    HIPCHK(ac, hipMalloc((void **)&ac->d_counts, n * sizeof(uint32_t)));
-    HIPCHK(ac, hipMalloc((void **)&ac->d_leads, n * sizeof(uint32_t)));
-    ac->cap_chunks = n;
+    HIPCHK(ac, hipMalloc((void **)&sc->d_counts, n * sizeof(uint32_t)));
+    HIPCHK(ac, hipMalloc((void **)&sc->d_leads, n * sizeof(uint32_t)));
+    sc->cap_chunks = n;
   }
-  if (n_blocks > ac->cap_blocks) {
-    if (ac->d_blk_hits) (void)hipFree(ac->d_blk_hits);
-    if (ac->d_blk_leads) (void)hipFree(ac->d_blk_leads);
-    ac->d_blk_hits = ac->d_blk_leads = nullptr;
-    ac->cap_blocks = 0;
+  if (n_blocks > sc->cap_blocks) {
+    if (sc->d_blk_hits) (void)hipFree(sc->d_blk_hits);
+    if (sc->d_blk_leads) (void)hipFree(sc->d_blk_leads);
+    sc->d_blk_hits = sc->d_blk_leads = nullptr;
+    sc->cap_blocks = 0;
     uint64_t n = n_blocks + n_blocks / 8 + 64;
-    HIPCHK(ac, hipMalloc((void **)&ac->d_blk_hits, n * sizeof(uint64_t)));
-    HIPCHK(ac, hipMalloc((void **)&ac->d_blk_leads, n * sizeof(uint64_t)));
-    ac->cap_blocks = n;
+    HIPCHK(ac, hipMalloc((void **)&sc->d_blk_hits, n * sizeof(uint64_t)));
+    HIPCHK(ac, hipMalloc((void **)&sc->d_blk_leads, n * sizeof(uint64_t)));
+    sc->cap_blocks = n;
   }
-  if (n_docs + 1 > ac->cap_docs) {
-    if (ac->d_docg) (void)hipFree(ac->d_docg);
-    ac->d_docg = nullptr;
-    ac->cap_docs = 0;
+  if (n_docs + 1 > sc->cap_docs) {
+    if (sc->d_docg) (void)hipFree(sc->d_docg);
+    sc->d_docg = nullptr;
+    sc->cap_docs = 0;
     uint64_t n = n_docs + 1 + n_docs / 8 + 64;
-    HIPCHK(ac, hipMalloc((void **)&ac->d_docg, n * sizeof(uint64_t)));
-    ac->cap_docs = n;
+    HIPCHK(ac, hipMalloc((void **)&sc->d_docg, n * sizeof(uint64_t)));
+    sc->cap_docs = n;
   }
-  if (!ac->d_totals) {
-    HIPCHK(ac, hipMalloc((void **)&ac->d_totals, 2 * sizeof(uint64_t)));
-    HIPCHK(ac, hipHostMalloc((void **)&ac->h_totals, 2 * sizeof(uint64_t), hipHostMallocDefault));
+  if (!sc->d_totals) {
+    HIPCHK(ac, hipMalloc((void **)&sc->d_totals, 2 * sizeof(uint64_t)));
+    HIPCHK(ac, hipHostMalloc((void **)&sc->h_totals, 2 * sizeof(uint64_t), hipHostMallocDefault));
   }
   return AHA_OK;
 }
@@ -168,14 +256,14 @@ int32_t fill_params(aha_ac *ac, const aha_match_params *p, MatchArgs &M, int *lo
   if (!p) return AHA_OK;
   if (p->struct_size >= offsetof(aha_match_params, longest) + sizeof(int32_t)) {
     if (p->longest < 0 || p->longest > 2 || (p->longest && p->sep_size > 0)) {
-      ac->err = "match_longest: intersectable is 1 or 2, and there is no separator overload";
+      tls_err = "match_longest: intersectable is 1 or 2, and there is no separator overload";
       return AHA_E_INVALID;
     }
     *longest = p->longest;
   }
   M.chars = p->char_offsets ? 1 : 0;
   if (p->sep_size > 256) {  // raise "sep BitArray size > 256 is not supported" ac.cr:322
-    ac->err = "sep BitArray size > 256 is not supported";
+    tls_err = "sep BitArray size > 256 is not supported";
     return AHA_E_SEP_SIZE;
   }
   if (p->sep_size > 0) {
@@ -236,8 +324,8 @@ void v2_setup(aha_ac *ac) {
   }
 }
 
-int32_t v2_reserve(aha_ac *ac, int i, size_t bytes) {
-  aha_ac::Buf &b = ac->v2buf[i];
+int32_t v2_reserve(aha_ac *ac, Scratch *sc, int i, size_t bytes) {
+  Buf &b = sc->v2buf[i];
   if (b.bytes >= bytes) return AHA_OK;
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr;
@@ -259,7 +347,7 @@ enum V2Mode { kRegions = 0, kFullRegions = 1, kSlabs = 2 };
 constexpr uint64_t kV2MaxRegionBytes = 48ull << 30;
 
 // returns AHA_OK, an error, +1 when the caller must fall back to the two-pass engine, +2 when a region overflowed
-int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, V2Mode mode) {
+int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, V2Mode mode) {
   const uint64_t N = M1.n_bytes;
   const uint32_t Lmax = ac->aut.max_key_len;
   uint64_t s_min = std::max<uint64_t>(64, ((8ull * Lmax + 63) / 64) * 64);
@@ -290,7 +378,9 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, V2M
   if (M.sep || (mode == kRegions && sparse)) mode = kSlabs;
   if (mode == kRegions && dense) mode = kFullRegions;
   uint64_t stride = S;
-  if (mode == kRegions) stride = std::min<uint64_t>(S, std::max<uint64_t>(16, 2 * (M1.cap / M.n_chunks) + 64));
+  // twice the average the caller allows for, plus a slack of 1/64 of the chunk (64 events at 4 KiB): 16 bytes per hit of
+  // capacity + 1/8 byte per input byte
+  if (mode == kRegions) stride = std::min<uint64_t>(S, 2 * (M1.cap / M.n_chunks) + std::max<uint64_t>(16, S / 64));
   if (mode != kSlabs && M.n_chunks * stride * 8 > kV2MaxRegionBytes) mode = kSlabs;
   const bool direct = mode != kSlabs;
   const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
@@ -311,81 +401,82 @@ int32_t match_v2(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, V2M
                       0, 0, 0, 0};
   for (int i = 0; i < 24; i++) {
     if (!sizes[i]) continue;
-    if ((rc = v2_reserve(ac, i, sizes[i]))) {
+    if ((rc = v2_reserve(ac, sc, i, sizes[i]))) {
       // no room for the event regions (someone else holds the HBM): the slab pipeline needs far less temp
       if (i == 16 && mode != kSlabs) {
         (void)hipGetLastError();
-        return match_v2(ac, M1, s, n_hits, kSlabs);
+        return match_v2(ac, sc, M1, s, n_hits, kSlabs);
       }
       return rc;
     }
   }
-  M.ev = (uint4 *)ac->v2buf[0].p;
-  M.sorted_ev = (uint4 *)ac->v2buf[1].p;
-  M.sorted_cnt = (uint32_t *)ac->v2buf[2].p;
-  M.slab_used = (uint32_t *)ac->v2buf[3].p;
-  M.ev_cnt = (uint32_t *)ac->v2buf[4].p;
-  M.doc_ev_rank = (uint32_t *)ac->v2buf[5].p;
-  M.ev_base = (uint64_t *)ac->v2buf[6].p;
-  M.blk_a = (uint64_t *)ac->v2buf[7].p;
-  M.blk_b = (uint64_t *)ac->v2buf[8].p;
-  M.cursor = (unsigned long long *)ac->v2buf[9].p;
-  M.totals = (uint64_t *)ac->v2buf[9].p + 2;
-  M.ev_aux = (uint32_t *)ac->v2buf[10].p;
-  M.sorted_aux = (uint32_t *)ac->v2buf[11].p;
-  M.lead_cnt = (uint32_t *)ac->v2buf[12].p;
-  M.chunk_doc0 = (uint32_t *)ac->v2buf[13].p;
-  M.doc_lead_rank = (uint32_t *)ac->v2buf[14].p;
-  M.lead_base = (uint64_t *)ac->v2buf[15].p;
-  M.evd = (uint2 *)ac->v2buf[16].p;
-  M.chunk_hits = (uint32_t *)ac->v2buf[18].p;
-  M.hit_base = (uint64_t *)ac->v2buf[19].p;
-  if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+  M.ev = (uint4 *)sc->v2buf[0].p;
+  M.sorted_ev = (uint4 *)sc->v2buf[1].p;
+  M.sorted_cnt = (uint32_t *)sc->v2buf[2].p;
+  M.slab_used = (uint32_t *)sc->v2buf[3].p;
+  M.ev_cnt = (uint32_t *)sc->v2buf[4].p;
+  M.doc_ev_rank = (uint32_t *)sc->v2buf[5].p;
+  M.ev_base = (uint64_t *)sc->v2buf[6].p;
+  M.blk_a = (uint64_t *)sc->v2buf[7].p;
+  M.blk_b = (uint64_t *)sc->v2buf[8].p;
+  M.cursor = (unsigned long long *)sc->v2buf[9].p;
+  M.totals = (uint64_t *)sc->v2buf[9].p + 2;
+  M.ev_aux = (uint32_t *)sc->v2buf[10].p;
+  M.sorted_aux = (uint32_t *)sc->v2buf[11].p;
+  M.lead_cnt = (uint32_t *)sc->v2buf[12].p;
+  M.chunk_doc0 = (uint32_t *)sc->v2buf[13].p;
+  M.doc_lead_rank = (uint32_t *)sc->v2buf[14].p;
+  M.lead_base = (uint64_t *)sc->v2buf[15].p;
+  M.evd = (uint2 *)sc->v2buf[16].p;
+  M.chunk_hits = (uint32_t *)sc->v2buf[18].p;
+  M.hit_base = (uint64_t *)sc->v2buf[19].p;
+  if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
 
-  const bool prof = ac->profiling && ac->ev_ready;
-  HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 16 * 8, s));
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
+  const bool prof = ac->profiling.load() && sc->ev_ready;
+  HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[0], s));
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
   v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
   if (direct) {
-    if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
-    v2_launch_direct_post(ac->dev, M, s, prof ? (void *)ac->ev[3] : nullptr);
+    if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
+    v2_launch_direct_post(ac->dev, M, s, prof ? (void *)sc->ev[3] : nullptr);
   } else {
     v2_launch_chunk_scan(M, s);
-    if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
+    if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
     v2_launch_sort(ac->dev, M, M.ev_cap, s);
-    if (prof) HIPCHK(ac, hipEventRecord(ac->ev[3], s));
+    if (prof) HIPCHK(ac, hipEventRecord(sc->ev[3], s));
     v2_launch_expand(ac->dev, M, M.ev_cap, s);
   }
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[4], s));
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[4], s));
   HIPCHK(ac, hipGetLastError());
-  HIPCHK(ac, hipMemcpyAsync(ac->h_v2, ac->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(ac, hipStreamSynchronize(s));
-  if (ac->h_v2[1] == 2) return 2;  // a chunk's event region overflowed: the caller repeats with full-size regions
-  if (ac->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
-  *n_hits = ac->h_v2[2];
+  if (sc->h_v2[1] == 2) return 2;  // a chunk's event region overflowed: the caller repeats with full-size regions
+  if (sc->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
+  *n_hits = sc->h_v2[2];
   if (prof) {
-    aha_timing &t = ac->last;
+    aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
     t.engine = 2;
     t.chunk_bytes = M.S;
     t.n_kernels = 9;
-    (void)hipEventElapsedTime(&t.ms_total, ac->ev[0], ac->ev[4]);
-    (void)hipEventElapsedTime(&t.ms_count, ac->ev[0], ac->ev[1]);
-    (void)hipEventElapsedTime(&t.ms_scan, ac->ev[1], ac->ev[2]);
-    (void)hipEventElapsedTime(&t.ms_aux, ac->ev[2], ac->ev[3]);
-    (void)hipEventElapsedTime(&t.ms_write, ac->ev[3], ac->ev[4]);
+    (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
+    (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], sc->ev[1]);
+    (void)hipEventElapsedTime(&t.ms_scan, sc->ev[1], sc->ev[2]);
+    (void)hipEventElapsedTime(&t.ms_aux, sc->ev[2], sc->ev[3]);
+    (void)hipEventElapsedTime(&t.ms_write, sc->ev[3], sc->ev[4]);
     t.n_chunks = M.n_chunks;
     t.n_hits = *n_hits;
+    publish_timing(ac, t);
   }
   return AHA_OK;
 }
 
 // Position-parallel engine (plain byte offsets only).  Returns AHA_OK, an error, or +1 when the caller must take
 // the single-traversal engine (an item list or an event region overflowed: hit-dense input).
-int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
+int32_t match_pp(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   const uint64_t N = M1.n_bytes;
   V2Args M{};
   M.text = M1.text;
@@ -413,15 +504,15 @@ int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
                             M.n_chunks * (size_t)kPpDeepCap * 8, M.n_chunks * (size_t)kPpLongCap * 4,
                             M.n_chunks * 4};
   for (int i = 0; i < 14; i++)
-    if ((rc = v2_reserve(ac, idx[i], sizes[i]))) return rc;
-  M.ev_cnt = (uint32_t *)ac->v2buf[4].p;
-  M.doc_ev_rank = (uint32_t *)ac->v2buf[5].p;
-  M.blk_a = (uint64_t *)ac->v2buf[7].p;
-  M.cursor = (unsigned long long *)ac->v2buf[9].p;
-  M.totals = (uint64_t *)ac->v2buf[9].p + 2;
-  M.evd = (uint2 *)ac->v2buf[16].p;
-  M.chunk_hits = (uint32_t *)ac->v2buf[18].p;
-  M.hit_base = (uint64_t *)ac->v2buf[19].p;
+    if ((rc = v2_reserve(ac, sc, idx[i], sizes[i]))) return rc;
+  M.ev_cnt = (uint32_t *)sc->v2buf[4].p;
+  M.doc_ev_rank = (uint32_t *)sc->v2buf[5].p;
+  M.blk_a = (uint64_t *)sc->v2buf[7].p;
+  M.cursor = (unsigned long long *)sc->v2buf[9].p;
+  M.totals = (uint64_t *)sc->v2buf[9].p + 2;
+  M.evd = (uint2 *)sc->v2buf[16].p;
+  M.chunk_hits = (uint32_t *)sc->v2buf[18].p;
+  M.hit_base = (uint64_t *)sc->v2buf[19].p;
   PpArgs P{};
   P.text = M1.text;
   P.n_bytes = N;
@@ -429,48 +520,49 @@ int32_t match_pp(aha_ac *ac, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
   P.t2 = ac->d_pp_t2;
   P.bloom = ac->d_pp_bloom;
   P.b_words = (uint32_t)ac->pp.bloom.size();
-  P.items = (uint16_t *)ac->v2buf[20].p;
-  P.tile_end = (unsigned long long *)ac->v2buf[21].p;
-  P.chunk_doc = (uint32_t *)ac->v2buf[22].p;
+  P.items = (uint16_t *)sc->v2buf[20].p;
+  P.tile_end = (unsigned long long *)sc->v2buf[21].p;
+  P.chunk_doc = (uint32_t *)sc->v2buf[22].p;
   P.lds_slots = ac->pp_lds_slots;
-  P.long_cnt = (uint32_t *)ac->v2buf[23].p;
-  P.deep = (uint2 *)ac->v2buf[0].p;
-  P.longs = (uint32_t *)ac->v2buf[1].p;
-  P.deep_cnt = (uint32_t *)ac->v2buf[2].p;
+  P.long_cnt = (uint32_t *)sc->v2buf[23].p;
+  P.deep = (uint2 *)sc->v2buf[0].p;
+  P.longs = (uint32_t *)sc->v2buf[1].p;
+  P.deep_cnt = (uint32_t *)sc->v2buf[2].p;
   P.flags = M.cursor;
-  if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
-  const bool prof = ac->profiling && ac->ev_ready;
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
-  HIPCHK(ac, hipMemsetAsync(ac->v2buf[9].p, 0, 16 * 8, s));
+  if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+  const bool prof = ac->profiling.load() && sc->ev_ready;
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[0], s));
+  HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
   HIPCHK(ac, hipMemsetAsync(M.ev_cnt, 0, M.n_chunks * 4, s));       // raw candidate counts, then event counts
   HIPCHK(ac, hipMemsetAsync(P.long_cnt, 0, M.n_chunks * 4, s));
   HIPCHK(ac, hipMemsetAsync(P.deep_cnt, 0, M.n_chunks * 4, s));
   const uint64_t waves = (M.n_chunks + 15) / 16;  // 16 waves (chunks) per filter workgroup
   pp_launch_filter(P, (uint32_t)std::min<uint64_t>(ac->pp_grid, std::max<uint64_t>(waves, 1)), s);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
   pp_launch_resolve(ac->dev, M, P, walk_grid, s);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
-  v2_launch_direct_post(ac->dev, M, s, prof ? (void *)ac->ev[3] : nullptr);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[4], s));
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
+  v2_launch_direct_post(ac->dev, M, s, prof ? (void *)sc->ev[3] : nullptr);
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[4], s));
   HIPCHK(ac, hipGetLastError());
-  HIPCHK(ac, hipMemcpyAsync(ac->h_v2, ac->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(ac, hipStreamSynchronize(s));
-  if (ac->h_v2[1]) return 1;
-  *n_hits = ac->h_v2[2];
+  if (sc->h_v2[1]) return 1;
+  *n_hits = sc->h_v2[2];
   if (prof) {
-    aha_timing &t = ac->last;
+    aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
     t.engine = 3;
     t.chunk_bytes = kPpChunk;
     t.n_kernels = 8;
-    (void)hipEventElapsedTime(&t.ms_total, ac->ev[0], ac->ev[4]);
-    (void)hipEventElapsedTime(&t.ms_count, ac->ev[0], ac->ev[1]);
-    (void)hipEventElapsedTime(&t.ms_scan, ac->ev[1], ac->ev[2]);
-    (void)hipEventElapsedTime(&t.ms_aux, ac->ev[2], ac->ev[3]);
-    (void)hipEventElapsedTime(&t.ms_write, ac->ev[3], ac->ev[4]);
+    (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
+    (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], sc->ev[1]);
+    (void)hipEventElapsedTime(&t.ms_scan, sc->ev[1], sc->ev[2]);
+    (void)hipEventElapsedTime(&t.ms_aux, sc->ev[2], sc->ev[3]);
+    (void)hipEventElapsedTime(&t.ms_write, sc->ev[3], sc->ev[4]);
     t.n_chunks = M.n_chunks;
     t.n_hits = *n_hits;
+    publish_timing(ac, t);
   }
   return AHA_OK;
 }
@@ -510,7 +602,10 @@ const char *aha_strerror(int32_t code) {
   return "unknown error";
 }
 
-const char *aha_last_error(const aha_ac *ac) { return ac ? ac->err.c_str() : ""; }
+const char *aha_last_error(const aha_ac *ac) {
+  (void)ac;
+  return tls_err.c_str();
+}
 uint32_t aha_abi_version(void) { return AHA_ABI_VERSION; }
 
 int32_t aha_device_count(void) {
@@ -587,7 +682,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     DeviceGuard g(device);
     int32_t rc = upload_image(ac, img);
     if (rc != AHA_OK) {
-      fprintf(stderr, "aha_ac_compile: %s\n", ac->err.c_str());
+      fprintf(stderr, "aha_ac_compile: %s\n", tls_err.c_str());
       aha_ac_free(ac);
       return rc;
     }
@@ -602,17 +697,7 @@ void aha_ac_free(aha_ac *ac) {
   if (ac->device >= 0) {
     DeviceGuard g(ac->device);
     for (void *p : ac->dev_allocs) (void)hipFree(p);
-    void *scratch[] = {ac->d_counts, ac->d_leads, ac->d_blk_hits, ac->d_blk_leads, ac->d_docg, ac->d_totals};
-    for (void *p : scratch)
-      if (p) (void)hipFree(p);
-    if (ac->h_totals) (void)hipHostFree(ac->h_totals);
-    for (auto &b : ac->v2buf)
-      if (b.p) (void)hipFree(b.p);
-    for (auto &b : ac->hostbuf)
-      if (b.p) (void)hipFree(b.p);
-    if (ac->h_v2) (void)hipHostFree(ac->h_v2);
-    if (ac->ev_ready)
-      for (auto &e : ac->ev) (void)hipEventDestroy(e);
+    for (auto &u : ac->pool) free_scratch(u.get(), true);
   }
   delete ac;
 }
@@ -784,95 +869,105 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
 int32_t aha_ac_release_scratch(aha_ac *ac) {
   if (!ac) return AHA_E_INVALID;
   if (ac->device < 0) return AHA_OK;
-  std::lock_guard<std::mutex> lk(ac->mu);
-  std::lock_guard<std::mutex> lk2(ac->hmu);
+  std::lock_guard<std::mutex> lk(ac->pool_mu);
   DeviceGuard g(ac->device);
-  for (auto &b : ac->v2buf) {
-    if (b.p) (void)hipFree(b.p);
-    b = aha_ac::Buf();
+  for (auto &u : ac->pool) {
+    std::lock_guard<std::mutex> lk2(u->mu);  // waits for a call that still uses the set
+    free_scratch(u.get(), false);
   }
-  for (auto &b : ac->hostbuf) {
-    if (b.p) (void)hipFree(b.p);
-    b = aha_ac::Buf();
-  }
-  void **scratch[] = {(void **)&ac->d_counts, (void **)&ac->d_leads, (void **)&ac->d_blk_hits, (void **)&ac->d_blk_leads,
-                      (void **)&ac->d_docg};
-  for (void **p : scratch) {
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-  }
-  ac->cap_chunks = ac->cap_blocks = ac->cap_docs = 0;
   return AHA_OK;
+}
+
+int64_t aha_ac_scratch_bytes(aha_ac *ac) {
+  if (!ac) return AHA_E_INVALID;
+  std::lock_guard<std::mutex> lk(ac->pool_mu);
+  uint64_t n = 0;
+  for (auto &u : ac->pool) {
+    std::lock_guard<std::mutex> lk2(u->mu);
+    n += scratch_bytes(u.get());
+  }
+  return (int64_t)n;
 }
 
 int32_t aha_ac_set_profiling(aha_ac *ac, int32_t enabled) {
   if (!ac) return AHA_E_INVALID;
   if (ac->device < 0) return AHA_E_NO_DEVICE;
-  std::lock_guard<std::mutex> lk(ac->mu);
-  if (enabled && !ac->ev_ready) {
-    DeviceGuard g(ac->device);
-    for (auto &e : ac->ev) HIPCHK(ac, hipEventCreate(&e));
-    ac->ev_ready = true;
-  }
-  ac->profiling = enabled != 0;
+  ac->profiling.store(enabled != 0);  // a scratch set creates its events when a profiled call first leases it
   return AHA_OK;
 }
 
 int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t) {
   if (!ac || !t) return AHA_E_INVALID;
-  *t = ac->last;
+  {
+    std::lock_guard<std::mutex> lk(const_cast<aha_ac *>(ac)->last_mu);
+    *t = ac->last;
+  }
   t->struct_size = sizeof(*t);
   return AHA_OK;
 }
 
-static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
+static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
                                        uint64_t n_docs, uint64_t n_bytes, const aha_match_params *params,
                                        aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets, uint64_t *n_hits,
                                        void *stream, bool offsets_checked);
+
+// the events of a scratch set are created by the first profiled call that leases it
+static int32_t ready_events(aha_ac *ac, Scratch *sc) {
+  if (!ac->profiling.load() || sc->ev_ready) return AHA_OK;
+  for (auto &e : sc->ev) HIPCHK(ac, hipEventCreate(&e));
+  sc->ev_ready = true;
+  return AHA_OK;
+}
 
 int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
                                   const uint64_t *d_doc_offsets, uint64_t n_docs,
                                   uint64_t n_bytes, const aha_match_params *params,
                                   aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets,
                                   uint64_t *n_hits, void *stream) {
-  return match_batch_device_impl(ac, d_corpus, d_doc_offsets, n_docs, n_bytes, params, d_out, cap, d_doc_hit_offsets,
-                                 n_hits, stream, false);
+  if (!ac || !n_hits || !d_doc_offsets) return AHA_E_INVALID;
+  if (ac->device < 0) {
+    tls_err = aha_strerror(AHA_E_NO_DEVICE);
+    return AHA_E_NO_DEVICE;
+  }
+  Lease lease(ac);
+  return match_batch_device_impl(ac, lease.get(), d_corpus, d_doc_offsets, n_docs, n_bytes, params, d_out, cap,
+                                 d_doc_hit_offsets, n_hits, stream, false);
 }
 
-static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
+static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
                                        uint64_t n_docs, uint64_t n_bytes, const aha_match_params *params,
                                        aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets, uint64_t *n_hits,
                                        void *stream, bool offsets_checked) {
   if (!ac || !n_hits || !d_doc_offsets) return AHA_E_INVALID;
   if (ac->device < 0) {
-    ac->err = aha_strerror(AHA_E_NO_DEVICE);
+    tls_err = aha_strerror(AHA_E_NO_DEVICE);
     return AHA_E_NO_DEVICE;
   }
   if (cap && !d_out) return AHA_E_INVALID;
-  std::lock_guard<std::mutex> lk(ac->mu);
   DeviceGuard g(ac->device);
   hipStream_t s = (hipStream_t)stream;
   MatchArgs M{};
   int longest = 0;
   int32_t rc = fill_params(ac, params, M, &longest);
   if (rc) return rc;
+  if ((rc = ready_events(ac, sc))) return rc;
   *n_hits = 0;
   if (!offsets_checked) {
     // the offsets live in HBM: one small kernel and an 4-byte read-back before anything indexes with them
-    if ((rc = v2_reserve(ac, 9, 16 * 8))) return rc;
-    if (!ac->h_v2) HIPCHK(ac, hipHostMalloc((void **)&ac->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
-    uint32_t *flag = (uint32_t *)ac->v2buf[9].p + 30;
+    if ((rc = v2_reserve(ac, sc, 9, 16 * 8))) return rc;
+    if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+    uint32_t *flag = (uint32_t *)sc->v2buf[9].p + 30;
     HIPCHK(ac, hipMemsetAsync(flag, 0, 4, s));
     launch_check_docs(d_doc_offsets, n_docs, n_bytes, flag, s);
-    HIPCHK(ac, hipMemcpyAsync(ac->h_v2, flag, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ac, hipMemcpyAsync(sc->h_v2, flag, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ac, hipStreamSynchronize(s));
-    const uint32_t bad = (uint32_t)ac->h_v2[0];
+    const uint32_t bad = (uint32_t)sc->h_v2[0];
     if (bad & 1u) {
-      ac->err = "doc offsets: need doc_offsets[0] = 0, ascending, doc_offsets[n_docs] = n_bytes";
+      tls_err = "doc offsets: need doc_offsets[0] = 0, ascending, doc_offsets[n_docs] = n_bytes";
       return AHA_E_INVALID;
     }
     if (bad & 2u) {
-      ac->err = aha_strerror(AHA_E_TOO_LONG);
+      tls_err = aha_strerror(AHA_E_TOO_LONG);
       return AHA_E_TOO_LONG;
     }
   }
@@ -886,9 +981,9 @@ static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, cons
   if (reinterpret_cast<uintptr_t>(d_corpus) % 16 != 0) {
     // the kernels read the corpus in aligned 16-byte pieces: an unaligned view (a slice of a larger buffer) is copied
     // once, device to device, into the handle's scratch (~0.7 ms per GiB: about a fifth of the match itself)
-    if ((rc = v2_reserve(ac, 17, n_bytes + 64))) return rc;
-    HIPCHK(ac, hipMemcpyAsync(ac->v2buf[17].p, d_corpus, n_bytes, hipMemcpyDeviceToDevice, s));
-    d_corpus = (const uint8_t *)ac->v2buf[17].p;
+    if ((rc = v2_reserve(ac, sc, 17, n_bytes + 64))) return rc;
+    HIPCHK(ac, hipMemcpyAsync(sc->v2buf[17].p, d_corpus, n_bytes, hipMemcpyDeviceToDevice, s));
+    d_corpus = (const uint8_t *)sc->v2buf[17].p;
   }
   M.text = d_corpus;
   M.doc_off = d_doc_offsets;
@@ -905,13 +1000,13 @@ static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, cons
     M.n_chunks = (n_bytes + M.chunk - 1) / M.chunk;
     const uint64_t units = mode == 2 ? M.n_chunks : n_docs + 1;
     const uint64_t n_blocks = (units + kBlock - 1) / kBlock;
-    if ((rc = ensure_scratch(ac, units, n_blocks, n_docs))) return rc;
-    M.counts = ac->d_counts;
-    M.leads = ac->d_leads;
-    M.blk_hits = ac->d_blk_hits;
-    M.blk_leads = ac->d_blk_leads;
-    M.docg = ac->d_docg;
-    M.totals = ac->d_totals;
+    if ((rc = ensure_scratch(ac, sc, units, n_blocks, n_docs))) return rc;
+    M.counts = sc->d_counts;
+    M.leads = sc->d_leads;
+    M.blk_hits = sc->d_blk_hits;
+    M.blk_leads = sc->d_blk_leads;
+    M.docg = sc->d_docg;
+    M.totals = sc->d_totals;
     const int chars = M.chars;
     launch_longest(ac->dev, M, mode, false, s);
     M.chars = 0;  // the block scan has no lead counts to scan here
@@ -919,21 +1014,21 @@ static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, cons
     M.chars = chars;
     launch_longest(ac->dev, M, mode, true, s);
     HIPCHK(ac, hipGetLastError());
-    HIPCHK(ac, hipMemcpyAsync(ac->h_totals, ac->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(ac, hipMemcpyAsync(sc->h_totals, sc->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(ac, hipStreamSynchronize(s));
-    *n_hits = ac->h_totals[0];
+    *n_hits = sc->h_totals[0];
     if (*n_hits > cap) {
-      ac->err = "output buffer too small";
+      tls_err = "output buffer too small";
       return AHA_E_CAPACITY;
     }
     return AHA_OK;
   }
   if (ac->pp_ok && !M.chars && !M.sep) {
-    rc = match_pp(ac, M, s, n_hits);
+    rc = match_pp(ac, sc, M, s, n_hits);
     if (rc < 0) return rc;
     if (rc == AHA_OK) {
       if (*n_hits > cap) {
-        ac->err = "output buffer too small";
+        tls_err = "output buffer too small";
         return AHA_E_CAPACITY;
       }
       return AHA_OK;
@@ -941,13 +1036,13 @@ static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, cons
     *n_hits = 0;  // rc == 1: hit-dense or unaligned input -> single-traversal engine
   }
   if (ac->v2_ok) {
-    rc = match_v2(ac, M, s, n_hits, kRegions);
-    if (rc == 2) rc = match_v2(ac, M, s, n_hits, kFullRegions);  // denser than cap said: regions of one event per byte
-    if (rc == 2) rc = match_v2(ac, M, s, n_hits, kSlabs);        // (not reached: full-size regions cannot overflow)
+    rc = match_v2(ac, sc, M, s, n_hits, kRegions);
+    if (rc == 2) rc = match_v2(ac, sc, M, s, n_hits, kFullRegions);  // denser than cap said: regions of one event per byte
+    if (rc == 2) rc = match_v2(ac, sc, M, s, n_hits, kSlabs);        // (not reached: full-size regions cannot overflow)
     if (rc < 0) return rc;
     if (rc == AHA_OK) {
       if (*n_hits > cap) {
-        ac->err = "output buffer too small";
+        tls_err = "output buffer too small";
         return AHA_E_CAPACITY;
       }
       return AHA_OK;
@@ -959,48 +1054,49 @@ static int32_t match_batch_device_impl(aha_ac *ac, const uint8_t *d_corpus, cons
   while (M.chunk < 8ull * ac->aut.max_key_len && M.chunk < (1u << 20)) M.chunk *= 2;
   M.n_chunks = (n_bytes + M.chunk - 1) / M.chunk;
   const uint64_t n_blocks = (M.n_chunks + kBlock - 1) / kBlock;
-  if ((rc = ensure_scratch(ac, M.n_chunks, n_blocks, n_docs))) return rc;
-  M.counts = ac->d_counts;
-  M.leads = ac->d_leads;
-  M.blk_hits = ac->d_blk_hits;
-  M.blk_leads = ac->d_blk_leads;
-  M.docg = ac->d_docg;
-  M.totals = ac->d_totals;
+  if ((rc = ensure_scratch(ac, sc, M.n_chunks, n_blocks, n_docs))) return rc;
+  M.counts = sc->d_counts;
+  M.leads = sc->d_leads;
+  M.blk_hits = sc->d_blk_hits;
+  M.blk_leads = sc->d_blk_leads;
+  M.docg = sc->d_docg;
+  M.totals = sc->d_totals;
   M.out = d_out;
   M.cap = cap;
   M.doc_hit_off = d_doc_hit_offsets;
 
-  const bool prof = ac->profiling && ac->ev_ready;
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[0], s));
+  const bool prof = ac->profiling.load() && sc->ev_ready;
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[0], s));
   launch_count(ac->dev, M, s);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[1], s));
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
   launch_scan_blocks(M, n_blocks, s);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[2], s));
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
   if (M.chars) launch_docg(M, s);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[3], s));
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[3], s));
   launch_write(ac->dev, M, s);
-  if (prof) HIPCHK(ac, hipEventRecord(ac->ev[4], s));
+  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[4], s));
   HIPCHK(ac, hipGetLastError());
-  HIPCHK(ac, hipMemcpyAsync(ac->h_totals, ac->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(ac, hipMemcpyAsync(sc->h_totals, sc->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
   HIPCHK(ac, hipStreamSynchronize(s));
-  *n_hits = ac->h_totals[0];
+  *n_hits = sc->h_totals[0];
   if (prof) {
-    aha_timing &t = ac->last;
+    aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
     t.n_kernels = M.chars ? 4 : 3;
-    (void)hipEventElapsedTime(&t.ms_total, ac->ev[0], ac->ev[4]);
-    (void)hipEventElapsedTime(&t.ms_count, ac->ev[0], ac->ev[1]);
-    (void)hipEventElapsedTime(&t.ms_scan, ac->ev[1], ac->ev[2]);
-    (void)hipEventElapsedTime(&t.ms_aux, ac->ev[2], ac->ev[3]);
-    (void)hipEventElapsedTime(&t.ms_write, ac->ev[3], ac->ev[4]);
+    (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
+    (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], sc->ev[1]);
+    (void)hipEventElapsedTime(&t.ms_scan, sc->ev[1], sc->ev[2]);
+    (void)hipEventElapsedTime(&t.ms_aux, sc->ev[2], sc->ev[3]);
+    (void)hipEventElapsedTime(&t.ms_write, sc->ev[3], sc->ev[4]);
     t.n_chunks = M.n_chunks;
     t.n_hits = *n_hits;
     t.engine = 1;
     t.chunk_bytes = M.chunk;
+    publish_timing(ac, t);
   }
   if (*n_hits > cap) {
-    ac->err = "output buffer too small";
+    tls_err = "output buffer too small";
     return AHA_E_CAPACITY;
   }
   return AHA_OK;
@@ -1011,7 +1107,7 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
                            uint64_t cap, uint64_t *doc_hit_offsets, uint64_t *n_hits) {
   if (!ac || !doc_offsets || !n_hits) return AHA_E_INVALID;
   if (ac->device < 0) {
-    ac->err = aha_strerror(AHA_E_NO_DEVICE);
+    tls_err = aha_strerror(AHA_E_NO_DEVICE);
     return AHA_E_NO_DEVICE;
   }
   if (doc_offsets[0] != 0) return AHA_E_INVALID;
@@ -1023,11 +1119,12 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
   if (n_bytes && !corpus) return AHA_E_INVALID;
   if (cap && !out) return AHA_E_INVALID;
   DeviceGuard g(ac->device);
-  // device staging buffers are kept in the handle (grow-only): the reference's
+  // device staging buffers are kept in the leased scratch set (grow-only): the reference's
   // usage is one #match per string, so per-call hipMalloc/hipFree would dominate
-  std::unique_lock<std::mutex> lk(ac->hmu);
+  Lease lease(ac);
+  Scratch *sc = lease.get();
   auto reserve = [&](int i, size_t bytes) -> void * {
-    aha_ac::Buf &b = ac->hostbuf[i];
+    Buf &b = sc->hostbuf[i];
     if (b.bytes < bytes) {
       if (b.p) (void)hipFree(b.p);
       b.p = nullptr;
@@ -1043,7 +1140,7 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
   uint64_t *d_dho = (uint64_t *)reserve(2, (n_docs + 1) * sizeof(uint64_t));
   aha_hit *d_out = cap ? (aha_hit *)reserve(3, cap * sizeof(aha_hit)) : nullptr;
   if (!d_corpus || !d_doc || !d_dho || (cap && !d_out)) {
-    ac->err = "hipMalloc failed for the staging buffers";
+    tls_err = "hipMalloc failed for the staging buffers";
     return AHA_E_HIP;
   }
   int32_t rc = AHA_OK;
@@ -1051,13 +1148,13 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
   do {                                                                 \
     hipError_t e_ = (call);                                            \
     if (e_ != hipSuccess) {                                            \
-      ac->err = std::string(#call) + ": " + hipGetErrorString(e_);     \
+      tls_err = std::string(#call) + ": " + hipGetErrorString(e_);     \
       return AHA_E_HIP;                                                \
     }                                                                  \
   } while (0)
   if (n_bytes) HIPCHK2(hipMemcpy(d_corpus, corpus, n_bytes, hipMemcpyHostToDevice));
   HIPCHK2(hipMemcpy(d_doc, doc_offsets, (n_docs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-  rc = match_batch_device_impl(ac, d_corpus, d_doc, n_docs, n_bytes, params, d_out, cap, d_dho, n_hits, nullptr,
+  rc = match_batch_device_impl(ac, sc, d_corpus, d_doc, n_docs, n_bytes, params, d_out, cap, d_dho, n_hits, nullptr,
                                true);  // checked on the host above
   if (rc == AHA_OK || rc == AHA_E_CAPACITY) {
     uint64_t n = std::min<uint64_t>(*n_hits, cap);

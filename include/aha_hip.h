@@ -12,14 +12,18 @@
  * unless stated.  The caller owns every buffer it passes; the library never
  * retains caller pointers past return.  The AUTOMATON of a handle is immutable after compile and which pipeline a
  * match call takes is a function of that call alone (its size, its params and its `cap`), never of earlier calls.
- * What a handle does keep between calls is grow-only device scratch (aha_ac_release_scratch frees it); concurrent
- * match calls on one handle are serialised internally on that scratch.
+ * What a handle does keep between calls is grow-only device scratch (aha_ac_release_scratch frees it,
+ * aha_ac_scratch_bytes reports it), organised in sets: a match call leases one set for its duration, so concurrent
+ * calls on one handle (one host thread and one stream each) run side by side on up to 8 sets and only then wait.
+ * aha_last_error returns the text of the calling thread's last failure.
  *
  * Device scratch of one match call on N input bytes with output capacity `cap` hits (single-traversal engine): the
- * event records, 8 bytes each -- per 4 KiB-class chunk min(chunk bytes, 2 * cap / n_chunks + 64) of them, i.e. about
- * 16 bytes per hit the caller can take; one event per input byte (8 N bytes, bounded at 48 GiB) only when `cap`
- * announces more than one hit per 4 input bytes or a chunk overflowed its region; plus ~20 bytes per chunk and
- * 4 bytes per document.  A device corpus that is not 16-byte aligned is first copied into scratch (N bytes).
+ * event records.  Region pipeline: 8 bytes each, per chunk (N / 2^18 bytes, at least 192) twice the average the
+ * capacity allows for plus 1/64 of the chunk, i.e. 16 bytes per hit of capacity + N/8.  Slab pipeline (capacity
+ * below 16 hits per chunk, or a separator filter): 41 bytes per hit of capacity + 80 MB.  One event per input byte
+ * (8 N bytes, bounded at 48 GiB) only when `cap` announces more than one hit per 4 input bytes or a chunk
+ * overflowed its region.  Plus ~24 bytes per chunk and 4 bytes per document.  A device corpus that is not 16-byte
+ * aligned is first copied into scratch (N bytes).
  */
 #ifndef AHA_HIP_H
 #define AHA_HIP_H
@@ -224,6 +228,8 @@ int32_t aha_ac_load(const void *buf, uint64_t n_bytes, const aha_options *opts, 
 
 /* Frees the handle's device scratch (it grows with the largest batch seen and is otherwise kept for reuse). */
 int32_t aha_ac_release_scratch(aha_ac *ac);
+/* Device bytes currently held as scratch by the handle (all sets); waits for running calls. */
+int64_t aha_ac_scratch_bytes(aha_ac *ac);
 
 /* Enable/disable HIP-event timing of device matches on this handle.  aha_timing.engine tells which engine answered the
  * last call: keys longer than 4096 bytes, a NULL-capacity sizing call and event-temp overflow take the two-pass

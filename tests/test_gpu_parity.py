@@ -710,6 +710,93 @@ def test_concurrent_calls_on_one_handle():
     assert got == want
 
 
+def test_concurrent_device_calls_lease_their_own_scratch(engine):
+    """Two host threads, one stream each, one handle: the calls run on separate scratch sets (no handle-wide lock) and
+    both give the oracle's answer."""
+    if engine != "v2":
+        pytest.skip("one engine is enough")
+    import threading
+
+    import torch
+
+    blob, offs, nf = synth.keys(3, K=20_000)
+    g = AC.compile_packed(blob, offs)
+    o = orc.AC.compile_packed(blob, offs)
+    jobs = []
+    for seed in (0, 1, 2):
+        corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 24, doc_bytes=1 << 18, seed=seed + 5)
+        oh, _ = o.match_batch(corpus[: int(doc[4])], doc[:5])  # the oracle on the first four documents
+        jobs.append((corpus, doc, oh))
+    res = [None] * len(jobs)
+    errs = []
+
+    def work(i):
+        try:
+            corpus, doc, _ = jobs[i]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                dc = torch.from_numpy(corpus).cuda()
+                dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+                out = torch.zeros((corpus.size // 8, 3), dtype=torch.int32, device="cuda")
+                dho = torch.zeros(doc.size, dtype=torch.int64, device="cuda")
+                st.synchronize()
+                for _ in range(8):
+                    n = g.match_batch_device(dc, dd, out, dho, stream=st.cuda_stream)
+                res[i] = (out[:n].cpu().numpy().copy(), dho.cpu().numpy().copy())
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for (corpus, doc, oh), (hits, dho) in zip(jobs, res):
+        assert dho[4] == len(oh) and hits[: len(oh)].tobytes() == oh.tobytes()
+    assert g.scratch_bytes() > 0
+
+
+def test_scratch_is_bounded_by_the_capacity_the_caller_gives(engine):
+    """the temp of a call follows the hits the caller allows for -- event regions: 16 B per hit of
+    capacity + 1/8 B per input byte; slab pipeline (fewer than 16 hits per chunk): 41 B per hit of capacity + 80 MB --
+    not 8 B per input byte; release_scratch gives it back to the device."""
+    if engine != "v2":
+        pytest.skip("the bound is the single-traversal engine's")
+    import torch
+
+    blob, offs, nf = synth.keys(3, K=20_000)
+    n_bytes = 1 << 28
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=n_bytes, doc_bytes=1 << 20)
+    g = AC.compile_packed(blob, offs)
+    dc = torch.from_numpy(corpus).cuda()
+    dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+    dho = torch.zeros(doc.size, dtype=torch.int64, device="cuda")
+    try:
+        n = g.match_batch_device(dc, dd, torch.zeros((1, 3), dtype=torch.int32, device="cuda"), dho)
+    except AhaError as e:
+        n = e.required
+    g.release_scratch()
+    assert g.scratch_bytes() == 0
+    g.set_profiling(True)
+    cap = n + n // 8
+    out = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    assert g.match_batch_device(dc, dd, out, dho) == n
+    assert g.last_timing()["engine"] == 2
+    free1, _ = torch.cuda.mem_get_info()
+    bound = 41 * cap + n_bytes // 8 + (128 << 20)
+    assert g.scratch_bytes() <= bound, (g.scratch_bytes(), bound)
+    assert free0 - free1 <= bound + (64 << 20), (free0 - free1, bound)  # what the device really lost (allocator slack)
+    assert g.scratch_bytes() < 8 * n_bytes // 4                          # far below one event per input byte
+    g.release_scratch()
+    assert g.scratch_bytes() == 0
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free2 >= free0 - (64 << 20)
+
+
 def test_device_entry_validates_its_offsets():
     import torch
 

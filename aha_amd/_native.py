@@ -61,7 +61,7 @@ class aha_timing(C.Structure):
 class aha_group_timing(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_devices", C.c_uint32), ("ms_match", C.c_float),
                 ("ms_match_max_shard", C.c_float), ("ms_exchange", C.c_float), ("ms_download", C.c_float),
-                ("n_hits", C.c_uint64), ("exchange", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_hits", C.c_uint64), ("exchange", C.c_uint32), ("packed", C.c_uint32), ("wire_bytes", C.c_uint64)]
 
 
 # every symbol include/aha_hip.h declares: name -> (restype, argtypes)
@@ -84,6 +84,8 @@ SIGNATURES = {
     "aha_ac_export": (C.c_int64, [_vp, _i32, _vp, _u64]),
     "aha_ac_hits_pack_device": (_i32, [_vp, _vp, _u64, _vp, _vp]),
     "aha_ac_hits_unpack_device": (_i32, [_vp, _vp, _u64, _i32, _vp, _vp]),
+    "aha_ac_hits_pack4_device": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp, _vp]),
+    "aha_ac_hits_unpack4_device": (_i32, [_vp, _vp, _u64, _i32, _vp, _vp]),
     "aha_ac_save": (C.c_int64, [_vp, _vp, _u64]),
     "aha_ac_load": (_i32, [_vp, _u64, C.POINTER(aha_options), C.POINTER(_vp)]),
     "aha_ac_release_scratch": (_i32, [_vp]),

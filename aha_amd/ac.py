@@ -328,6 +328,31 @@ class AC:
         self._check(N.lib().aha_ac_hits_unpack_device(self._h, pairs.data_ptr(), n, 1 if chars else 0,
                                                       hits.data_ptr(), C.c_void_p(s)))
 
+    def hits_pack4_device(self, hits, n, words, n_words, stream=None):
+        """hits [>=n,3] int32 -> the 4-byte exchange stream in `words` (int32, capacity >= 2n + ceil(n/1024)); the
+        stream length lands in n_words[0] (int64 device tensor).  Asynchronous."""
+        import torch
+
+        assert hits.is_cuda and words.is_cuda and n_words.is_cuda and hits.dtype == words.dtype == torch.int32
+        assert n_words.dtype == torch.int64 and hits.is_contiguous() and words.is_contiguous() and hits.numel() >= 3 * n
+        s = stream if stream is not None else torch.cuda.current_stream(hits.device).cuda_stream
+        self._check(N.lib().aha_ac_hits_pack4_device(self._h, hits.data_ptr(), n, words.data_ptr(), words.numel(),
+                                                     n_words.data_ptr(), C.c_void_p(s)))
+
+    def hits_unpack4_device(self, words, n, hits, chars=False, stream=None):
+        """4-byte exchange stream of n hits -> hits [>=n,3] int32, asynchronous."""
+        import torch
+
+        assert hits.is_cuda and words.is_cuda and hits.dtype == words.dtype == torch.int32
+        assert hits.is_contiguous() and words.is_contiguous() and hits.numel() >= 3 * n
+        s = stream if stream is not None else torch.cuda.current_stream(hits.device).cuda_stream
+        self._check(N.lib().aha_ac_hits_unpack4_device(self._h, words.data_ptr(), n, 1 if chars else 0,
+                                                       hits.data_ptr(), C.c_void_p(s)))
+
+    @property
+    def n_keys(self):
+        return self.info["n_keys"]
+
     def key_lengths(self, chars=False):
         """Length of every key in bytes (or in chars): Hit#end - Hit#start of its hits."""
         ln = self.export(N.AHA_IMG_KEY_LN, np.uint32).reshape(-1, 2)[:, 0].astype(np.int32)

@@ -719,6 +719,34 @@ int32_t aha_ac_hits_unpack_device(aha_ac *ac, const int32_t *d_pairs, uint64_t n
   return AHA_OK;
 }
 
+int32_t aha_ac_hits_pack4_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, uint32_t *d_words, uint64_t cap_words,
+                                 uint64_t *d_n_words, void *stream) {
+  if (!ac || ac->device < 0 || !d_words || !d_n_words || (n && !d_hits)) return AHA_E_INVALID;
+  if (ac->aut.n_keys > (1u << 20)) {
+    tls_err = "the 4-byte exchange stream holds key ids below 2^20: use the {end, value} pairs";
+    return AHA_E_INVALID;
+  }
+  if (n >= (1ull << 41)) return AHA_E_INVALID;
+  if (cap_words < 2 * n + (n + 1023) / 1024) {
+    tls_err = "4-byte exchange stream: capacity below 2 n + ceil(n / 1024) words";
+    return AHA_E_CAPACITY;
+  }
+  DeviceGuard g(ac->device);
+  launch_hits_pack4(reinterpret_cast<const int32_t *>(d_hits), n, d_words,
+                    reinterpret_cast<unsigned long long *>(d_n_words), stream);
+  HIPCHK(ac, hipGetLastError());
+  return AHA_OK;
+}
+
+int32_t aha_ac_hits_unpack4_device(aha_ac *ac, const uint32_t *d_words, uint64_t n, int32_t char_offsets,
+                                   aha_hit *d_hits, void *stream) {
+  if (!ac || ac->device < 0 || (n && (!d_hits || !d_words))) return AHA_E_INVALID;
+  DeviceGuard g(ac->device);
+  launch_hits_unpack4(ac->dev, d_words, n, char_offsets ? 1 : 0, reinterpret_cast<int32_t *>(d_hits), stream);
+  HIPCHK(ac, hipGetLastError());
+  return AHA_OK;
+}
+
 // ---- save / load: the library's own container (see include/aha_hip.h) ----------
 namespace {
 constexpr char kSaveMagic[8] = {'A', 'H', 'A', 'H', 'I', 'P', '0', '1'};

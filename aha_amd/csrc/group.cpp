@@ -85,8 +85,10 @@ struct Shard {
   int device = 0;
   hipStream_t stream = nullptr;
   DevBuf corpus, doc, dho, out, all;
+  DevBuf pk, land, nw;  // 4-byte exchange stream: packed own hits, landing area of the peers' streams, stream length
   // per call
-  uint64_t d0 = 0, d1 = 0, n_hits = 0;
+  uint64_t d0 = 0, d1 = 0, n_hits = 0, n_words = 0;
+  std::string err;
   std::vector<uint64_t> h_dho;
   int32_t rc = AHA_OK;
   double ms_match = 0;
@@ -151,6 +153,9 @@ void aha_group_free(aha_group *g) {
     s.dho.release();
     s.out.release();
     s.all.release();
+    s.pk.release();
+    s.land.release();
+    s.nw.release();
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.ac) aha_ac_free(s.ac);
   }
@@ -241,7 +246,10 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
         }
       }
       s.ms_match = ms_since(t0);
-      if (s.rc != AHA_OK) return;
+      if (s.rc != AHA_OK) {
+        s.err = aha_last_error(s.ac);  // the text is the calling thread's: take it along
+        return;
+      }
       if (hipMemcpy(s.h_dho.data(), s.dho.p, (D + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) s.rc = AHA_E_HIP;
     });
   }
@@ -252,7 +260,7 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   for (size_t r = 0; r < n; r++) {
     Shard &s = g->shards[r];
     if (s.rc != AHA_OK) {
-      g->err = std::string("shard ") + std::to_string(r) + ": " + aha_last_error(s.ac);
+      g->err = std::string("shard ") + std::to_string(r) + ": " + s.err;
       return s.rc;
     }
     T.ms_match_max_shard = std::max(T.ms_match_max_shard, (float)s.ms_match);
@@ -278,6 +286,48 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
       return AHA_E_HIP;
     }
   }
+  // What travels: the 4-byte stream of include/aha_hip.h (aha_ac_hits_pack4_device) when the key ids fit 20 bits,
+  // else the 12-byte triples.  Same code for both transports, so the packed path runs on a one-GPU box too.
+  aha_ac_info_t info{};
+  info.struct_size = sizeof(info);
+  (void)aha_ac_info(g->shards[0].ac, &info);
+  const bool words = n > 1 && info.n_keys <= (1u << 20);
+  const int chars = (params && params->char_offsets) ? 1 : 0;
+  std::vector<uint64_t> ebase(n + 1, 0);  // in 32-bit elements
+  if (words) {
+    for (size_t r = 0; r < n; r++) {
+      Shard &s = g->shards[r];
+      const uint64_t capw = 2 * s.n_hits + (s.n_hits + 1023) / 1024 + 16;
+      if (hipSetDevice(s.device) != hipSuccess || !s.pk.reserve(capw * 4) || !s.nw.reserve(8)) return AHA_E_HIP;
+      int32_t rc = aha_ac_hits_pack4_device(s.ac, (const aha_hit *)s.out.p, s.n_hits, (uint32_t *)s.pk.p, capw,
+                                            (uint64_t *)s.nw.p, s.stream);
+      if (rc != AHA_OK) {
+        g->err = std::string("pack: ") + aha_last_error(s.ac);
+        return rc;
+      }
+    }
+    for (size_t r = 0; r < n; r++) {
+      Shard &s = g->shards[r];
+      if (hipSetDevice(s.device) != hipSuccess ||
+          hipMemcpyAsync(&s.n_words, s.nw.p, 8, hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
+          hipStreamSynchronize(s.stream) != hipSuccess)
+        return AHA_E_HIP;
+    }
+  } else {
+    for (size_t r = 0; r < n; r++) g->shards[r].n_words = g->shards[r].n_hits * 3;
+  }
+  for (size_t r = 0; r < n; r++) ebase[r + 1] = ebase[r] + g->shards[r].n_words;
+  T.wire_bytes = 4 * ebase[n];
+  if (words)
+    for (size_t r = 0; r < n; r++) {
+      Shard &s = g->shards[r];
+      if (hipSetDevice(s.device) != hipSuccess || !s.land.reserve(std::max<uint64_t>(ebase[n], 1) * 4)) return AHA_E_HIP;
+    }
+  // payload of shard p as shard r sees it arrive: triples land in place, words in the landing area
+  auto landing = [&](Shard &s, size_t p) -> void * {
+    return words ? (void *)((uint32_t *)s.land.p + ebase[p]) : (void *)((aha_hit *)s.all.p + base[p]);
+  };
+  auto payload = [&](const Shard &q) -> const void * { return words ? q.pk.p : q.out.p; };
   if (g->distinct && n > 1) {
     if (g->comms.empty()) {
       if (!g->rccl.load(g->err)) return AHA_E_HIP;
@@ -293,12 +343,11 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     bool ok = g->rccl.GroupStart() == 0;
     for (size_t r = 0; r < n && ok; r++) {
       Shard &s = g->shards[r];
-      aha_hit *all = (aha_hit *)s.all.p;
       for (size_t p = 0; p < n && ok; p++) {
         if (p == r) continue;
-        if (s.n_hits) ok = ok && g->rccl.Send(s.out.p, s.n_hits * 3, kNcclInt32, (int)p, g->comms[r], s.stream) == 0;
-        if (g->shards[p].n_hits)
-          ok = ok && g->rccl.Recv(all + base[p], g->shards[p].n_hits * 3, kNcclInt32, (int)p, g->comms[r], s.stream) == 0;
+        if (s.n_words) ok = ok && g->rccl.Send(payload(s), s.n_words, kNcclInt32, (int)p, g->comms[r], s.stream) == 0;
+        if (g->shards[p].n_words)
+          ok = ok && g->rccl.Recv(landing(s, p), g->shards[p].n_words, kNcclInt32, (int)p, g->comms[r], s.stream) == 0;
       }
     }
     ok = (g->rccl.GroupEnd() == 0) && ok;
@@ -306,23 +355,29 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
       g->err = "RCCL send/recv failed";
       return AHA_E_HIP;
     }
-    for (size_t r = 0; r < n; r++) {  // the own part
-      Shard &s = g->shards[r];
-      if (s.n_hits && (hipSetDevice(s.device) != hipSuccess ||
-                       hipMemcpyAsync((aha_hit *)s.all.p + base[r], s.out.p, s.n_hits * sizeof(aha_hit),
-                                      hipMemcpyDeviceToDevice, s.stream) != hipSuccess))
-        return AHA_E_HIP;
-    }
   } else {
     for (size_t r = 0; r < n; r++) {
       Shard &s = g->shards[r];
       if (hipSetDevice(s.device) != hipSuccess) return AHA_E_HIP;
       for (size_t p = 0; p < n; p++) {
         const Shard &q = g->shards[p];
-        if (q.n_hits && hipMemcpyAsync((aha_hit *)s.all.p + base[p], q.out.p, q.n_hits * sizeof(aha_hit),
-                                       hipMemcpyDeviceToDevice, s.stream) != hipSuccess)
+        if (p != r && q.n_words &&
+            hipMemcpyAsync(landing(s, p), payload(q), q.n_words * 4, hipMemcpyDeviceToDevice, s.stream) != hipSuccess)
           return AHA_E_HIP;
       }
+    }
+  }
+  for (size_t r = 0; r < n; r++) {  // the own part as it is; the peers' streams rebuilt into triples at their place
+    Shard &s = g->shards[r];
+    if (hipSetDevice(s.device) != hipSuccess) return AHA_E_HIP;
+    if (s.n_hits && hipMemcpyAsync((aha_hit *)s.all.p + base[r], s.out.p, s.n_hits * sizeof(aha_hit),
+                                   hipMemcpyDeviceToDevice, s.stream) != hipSuccess)
+      return AHA_E_HIP;
+    for (size_t p = 0; words && p < n; p++) {
+      if (p == r || !g->shards[p].n_hits) continue;
+      int32_t rc = aha_ac_hits_unpack4_device(s.ac, (const uint32_t *)s.land.p + ebase[p], g->shards[p].n_hits, chars,
+                                              (aha_hit *)s.all.p + base[p], s.stream);
+      if (rc != AHA_OK) return rc;
     }
   }
   for (size_t r = 0; r < n; r++) {
@@ -335,6 +390,7 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   T.ms_exchange = (float)ms_since(t_x);
   T.n_hits = total;
   T.exchange = (g->distinct && n > 1) ? 1u : 0u;
+  T.packed = words ? 1u : 0u;
   if (total > cap) return AHA_E_CAPACITY;
   const auto t_d = std::chrono::steady_clock::now();
   Shard &s0 = g->shards[0];

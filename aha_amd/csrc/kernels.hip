@@ -440,6 +440,157 @@ void launch_hits_unpack(const DevAut &A, const int32_t *pairs, uint64_t n, int c
                      hits);
 }
 
+// -------------------------------------------------- 4-byte exchange stream
+// Hits leave the match in per-document order with ascending `end`, so the stream of `end` values is a sequence of
+// small non-negative steps with a reset per document.  The compressed exchange format of n hits:
+//   words[n]   value << 12 | step, step = end - previous end when that is 0..4094, else 4095 = exception
+//   blk[nb]    nb = ceil(n / 1024): index into exc[] of the block's first exception (every block starts with one)
+//   exc[]      the absolute `end` of every exception, in hit order
+// i.e. 4 bytes per hit + 8 bytes per 1024 hits + 4 bytes per document change or gap of 4095+ bytes.  Needs
+// value < 2^20.  Hit#start is rebuilt from the key length like in the 8-byte form (ac.cr:270-272).
+constexpr uint32_t kPk4Block = 1024;
+constexpr uint32_t kPk4Exc = 4095;
+
+__device__ __forceinline__ bool pack4_is_exc(const int32_t *hits, uint64_t i, uint32_t t, int32_t &e, uint32_t &step) {
+  e = hits[i * 3 + 1];
+  if (t == 0) {
+    step = kPk4Exc;
+    return true;
+  }
+  const int64_t d = (int64_t)e - (int64_t)hits[(i - 1) * 3 + 1];
+  const bool x = d < 0 || d >= (int64_t)kPk4Exc;
+  step = x ? kPk4Exc : (uint32_t)d;
+  return x;
+}
+
+__global__ __launch_bounds__(kPk4Block) void k_pack4_flags(const int32_t *hits, uint64_t n, uint32_t *blk) {
+  const uint64_t i = (uint64_t)blockIdx.x * kPk4Block + threadIdx.x;
+  int32_t e;
+  uint32_t step;
+  const int x = i < n && pack4_is_exc(hits, i, threadIdx.x, e, step);
+  const int c = __syncthreads_count(x);
+  if (threadIdx.x == 0) blk[blockIdx.x] = (uint32_t)c;
+}
+
+// exclusive scan of blk[0..nb) in place by one workgroup; n_words = n + nb + number of exceptions
+__global__ __launch_bounds__(1024) void k_pack4_scan(uint32_t *blk, uint64_t nb, uint64_t n, unsigned long long *n_words) {
+  __shared__ uint32_t wsum[16];
+  __shared__ unsigned long long run;
+  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) run = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < nb; base += 1024) {
+    const uint64_t i = base + t;
+    const uint32_t v = i < nb ? blk[i] : 0;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o);
+      if ((int)lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t u = 0; u < w; u++) before += wsum[u];
+    const unsigned long long r = run;
+    if (i < nb) blk[i] = (uint32_t)(r + before + inc - v);
+    __syncthreads();
+    if (t == 1023) run = r + before + inc;
+    __syncthreads();
+  }
+  if (t == 0) *n_words = n + nb + run;
+}
+
+__global__ __launch_bounds__(kPk4Block) void k_pack4_write(const int32_t *hits, uint64_t n, uint32_t *words,
+                                                           const uint32_t *blk, int32_t *exc) {
+  __shared__ uint32_t wcnt[16];
+  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * kPk4Block + t;
+  int32_t e = 0;
+  uint32_t step = 0;
+  const bool x = i < n && pack4_is_exc(hits, i, t, e, step);
+  const unsigned long long m = __ballot(x);
+  if (lane == 0) wcnt[w] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (i >= n) return;
+  uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  for (uint32_t u = 0; u < w; u++) rank += wcnt[u];
+  words[i] = ((uint32_t)hits[i * 3 + 2] << 12) | step;
+  if (x) exc[(uint64_t)blk[blockIdx.x] + rank] = e;
+}
+
+__global__ __launch_bounds__(kPk4Block) void k_unpack4(const uint32_t *words, uint64_t n, const uint32_t *blk,
+                                                       const int32_t *exc, const uint2 *key_ln, const uint32_t *key_kc,
+                                                       int chars, int32_t *hits) {
+  __shared__ uint32_t wcnt[16];
+  __shared__ int32_t wagg[16];
+  __shared__ uint32_t wflag[16];
+  __shared__ int32_t stage[kPk4Block * 3];
+  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * kPk4Block + t;
+  const bool valid = i < n;
+  const uint32_t wd = valid ? words[i] : 0u;
+  const uint32_t step = wd & 0xFFFu, value = wd >> 12;
+  const bool f = valid && step == kPk4Exc;
+  const unsigned long long m = __ballot(f);
+  if (lane == 0) wcnt[w] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  for (uint32_t u = 0; u < w; u++) rank += wcnt[u];
+  int32_t x = f ? exc[(uint64_t)blk[blockIdx.x] + rank] : (int32_t)step;
+  // segmented inclusive scan inside the wave: an exception restarts the sum
+  uint32_t fl = f ? 1u : 0u;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t ux = __shfl_up(x, o);
+    const uint32_t uf = __shfl_up(fl, o);
+    if ((int)lane >= o) {
+      if (!fl) x += ux;
+      fl |= uf;
+    }
+  }
+  if (lane == 63) {
+    wagg[w] = x;
+    wflag[w] = fl;
+  }
+  __syncthreads();
+  if (!fl) {  // nothing restarted the sum inside this wave so far: carry what the earlier waves of the block hold
+    int32_t c = 0;
+    for (uint32_t u = 0; u < w; u++) c = wflag[u] ? wagg[u] : c + wagg[u];
+    x += c;
+  }
+  int32_t len = 0;
+  if (valid) len = chars ? (int32_t)key_kc[value] + 1 : (int32_t)key_ln[value].x;
+  stage[t * 3 + 0] = x - len;
+  stage[t * 3 + 1] = x;
+  stage[t * 3 + 2] = (int32_t)value;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * kPk4Block * 3;
+  const uint64_t total = n * 3;
+  for (uint32_t k = 0; k < 3; k++) {
+    const uint64_t j = base + k * kPk4Block + t;
+    if (j < total) hits[j] = stage[k * kPk4Block + t];
+  }
+}
+
+void launch_hits_pack4(const int32_t *hits, uint64_t n, uint32_t *stream_words, unsigned long long *n_words,
+                       void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t nb = (n + kPk4Block - 1) / kPk4Block;
+  uint32_t *words = stream_words, *blk = stream_words + n;
+  int32_t *exc = reinterpret_cast<int32_t *>(stream_words + n + nb);
+  if (nb) hipLaunchKernelGGL(k_pack4_flags, dim3((uint32_t)nb), dim3(kPk4Block), 0, s, hits, n, blk);
+  hipLaunchKernelGGL(k_pack4_scan, dim3(1), dim3(1024), 0, s, blk, nb, n, n_words);
+  if (nb) hipLaunchKernelGGL(k_pack4_write, dim3((uint32_t)nb), dim3(kPk4Block), 0, s, hits, n, words, blk, exc);
+}
+
+void launch_hits_unpack4(const DevAut &A, const uint32_t *stream_words, uint64_t n, int chars, int32_t *hits,
+                         void *stream) {
+  if (!n) return;
+  const uint64_t nb = (n + kPk4Block - 1) / kPk4Block;
+  hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)nb), dim3(kPk4Block), 0, (hipStream_t)stream, stream_words, n,
+                     stream_words + n, reinterpret_cast<const int32_t *>(stream_words + n + nb), A.key_ln, A.key_kc,
+                     chars, hits);
+}
+
 // -------------------------------------------------- device-resident doc offsets
 // The device entry point cannot read its doc offsets on the host: flag[0] |= 1 when they are not the offsets of
 // n_docs documents over exactly n_bytes (doc_off[0] = 0, ascending, doc_off[D] = n_bytes), |= 2 when a document

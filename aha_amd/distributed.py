@@ -14,9 +14,11 @@ RCCL over xGMI on ROCm; "gloo" in the CPU tests):
                         Send/Recv .. GroupEnd under RCCL).  On MI355X's fully
                         connected xGMI mesh every rank then drives its 7 links
                         at once (time ~ 12*max_r H_r / 153 GB/s), where a ring
-                        all-gather would be per-link bound.  packed=True puts
-                        {end, value} pairs on the links (8 B per hit; the start
-                        is end - key length) and rebuilds the triples on arrival.
+                        all-gather would be per-link bound.  exchange="pairs"
+                        puts {end, value} pairs on the links (8 B per hit; the
+                        start is end - key length), exchange="words" a 4-byte
+                        stream (value | step of end); the triples are rebuilt
+                        on arrival.
 
 The automaton is replicated: every rank compiles the same keys (~0.2 s for
 100k keys), which is cheaper than broadcasting and needs no collective.
@@ -52,152 +54,207 @@ def local_shard(corpus, doc_offsets, rank, world):
     return corpus[b0:b1], (doc_offsets[lo:hi + 1] - doc_offsets[lo]).astype(np.uint64), lo
 
 
+PK4_BLOCK = 1024
+PK4_EXC = 4095
+
+
+def pack4_host(hits):
+    """CPU restatement of the 4-byte exchange stream (include/aha_hip.h, aha_ac_hits_pack4_device) for the gloo
+    rehearsal: hits [n,3] int32 CPU tensor -> int32 tensor words[n] . first_exception[nb] . exception_end[...]."""
+    n = int(hits.shape[0])
+    nb = (n + PK4_BLOCK - 1) // PK4_BLOCK
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int32)
+    end = hits[:, 1].to(torch.int64)
+    step = torch.zeros(n, dtype=torch.int64)
+    step[1:] = end[1:] - end[:-1]
+    exc = (step < 0) | (step >= PK4_EXC)
+    exc[::PK4_BLOCK] = True
+    step = torch.where(exc, torch.full_like(step, PK4_EXC), step)
+    words = (hits[:, 2].to(torch.int64) << 12) | step
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    rank = torch.cumsum(exc.to(torch.int64), 0) - exc.to(torch.int64)
+    blk = rank[::PK4_BLOCK].to(torch.int32)
+    assert blk.numel() == nb
+    return torch.cat([words, blk, hits[:, 1][exc].to(torch.int32)])
+
+
+def unpack4_host(stream, n, key_len):
+    """Inverse of pack4_host: -> hits [n,3] int32 (start = end - key length)."""
+    out = torch.zeros((n, 3), dtype=torch.int32)
+    if n == 0:
+        return out
+    nb = (n + PK4_BLOCK - 1) // PK4_BLOCK
+    words = stream[:n].to(torch.int64) & 0xFFFFFFFF
+    exc_end = stream[n + nb:].to(torch.int64)
+    step = words & 0xFFF
+    value = words >> 12
+    exc = step == PK4_EXC
+    x = step.clone()
+    x[exc] = exc_end[: int(exc.sum())]
+    # segmented running sum: an exception restarts it
+    tot = torch.cumsum(x, 0)
+    seg = torch.cumsum(exc.to(torch.int64), 0) - 1
+    head_tot = (tot - x)[exc]  # running total in front of every exception
+    end = tot - head_tot[seg]
+    out[:, 1] = end.to(torch.int32)
+    out[:, 2] = value.to(torch.int32)
+    out[:, 0] = (end - key_len[value].to(torch.int64)).to(torch.int32)
+    return out
+
+
 class HitGatherer:
     """all-gatherv of hit triples ([n,3] int32 tensors) across ranks.
 
-    packed=True (needs `ac`, the rank's automaton -- replicated, so every rank
-    holds the same key lengths): the payload on the links is {end, value} pairs,
-    8 instead of 12 bytes per hit, because Hit#start = Hit#end - len(key[value])
-    (src/aha/ac.cr:270-272); the triples are rebuilt on arrival
-    (aha_ac_hits_pack_device / _unpack_device on device tensors; plain torch
-    indexing on CPU tensors, i.e. in the gloo rehearsal).  xGMI links are the
-    scarce resource of the exchange (one link per peer), HBM bandwidth is not."""
+    What travels on the links is chosen with `exchange` (needs `ac`, the rank's automaton -- replicated, so every
+    rank holds the same key lengths -- for anything but "triples"):
+      "triples"  the 12-byte Hit triples as they are;
+      "pairs"    {end, value}, 8 bytes per hit: Hit#start = Hit#end - len(key[value]) (src/aha/ac.cr:270-272);
+      "words"    the 4-byte stream of include/aha_hip.h (value << 12 | step of `end`; automata below 2^20 keys).
+    The triples are rebuilt on arrival (aha_ac_hits_*_device on device tensors; plain torch on CPU tensors, i.e. in
+    the gloo rehearsal).  xGMI links are the scarce resource of the exchange (one link per peer: ~60 GB/s each way
+    against 8 TB/s of HBM), so bytes are traded for two small kernels.  `packed=True` is the old name of "pairs"."""
 
-    def __init__(self, dist, device, group=None, ac=None, packed=False, chars=False):
+    def __init__(self, dist, device, group=None, ac=None, packed=False, chars=False, exchange=None):
         self.dist = dist
         self.device = device
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self._counts = torch.zeros(self.world, dtype=torch.int64, device=device)
-        self._mine = torch.zeros(1, dtype=torch.int64, device=device)
-        self._buf = None
-        self.packed = bool(packed)
+        self.exchange = exchange or ("pairs" if packed else "triples")
+        if self.exchange not in ("triples", "pairs", "words"):
+            raise ValueError("exchange: triples, pairs or words")
+        self._counts = torch.zeros(self.world * 2, dtype=torch.int64, device=device)
+        self._mine = torch.zeros(2, dtype=torch.int64, device=device)
+        self.packed = self.exchange != "triples"
         self.chars = bool(chars)
         self.ac = ac
+        self._cuda = torch.device(device).type == "cuda"
+        self._pending = {}
+        self._bufs = {}
+        self._send = {}
+        self._land = {}
+        self.last_payload_elems = 0  # int32 elements this rank sent to each peer in the last exchange
         if self.packed:
             if ac is None:
-                raise ValueError("packed exchange needs the automaton (key lengths)")
-            self._klen = None if torch.device(device).type == "cuda" else torch.from_numpy(ac.key_lengths(chars))
-            self._pk = {}  # slot -> (send pairs, recv pairs)
+                raise ValueError("a packed exchange needs the automaton (key lengths)")
+            if self.exchange == "words" and ac.n_keys > (1 << 20):
+                raise ValueError("the 4-byte exchange stream holds key ids below 2^20")
+            self._klen = None if self._cuda else torch.from_numpy(ac.key_lengths(chars))
 
-    # -- packed payload helpers --------------------------------------------------------
-    def _pack(self, hits, n, slot):
-        """hits[:n] -> contiguous [n,2] pairs in a per-slot send buffer."""
-        send, recv = self._pk.get(slot, (None, None))
-        if send is None or send.shape[0] < n:
-            send = torch.empty((n + n // 8 + 16, 2), dtype=torch.int32, device=hits.device)
-        self._pk[slot] = (send, recv)
-        if n:
-            if hits.is_cuda:
-                self.ac.hits_pack_device(hits, n, send)
-            else:
-                send[:n].copy_(hits[:n, 1:3])
-        return send
+    # -- payload: what this rank sends to every peer -----------------------------------
+    def _payload(self, hits, n, slot):
+        """Returns (flat int32 payload tensor, its length in int32 elements).  For "words" the length is only known
+        after the pack kernels ran: it is read from the device together with the counts exchange."""
+        if self.exchange == "triples":
+            return hits.view(-1), 3 * n
+        need = 2 * n + (n + PK4_BLOCK - 1) // PK4_BLOCK + 16  # pairs: 2n; words: 2n + ceil(n/1024) in the worst case
+        send = self._send.get(slot)
+        if send is None or send.numel() < need:
+            send = torch.empty(need + need // 8, dtype=torch.int32, device=hits.device)
+            self._send[slot] = send
+        if self.exchange == "pairs":
+            if n:
+                if hits.is_cuda:
+                    self.ac.hits_pack_device(hits, n, send)
+                else:
+                    send[:2 * n].view(n, 2).copy_(hits[:n, 1:3])
+            return send, 2 * n
+        if hits.is_cuda:
+            self.ac.hits_pack4_device(hits, n, send, self._mine[1:2])
+            return send, None  # length in self._mine[1] (device)
+        w = pack4_host(hits[:n])
+        send[:w.numel()].copy_(w)
+        return send, int(w.numel())
 
-    def _recv_pairs(self, total, slot):
-        send, recv = self._pk.get(slot, (None, None))
-        if recv is None or recv.shape[0] < total:
-            recv = torch.empty((total + total // 8 + 16, 2), dtype=torch.int32, device=self.device)
-        self._pk[slot] = (send, recv)
-        return recv
-
-    def _unpack(self, pairs, lo, hi, out):
-        """pairs[lo:hi] -> out[lo:hi] triples."""
-        n = hi - lo
+    def _rebuild(self, land, elems_lo, n, out_rows):
+        """The payload of one peer (land[elems_lo:...], n hits) -> triples in out_rows ([n,3] view)."""
         if n <= 0:
             return
-        if pairs.is_cuda:
-            self.ac.hits_unpack_device(pairs[lo:hi], n, out[lo:hi], chars=self.chars)
+        if self.exchange == "pairs":
+            pairs = land[elems_lo:elems_lo + 2 * n]
+            if pairs.is_cuda:
+                self.ac.hits_unpack_device(pairs, n, out_rows, chars=self.chars)
+            else:
+                p = pairs.view(n, 2)
+                out_rows[:, 1:3] = p
+                out_rows[:, 0] = p[:, 0] - self._klen[p[:, 1].long()]
         else:
-            p = pairs[lo:hi]
-            out[lo:hi, 1:3] = p
-            out[lo:hi, 0] = p[:, 0] - self._klen[p[:, 1].long()]
+            if land.is_cuda:
+                self.ac.hits_unpack4_device(land[elems_lo:], n, out_rows, chars=self.chars)
+            else:
+                out_rows.copy_(unpack4_host(land[elems_lo:], n, self._klen))
 
     def all_gatherv(self, hits, n):
         """hits: [cap,3] int32 on self.device, first n rows valid.  Returns
         (gathered [sum_n,3] view, counts list); rank r's hits start at
         sum(counts[:r]) -- global order = rank order (contiguous doc ranges)."""
-        if self.packed:
-            self.start(hits, n, slot=2)
-            return self.finish(2)
-        dist = self.dist
-        self._mine[0] = n
-        dist.all_gather_into_tensor(self._counts, self._mine, group=self.group)
-        counts = [int(c) for c in self._counts.tolist()]
-        total = sum(counts)
-        if self._buf is None or self._buf.shape[0] < total:
-            self._buf = torch.empty((total + total // 8 + 16, 3), dtype=torch.int32, device=self.device)
-        out = self._buf
-        base = [0]
-        for c in counts:
-            base.append(base[-1] + c)
-        ops = []
-        for peer in range(self.world):
-            if peer == self.rank:
-                continue
-            if n:
-                ops.append(dist.P2POp(dist.isend, hits[:n], peer, group=self.group))
-            if counts[peer]:
-                ops.append(dist.P2POp(dist.irecv, out[base[peer]:base[peer + 1]], peer, group=self.group))
-        if n:
-            out[base[self.rank]:base[self.rank + 1]].copy_(hits[:n])
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        return out[:total], counts
+        self.start(hits, n, slot=2)
+        return self.finish(2)
 
     # -- overlapped form: the exchange of step i runs beside the match of step i+1 ------
     def start(self, hits, n, slot=0):
         """Issues the all-gatherv of hits[:n] without waiting for the payload
-        (the 8-byte counts exchange is synchronous).  Uses output buffer
-        `slot` (0/1) so that two exchanges can be in flight; the caller must not
+        (the 16-byte counts exchange is synchronous).  Uses output buffer
+        `slot` so that two exchanges can be in flight; the caller must not
         overwrite hits[:n] before finish(slot).  Returns the counts."""
         dist = self.dist
-        if not hasattr(self, "_pending"):
-            self._pending = {}
-            self._bufs = {}
         self.finish(slot)
+        payload, elems = self._payload(hits, n, slot)
         self._mine[0] = n
+        if elems is not None:
+            self._mine[1] = elems
         dist.all_gather_into_tensor(self._counts, self._mine, group=self.group)
-        counts = [int(c) for c in self._counts.tolist()]
+        both = [int(c) for c in self._counts.tolist()]
+        counts, sizes = both[0::2], both[1::2]
         total = sum(counts)
         buf = self._bufs.get(slot)
         if buf is None or buf.shape[0] < total:
             buf = torch.empty((total + total // 8 + 16, 3), dtype=torch.int32, device=self.device)
             self._bufs[slot] = buf
-        base = [0]
-        for c in counts:
+        base, ebase = [0], [0]
+        for c, z in zip(counts, sizes):
             base.append(base[-1] + c)
-        payload, landing = hits, buf
-        if self.packed:  # 8 B per hit on the links; triples rebuilt in finish()
-            payload = self._pack(hits, n, slot)
-            landing = self._recv_pairs(total, slot)
+            ebase.append(ebase[-1] + z)
+        if self.packed:
+            land = self._land.get(slot)
+            if land is None or land.numel() < ebase[-1]:
+                land = torch.empty(ebase[-1] + ebase[-1] // 8 + 16, dtype=torch.int32, device=self.device)
+                self._land[slot] = land
+        else:
+            land, ebase = buf.view(-1), [3 * b for b in base]
+        mine = sizes[self.rank]
+        self.last_payload_elems = mine
         ops = []
         for peer in range(self.world):
             if peer == self.rank:
                 continue
-            if n:
-                ops.append(dist.P2POp(dist.isend, payload[:n], peer, group=self.group))
-            if counts[peer]:
-                ops.append(dist.P2POp(dist.irecv, landing[base[peer]:base[peer + 1]], peer, group=self.group))
+            if mine:
+                ops.append(dist.P2POp(dist.isend, payload[:mine], peer, group=self.group))
+            if sizes[peer]:
+                ops.append(dist.P2POp(dist.irecv, land[ebase[peer]:ebase[peer + 1]], peer, group=self.group))
         if n:
             buf[base[self.rank]:base[self.rank + 1]].copy_(hits[:n])
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        self._pending[slot] = (reqs, buf, total, counts, base)
+        self._pending[slot] = (reqs, buf, total, counts, base, land, ebase)
         return counts
 
     def finish(self, slot=0):
         """Waits for the exchange issued with start(slot); returns (gathered, counts) or None."""
-        if not hasattr(self, "_pending") or slot not in self._pending:
+        if slot not in self._pending:
             return None
-        reqs, buf, total, counts, base = self._pending.pop(slot)
+        reqs, buf, total, counts, base, land, ebase = self._pending.pop(slot)
         for req in reqs:
             req.wait()
-        if self.packed:  # the received pairs of every peer -> triples at their final place
-            pairs = self._pk[slot][1]
-            self._unpack(pairs, 0, base[self.rank], buf)
-            self._unpack(pairs, base[self.rank + 1], total, buf)
+        if self.packed:  # the received payload of every peer -> triples at their final place
+            if self.exchange == "pairs":  # uniform layout: two launches cover all peers
+                lo, hi = base[self.rank], base[self.rank + 1]
+                self._rebuild(land, 0, lo, buf[:lo])
+                self._rebuild(land, ebase[self.rank + 1], total - hi, buf[hi:total])
+            else:
+                for peer in range(self.world):
+                    if peer != self.rank:
+                        self._rebuild(land, ebase[peer], counts[peer], buf[base[peer]:base[peer + 1]])
         return buf[:total], counts
 
     def gather_doc_hit_offsets(self, dho, counts):

@@ -48,9 +48,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
     ap.add_argument("--parity-bytes", type=int, default=32 << 20,
                     help="bytes of the first documents compared with the oracle on every run (the parity gate)")
-    ap.add_argument("--exchange", default="packed", choices=["packed", "triples"],
-                    help="N>1 payload of the all-gatherv: {end,value} pairs (8 B per hit, triples rebuilt on arrival; "
-                         "default) or the 12-byte Hit triples themselves")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "words", "packed", "triples"],
+                    help="N>1 payload of the all-gatherv: the 4-byte stream (value | step of end; default below 2^20 "
+                         "keys), {end,value} pairs (8 B per hit), or the 12-byte Hit triples themselves; packed forms "
+                         "are rebuilt into triples on arrival, inside the timed step")
     ap.add_argument("--gather", default="allgatherv", choices=["allgatherv", "none"],
                     help="N>1: exchange hit buffers over RCCL inside the timed step")
     ap.add_argument("--no-overlap", action="store_true",
@@ -237,7 +238,10 @@ def main():
     if world > 1 and args.gather == "allgatherv":
         from aha_amd.distributed import HitGatherer
 
-        gather = HitGatherer(dist, cdev, ac=ac, packed=args.exchange == "packed", chars=args.chars)
+        if args.exchange == "auto":
+            args.exchange = "words" if K <= (1 << 20) else "packed"
+        xmode = {"words": "words", "packed": "pairs", "triples": "triples"}[args.exchange]
+        gather = HitGatherer(dist, cdev, ac=ac, exchange=xmode, chars=args.chars)
 
     overlap = gather is not None and not args.no_overlap
     if overlap:
@@ -313,7 +317,9 @@ def main():
         scan_ms = timed(lambda: ac.match_batch_device(d_corpus, d_doc, d_out, d_dho, chars=args.chars))
         exch_ms = timed(lambda: gather.all_gatherv(d_out if cdev == dev else d_out[:n_hits].cpu(), n_hits))
         breakdown = {"scan_only_ms": round(scan_ms, 4), "exchange_only_ms": round(exch_ms, 4),
-                     "step_ms": round(ms_per_step, 4), "overlapped": bool(overlap)}
+                     "step_ms": round(ms_per_step, 4), "overlapped": bool(overlap), "exchange": args.exchange,
+                     "wire_bytes_per_hit": round(4.0 * gather.last_payload_elems / max(n_hits, 1), 3),
+                     "wire_bytes_per_peer": int(4 * gather.last_payload_elems)}
         log(f"breakdown: scan only {scan_ms:.3f} ms, exchange only {exch_ms:.3f} ms, step {ms_per_step:.3f} ms")
     if gather is not None and not args.no_strong:
         # ---- strong scaling: ONE corpus (rank 0's) cut into contiguous byte-balanced document ranges
@@ -332,7 +338,7 @@ def main():
                 raise
             sn = e.required
         s_out = torch.zeros((sn + 1024, 3), dtype=torch.int32, device=dev)
-        sg = HitGatherer(dist, cdev, ac=ac, packed=args.exchange == "packed", chars=args.chars)
+        sg = HitGatherer(dist, cdev, ac=ac, exchange=xmode, chars=args.chars)
 
         def match_fn(c, d):
             n = ac.match_batch_device(c, d, s_out, s_dho, chars=args.chars)

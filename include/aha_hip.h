@@ -197,6 +197,17 @@ int32_t aha_ac_hits_pack_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, i
 int32_t aha_ac_hits_unpack_device(aha_ac *ac, const int32_t *d_pairs, uint64_t n, int32_t char_offsets,
                                   aha_hit *d_hits, void *stream);
 
+/* The 4-byte form of the same exchange (automata with fewer than 2^20 keys).  Hits of a batch come in per-document
+ * order with ascending `end`, so the stream carries value << 12 | (end - previous end) in one word per hit, and the
+ * absolute `end` only for the first hit of every 1024, for a document change and for a gap of 4095 or more bytes:
+ *   d_words = words[n] . first_exception[ceil(n/1024)] . exception_end[...]
+ * pack4 needs cap_words >= 2 n + ceil(n/1024) (the worst case) and writes the real length -- what has to travel --
+ * into *d_n_words (device memory); unpack4 takes the stream and n.  Asynchronous on `stream`. */
+int32_t aha_ac_hits_pack4_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, uint32_t *d_words,
+                                 uint64_t cap_words, uint64_t *d_n_words, void *stream);
+int32_t aha_ac_hits_unpack4_device(aha_ac *ac, const uint32_t *d_words, uint64_t n, int32_t char_offsets,
+                                   aha_hit *d_hits, void *stream);
+
 /* Copies one array of the automaton image (as uploaded to HBM) into buf;
  * returns its size in bytes (call with cap_bytes = 0 to size the buffer).
  * Data only -- used by host-logic tests and debugging tools. */
@@ -256,7 +267,8 @@ typedef struct {
   float ms_download;         /* gathered hits -> caller's buffer */
   uint64_t n_hits;
   uint32_t exchange;         /* 1 = RCCL between distinct devices, 0 = device-to-device copies on one device */
-  uint32_t reserved;
+  uint32_t packed;           /* 1 = the 4-byte exchange stream travelled, 0 = the 12-byte triples (2^20 keys or more) */
+  uint64_t wire_bytes;       /* payload bytes of all shards together (each goes to every other shard) */
 } aha_group_timing;
 
 int32_t aha_group_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, uint32_t n_keys,

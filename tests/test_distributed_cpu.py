@@ -51,6 +51,16 @@ def _worker(rank, world, port, keys_blob, keys_offs, corpus, doc, out_q):
         for slot in (0, 1):
             oh, oc = gp.finish(slot)
             assert oc == counts and torch.equal(oh, allh)
+        # 4-byte exchange stream (value << 12 | step of `end`, exceptions aside): same result
+        gw = HitGatherer(dist, torch.device("cpu"), ac=pac, exchange="words")
+        wh, wc = gw.all_gatherv(t, len(hits))
+        assert wc == counts and torch.equal(wh, allh)
+        assert gw.last_payload_elems <= len(hits) + len(hits) // 8 + 64  # about 4 bytes per hit on the wire
+        gw.start(t, len(hits), 0)
+        gw.start(t, len(hits), 1)
+        for slot in (0, 1):
+            oh, oc = gw.finish(slot)
+            assert oc == counts and torch.equal(oh, allh)
         alld = g.gather_doc_hit_offsets(torch.from_numpy(dho.astype(np.int64)), counts)
         # the strong-scaling leg of bench.py, step for step (the matcher is the oracle here, the GPU there)
         from aha_amd.distributed import stream_digest, strong_scaling_pass
@@ -94,6 +104,34 @@ def test_allgatherv_matches_single_process(world):
         assert sum(counts) == len(ref_hits)
         assert np.array_equal(allh, ref), f"rank {rank}: gathered hits differ"
         assert np.array_equal(alld.astype(np.uint64), ref_dho), f"rank {rank}: doc offsets differ"
+
+
+def test_pack4_host_round_trip_and_format():
+    """The CPU restatement of the 4-byte exchange stream (the GPU kernels are compared with it in the GPU suite)."""
+    from aha_amd.distributed import PK4_BLOCK, pack4_host, unpack4_host
+
+    rng = np.random.default_rng(3)
+    klen = torch.from_numpy(rng.integers(1, 25, size=1 << 20).astype(np.int32))
+    for n, max_step in ((0, 10), (1, 10), (1023, 50), (1024, 50), (1025, 50), (5000, 9000), (3000, 4100)):
+        docs = rng.integers(0, 2, size=n).cumsum()  # a document change resets `end`
+        step = rng.integers(0, max_step, size=n)
+        end = np.zeros(n, dtype=np.int64)
+        run = 0
+        for i in range(n):
+            run = step[i] + 1 if (i == 0 or docs[i] != docs[i - 1]) else run + step[i]
+            end[i] = run + 30
+        value = rng.integers(0, 1 << 20, size=n)
+        hits = torch.zeros((n, 3), dtype=torch.int32)
+        hits[:, 1] = torch.from_numpy(end.astype(np.int32))
+        hits[:, 2] = torch.from_numpy(value.astype(np.int32))
+        hits[:, 0] = hits[:, 1] - klen[hits[:, 2].long()]
+        w = pack4_host(hits)
+        nb = (n + PK4_BLOCK - 1) // PK4_BLOCK
+        assert w.dtype == torch.int32 and n + nb <= w.numel() <= 2 * n + nb
+        if n:
+            first = w[n:n + nb].tolist()
+            assert first[0] == 0 and first == sorted(first)
+        assert torch.equal(unpack4_host(w, n, klen), hits)
 
 
 def test_partition_is_contiguous_and_balanced():

@@ -652,6 +652,120 @@ def test_exchange_pairs_round_trip(chars):
     assert np.array_equal(ac.key_lengths(chars)[hits["value"]], hits["end"] - hits["start"])
 
 
+def test_exchange_words_round_trip(engine):
+    """The 4-byte exchange stream (aha_ac_hits_pack4_device / _unpack4_device): bit-identical to its CPU restatement
+    (aha_amd/distributed.py pack4_host) and a lossless round trip -- dense hits, sparse hits with gaps beyond the
+    12-bit step, many tiny documents, char offsets, zero hits, a count that is not a multiple of 1024."""
+    if engine != "v2":
+        pytest.skip("independent of the match engine")
+    import torch
+
+    from aha_amd.distributed import PK4_BLOCK, pack4_host
+
+    dev = torch.device("cuda:0")
+    blob, offs, nf = synth.keys(3, K=20_000)
+    g = AC.compile_packed(blob, offs)
+    cases = []
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 22, doc_bytes=1 << 16)
+    cases.append((corpus, doc, False))
+    cases.append((corpus, doc, True))
+    cases.append((corpus[: 1 << 20], np.arange(0, (1 << 20) + 1, 64, dtype=np.uint64), False))  # 16 Ki tiny documents
+    sparse = np.full(1 << 22, 0x20, dtype=np.uint8)  # mostly blanks: a key every ~9000 bytes
+    rng = np.random.default_rng(5)
+    for p in range(100, sparse.size - 100, 9000):
+        k = int(rng.integers(0, 20_000))
+        kb = blob[int(offs[k]):int(offs[k + 1])]
+        sparse[p:p + kb.size] = kb
+    cases.append((sparse, np.array([0, sparse.size], dtype=np.uint64), False))
+    cases.append((np.full(4096, 0x20, dtype=np.uint8), np.array([0, 4096], dtype=np.uint64), False))  # zero hits
+    for corpus, doc, chars in cases:
+        dc = torch.from_numpy(corpus).to(dev)
+        dd = torch.from_numpy(doc.astype(np.int64)).to(dev)
+        out = torch.zeros((corpus.size // 4 + 16, 3), dtype=torch.int32, device=dev)
+        n = g.match_batch_device(dc, dd, out, None, chars=chars)
+        nb = (n + PK4_BLOCK - 1) // PK4_BLOCK
+        words = torch.full((2 * n + nb + 8,), -1, dtype=torch.int32, device=dev)
+        n_words = torch.zeros(1, dtype=torch.int64, device=dev)
+        g.hits_pack4_device(out, n, words, n_words)
+        torch.cuda.synchronize()
+        want = pack4_host(out[:n].cpu())
+        assert int(n_words[0]) == want.numel()
+        assert torch.equal(words[: want.numel()].cpu(), want)
+        back = torch.full((n + 3, 3), -7, dtype=torch.int32, device=dev)
+        g.hits_unpack4_device(words, n, back, chars=chars)
+        torch.cuda.synchronize()
+        assert torch.equal(back[:n], out[:n]) and bool((back[n:] == -7).all())
+        if n > 50_000 and not chars:
+            assert want.numel() < n + n // 16  # about 4 bytes per hit where hits are dense
+    with pytest.raises(AhaError):
+        g.hits_pack4_device(torch.zeros((5000, 3), dtype=torch.int32, device=dev), 5000,
+                            torch.zeros(5000, dtype=torch.int32, device=dev), n_words)  # capacity below 2n + n/1024
+
+
+class _LoopbackDist:
+    """Stand-in for torch.distributed with two ranks whose peer is a copy of this rank: what rank 0 sends to rank 1
+    comes back as rank 1's payload.  Exercises HitGatherer's device path (pack kernels, sizes read from the device,
+    rebuild kernels) on the one GPU of the test box; the real transports are covered by the gloo tests (CPU tensors)
+    and by bench.py --gpus N (RCCL)."""
+
+    isend, irecv = "isend", "irecv"
+
+    class P2POp:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def get_rank(self, group=None):
+        return 0
+
+    def get_world_size(self, group=None):
+        return 2
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        out.view(2, -1)[:] = inp
+
+    def batch_isend_irecv(self, ops):
+        sends = [o.tensor for o in ops if o.op == "isend"]
+        recvs = [o.tensor for o in ops if o.op == "irecv"]
+        assert len(sends) == len(recvs) == 1
+        recvs[0].copy_(sends[0])
+        return [self._Done()]
+
+
+@pytest.mark.parametrize("exchange", ["triples", "pairs", "words"])
+def test_hit_gatherer_device_path(engine, exchange):
+    if engine != "v2":
+        pytest.skip("independent of the match engine")
+    import torch
+
+    from aha_amd.distributed import HitGatherer
+
+    dev = torch.device("cuda:0")
+    blob, offs, nf = synth.keys(3, K=20_000)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 22, doc_bytes=1 << 16)
+    g = AC.compile_packed(blob, offs)
+    dc = torch.from_numpy(corpus).to(dev)
+    dd = torch.from_numpy(doc.astype(np.int64)).to(dev)
+    out = torch.zeros((corpus.size // 4, 3), dtype=torch.int32, device=dev)
+    n = g.match_batch_device(dc, dd, out, None)
+    hg = HitGatherer(_LoopbackDist(), dev, ac=g, exchange=exchange)
+    allh, counts = hg.all_gatherv(out, n)
+    assert counts == [n, n]
+    assert torch.equal(allh[:n], out[:n]) and torch.equal(allh[n:], out[:n])
+    hg.start(out, n, 0)
+    hg.start(out, n, 1)
+    for slot in (0, 1):
+        h2, c2 = hg.finish(slot)
+        assert c2 == counts and torch.equal(h2, allh)
+    per_hit = 4.0 * hg.last_payload_elems / n
+    assert per_hit == {"triples": 12.0, "pairs": 8.0}.get(exchange, per_hit) and per_hit <= 12.0
+    if exchange == "words":
+        assert per_hit < 4.2
+
+
 def test_group_of_shards_on_one_device(engine):
     """aha_group_match_batch with three shards on cuda:0 (device list [0, 0, 0]): partition, concurrent matches on
     three handles / streams, all-gatherv by device-to-device copies -- the RCCL leg needs distinct devices and is
@@ -670,6 +784,7 @@ def test_group_of_shards_on_one_device(engine):
         assert np.array_equal(gd, od) and gh.tobytes() == oh.tobytes()
     t = grp.last_timing()
     assert t["n_devices"] == 3 and t["exchange"] == 0 and t["n_hits"] == len(oh)
+    assert t["packed"] == 1 and t["wire_bytes"] < 4.3 * len(oh)  # the 4-byte stream travelled between the shards
     # ragged: fewer documents than shards, empty documents, an empty batch
     g2 = ACGroup.compile(["ab", "b"], [0, 0, 0, 0])
     o2 = orc.AC.compile(["ab", "b"])

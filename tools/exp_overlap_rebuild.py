@@ -1,0 +1,62 @@
+"""Experiment: does the rebuild of the peers' exchange streams (7 x unpack4 of one rank's hits = what an 8-GPU step
+receives) hide under the match of the next step?  Two host threads, two streams, one GPU."""
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from aha_amd import AC, synth
+
+n_bytes = 1 << 30
+blob, offs, nf = synth.keys(3)
+corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=n_bytes)
+ac = AC.compile_packed(blob, offs)
+dev = torch.device("cuda:0")
+dc = torch.from_numpy(corpus).to(dev)
+dd = torch.from_numpy(doc.astype(np.int64)).to(dev)
+out = torch.zeros((n_bytes // 16, 3), dtype=torch.int32, device=dev)
+dho = torch.zeros(doc.size, dtype=torch.int64, device=dev)
+n = ac.match_batch_device(dc, dd, out, dho)
+words = torch.zeros(2 * n + n // 1024 + 64, dtype=torch.int32, device=dev)
+nw = torch.zeros(1, dtype=torch.int64, device=dev)
+ac.hits_pack4_device(out, n, words, nw)
+allh = torch.zeros((8 * n, 3), dtype=torch.int32, device=dev)
+out2 = torch.zeros_like(out)
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+K = 10
+
+
+def match_loop():
+    for _ in range(K):
+        ac.match_batch_device(dc, dd, out2, dho, stream=sa.cuda_stream)
+
+
+def rebuild_loop():
+    for _ in range(K):
+        ac.hits_pack4_device(out, n, words, nw, stream=sb.cuda_stream)
+        for p in range(1, 8):
+            ac.hits_unpack4_device(words, n, allh[p * n:(p + 1) * n], stream=sb.cuda_stream)
+    sb.synchronize()
+
+
+def run(fns):
+    ths = [threading.Thread(target=f) for f in fns]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / K * 1e3
+
+
+for fns, name in (([match_loop], "match alone"), ([rebuild_loop], "pack + 7 rebuilds alone"),
+                  ([match_loop, rebuild_loop], "both, two streams")):
+    run(fns)
+    print(f"{name}: {run(fns):.3f} ms per step", flush=True)

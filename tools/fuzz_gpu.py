@@ -1,7 +1,7 @@
 """Differential fuzzing of the HIP path against the CPU oracle (test tooling, run on the GPU box):
 random automata (small alphabets -> deep fail links, UTF-8-like bytes, nested keys), random batches
 (ragged documents, NUL bytes), random image variants (compact/wide, capped LDS prefix, shadow fail
-links on/off, two-pass engine).  python tools/fuzz_gpu.py [seconds] [seed]"""
+links on/off, two-pass and position-parallel engines), match_longest against the independent model.  python tools/fuzz_gpu.py [seconds] [seed]"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -9,13 +9,14 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 import numpy as np
 import pyoracle as orc
 from aha_amd import AC
+from pymodel import ModelAC
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
 ALPHABETS = [b"ab", b"abc", b"abcd", b"ab\xe4\xb8\x80", b"abcdefgh", b"xyz\xd0\xb0\xd1\x8f\xe4\xb8\xad\xe5\x9b\xbd",
              bytes(range(0x61, 0x7b)), bytes(range(1, 256))]
-n_cases = n_hits = 0
+n_cases = n_hits = n_long = 0
 seed = seed0
 while time.time() < t_end:
     rng = random.Random(seed)
@@ -36,7 +37,7 @@ while time.time() < t_end:
             keys.append(k)
     env = {"AHA_LDS_SLOTS": rng.choice([None, None, "512", "1024", "4096"]),
            "AHA_SHADOW_FAIL": rng.choice([None, None, None, "0"]),
-           "AHA_ENGINE": rng.choice([None, None, None, "v1"]),
+           "AHA_ENGINE": rng.choice([None, None, "pp", "pp", "v1"]),
            "AHA_DIRECT": rng.choice([None, None, "0"])}
     for k, v in env.items():
         if v is None:
@@ -73,7 +74,18 @@ while time.time() < t_end:
             sys.exit(1)
         n_cases += 1
         n_hits += len(gh)
+        if text.size <= 20000 and len(keys) <= 2000 and rng.random() < 0.5:
+            # match_longest against the independent restatement (tests/pymodel.py), first document of the batch
+            m = ModelAC(keys)
+            d0 = bytes(text[int(doc[0]):int(doc[1])]) if doc.size > 1 else b""
+            for inter in (False, True):
+                got = [(h.start, h.end, h.value) for h in ac.match_longest(d0, inter)]
+                if got != m.match_longest(d0, inter):
+                    print("LONGEST MISMATCH seed", seed, "keys", len(keys), "env", env, "wide", wide, "n", len(d0),
+                          "intersectable", inter, flush=True)
+                    sys.exit(1)
+            n_long += 1
     seed += 1
     if seed % 5 == 0:
         print(f"[fuzz] {seed - seed0} automata, {n_cases} batches, {n_hits} hits ok", flush=True)
-print(f"fuzz ok: {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")
+print(f"fuzz ok: {n_long} match_longest documents, {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")

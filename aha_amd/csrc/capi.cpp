@@ -17,6 +17,7 @@
 #include "automaton.hpp"
 #include "image.hpp"
 #include "pp.hpp"
+#include "unit.hpp"
 
 using namespace aha;
 
@@ -68,6 +69,9 @@ struct aha_ac {
   uint32_t v2_grid = 0;
   uint32_t v2_bpc = 1;
   uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
+  // character-level image (unit.hpp, scan_unit.hip)
+  UnitImage unit;
+  bool unit_ok = false;  // uploaded and usable on the device
   // position-parallel engine (scan_pp.hip)
   PpTables pp;
   bool pp_ok = false;
@@ -665,6 +669,10 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   ac->s2_lo = shadow ? pl.seg_start[3] : 0;
   ac->s2_hi = shadow ? pl.deep_fail_start : 0;
   build_pp(ac->aut, ac->compact, 0, ac->pp);
+  {
+    const char *eng = getenv("AHA_ENGINE");
+    build_unit(ac->aut, ac->unit, eng && strcmp(eng, "unit") == 0);
+  }
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     int n = aha_device_count();
     if (n <= 0) {
@@ -821,6 +829,11 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->fail_s1_lo = ac->s1_lo;
   info->fail_s2_lo = ac->s2_lo;
   info->fail_hdr_lo = ac->s2_hi;
+  info->unit_enabled = ac->unit.ok ? 1u : 0u;
+  info->unit_slots = ac->unit.n_slots;
+  info->unit_lo3 = ac->unit.lo3;
+  info->unit_n3 = ac->unit.n3;
+  info->unit_multi_permille = ac->unit.multi_permille;
   info->pp_enabled = ac->pp.ok ? 1u : 0u;
   info->pp_bloom_words = (uint32_t)ac->pp.bloom.size();
   info->pp_entries = ac->pp.n_entries;
@@ -886,6 +899,18 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
     case AHA_IMG_PP_BLOOM:
       src = ac->pp.bloom.data();
       bytes = ac->pp.bloom.size() * 4;
+      break;
+    case AHA_IMG_UNIT_SLOTS:
+      src = ac->unit.slots.data();
+      bytes = ac->unit.slots.size() * 8;
+      break;
+    case AHA_IMG_UNIT_ROOT:
+      src = ac->unit.root.data();
+      bytes = ac->unit.root.size() * 4;
+      break;
+    case AHA_IMG_UNIT_END_INFO:
+      src = ac->unit.end_info.data();
+      bytes = ac->unit.end_info.size() * 4;
       break;
     default:
       return AHA_E_INVALID;

@@ -101,7 +101,13 @@ typedef struct {
   uint32_t slot_bytes;      /* 4 (compact) or 8 (wide) */
   uint32_t lds_slots;       /* slots of the image cached in LDS by the match kernel */
   int32_t device;           /* device the image lives on, -1 if host only */
-  uint32_t reserved0[5];    /* (fields of the removed boundary-filter mode) */
+  /* Character-level image (engine 4; aha_amd/csrc/unit.hpp): 1 when every key is a sequence of UTF-8-shaped units
+   * (and at least 30 % of the key bytes lie in multi-byte units): plain byte-offset matches then take one step per
+   * character instead of one per byte. */
+  uint32_t unit_enabled;
+  uint32_t unit_slots;          /* 8-byte slots of its double array */
+  uint32_t unit_lo3, unit_n3;   /* three-byte units with first byte 0xE0 + lo3 .. + n3 - 1: root transitions kept in LDS */
+  uint32_t unit_multi_permille; /* key bytes in multi-byte units, per 1000 */
   uint32_t reserved;
   /* Shadow fail links (all 0 = every state has a fail header at slot[base]).  Otherwise only the root and the
    * states with base >= fail_hdr_lo own one; for the others the fail target follows from the last input bytes:
@@ -218,7 +224,10 @@ enum {
   AHA_IMG_KEY_CNT = 3, /* uint32[K] */
   AHA_IMG_KEY_KC = 4,  /* uint32[K] */
   AHA_IMG_PP_T2 = 7,   /* uint32[4096]: 2-bit entries of the position-parallel engine's pair table */
-  AHA_IMG_PP_BLOOM = 8 /* uint32[pp_bloom_words] */
+  AHA_IMG_PP_BLOOM = 8, /* uint32[pp_bloom_words] */
+  AHA_IMG_UNIT_SLOTS = 9,     /* uint64[unit_slots]: lo = base | END << 31 | FAILROOT << 30, hi = unit code (unit.hpp) */
+  AHA_IMG_UNIT_ROOT = 10,     /* uint32[0x10880]: the root's transitions, indexed by unit code */
+  AHA_IMG_UNIT_END_INFO = 11  /* uint32[unit_slots]: key id | min(chain length, 255) << 24, or 0xFFFFFFFF */
 };
 int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_bytes);
 

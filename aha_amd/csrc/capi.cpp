@@ -72,6 +72,8 @@ struct aha_ac {
   // character-level image (unit.hpp, scan_unit.hip)
   UnitImage unit;
   bool unit_ok = false;  // uploaded and usable on the device
+  UnitDev udev{};
+  const uint32_t *d_unit_end_info = nullptr;
   // position-parallel engine (scan_pp.hip)
   PpTables pp;
   bool pp_ok = false;
@@ -315,6 +317,22 @@ void v2_setup(aha_ac *ac) {
   if (reserve < 0 || reserve >= cus) reserve = 0;
   ac->v2_grid = (uint32_t)(cus - reserve) * ac->v2_bpc;
   ac->v2_ok = true;
+  // character-level engine (unit.hpp): one step per UTF-8-shaped unit (AHA_ENGINE=unit built the image)
+  if (ac->unit.ok) {
+    uint32_t n3_max = 0;
+    while (n3_max < 16 && unit_lds_bytes(n3_max + 1) <= kLdsPerCU) n3_max++;
+    uint32_t n3 = std::min(ac->unit.n3, n3_max);
+    const uint64_t *us = nullptr;
+    if (unit_prepare(n3) == 0 && upload(ac, ac->unit.slots, &us) == AHA_OK &&
+        upload(ac, ac->unit.root, &ac->udev.root) == AHA_OK && upload(ac, ac->unit.end_info, &ac->d_unit_end_info) == AHA_OK) {
+      ac->udev.slots = reinterpret_cast<const uint2 *>(us);
+      ac->udev.n_slots = ac->unit.n_slots;
+      ac->udev.lo3 = ac->unit.lo3;
+      ac->udev.n3 = n3;
+      ac->udev.max_len = ac->aut.max_key_len;
+      ac->unit_ok = true;
+    }
+  }
   // position-parallel engine (pp.hpp): bit-exact, but on the BASELINE shapes still slower than the single-traversal
   // engine (DESIGN.md section 4.5 has the measured budget), so it is opt-in: AHA_ENGINE=pp
   if (ac->pp.ok && eng && strcmp(eng, "pp") == 0) {
@@ -440,11 +458,20 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[0], s));
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
-  v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+  // byte offsets through the event regions: the character-level traversal where the key set has a unit image
+  const bool unit = ac->unit_ok && direct && !M.chars;
+  DevAut post = ac->dev;
+  if (unit) {
+    post.end_info = ac->d_unit_end_info;  // events carry bases of the unit image
+    post.compact = 1;
+    unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+  } else {
+    v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+  }
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
   if (direct) {
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
-    v2_launch_direct_post(ac->dev, M, s, prof ? (void *)sc->ev[3] : nullptr);
+    v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr);
   } else {
     v2_launch_chunk_scan(M, s);
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
@@ -463,7 +490,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
-    t.engine = 2;
+    t.engine = unit ? 4 : 2;
     t.chunk_bytes = M.S;
     t.n_kernels = 9;
     (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
@@ -670,8 +697,10 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   ac->s2_hi = shadow ? pl.deep_fail_start : 0;
   build_pp(ac->aut, ac->compact, 0, ac->pp);
   {
+    // character-level image: opt-in (AHA_ENGINE=unit) -- bit-exact, but not faster than the single-traversal engine on
+    // the BASELINE shapes, and building it takes longer than the rest of compile
     const char *eng = getenv("AHA_ENGINE");
-    build_unit(ac->aut, ac->unit, eng && strcmp(eng, "unit") == 0);
+    if (eng && strcmp(eng, "unit") == 0) build_unit(ac->aut, ac->unit, true);
   }
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     int n = aha_device_count();

@@ -104,6 +104,18 @@ struct V2Args {
   uint64_t *doc_hit_off;
 };
 
+// ---- character-level engine (scan_unit.hip, unit.hpp) ---------------------------
+struct UnitDev {
+  const uint2 *slots;    // [n_slots] {lo, hi} entries
+  const uint32_t *root;  // [kUCodes] the root's transitions by unit code
+  uint32_t n_slots;
+  uint32_t lo3, n3;      // three-byte units of the lead bytes 0xE0 + lo3 .. + n3 - 1: root transitions in LDS
+  uint32_t max_len;      // longest key, bytes
+};
+size_t unit_lds_bytes(uint32_t n3);
+int unit_prepare(uint32_t n3);  // raises the dynamic-LDS limit; hipError_t as int
+void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream);
+
 // ---- position-parallel engine (scan_pp.hip, pp.hpp) ---------------------------
 struct PpArgs {
   const uint8_t *text;       // 16-byte aligned

@@ -186,7 +186,9 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     for (uint32_t t = first[s]; t < first[s + 1]; t++) {
       const uint32_t c = tr[t].child;
       if (s == 0) {
-        u.root[tr[t].code] = base[c] | (a.key_of[c] >= 0 ? 0x80000000u : 0u);
+        uint32_t flt = 0;
+        for (uint32_t q = first[c]; q < first[c + 1]; q++) flt |= 1u << u_fbit(tr[q].code);
+        u.root[tr[t].code] = base[c] | (flt << 21) | (a.key_of[c] >= 0 ? 0x80000000u : 0u);
         if (tr[t].code >= kUCode3) cnt3[(tr[t].code - kUCode3) >> 12]++;
       } else {
         u.slots[b ^ tr[t].code] = entry(tr[t].code, base[c], a.key_of[c] >= 0, c);

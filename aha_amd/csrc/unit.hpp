@@ -35,7 +35,9 @@
 //               to the root itself: falling INTO it by a fail link is the one way to be in a state without having read
 //               the entry that leads to it
 // A fail base of 0 is the root (base 0, owns no slot).  The root's transitions live in a directly indexed table:
-// root[code] = child base | END << 31 (a depth-1 state fails to the root).
+// root[code] = child base | filter << 21 | END << 31 (a depth-1 state fails to the root).  `filter` is an 8-bit Bloom
+// filter over the unit codes the depth-1 state has transitions on (bit u_fbit(code)): most units that follow a
+// character do not continue a key, and a clear bit answers that without the probe.
 #pragma once
 
 #include <cstdint>
@@ -57,6 +59,8 @@ AHA_HD inline bool u_end(uint32_t lo) { return (lo >> 31) != 0; }
 AHA_HD inline uint32_t u_code(uint32_t hi) { return hi & 0x1FFFFu; }
 AHA_HD inline uint32_t u_fail(uint32_t lo, uint32_t hi) { return ((lo >> 21) & 0x3FFu) | (((hi >> 17) & 0x7FFu) << 10); }
 AHA_HD inline bool u_ffr(uint32_t hi) { return ((hi >> 28) & 1u) != 0; }
+AHA_HD inline uint32_t u_fbit(uint32_t code) { return (code ^ (code >> 4) ^ (code >> 9)) & 7u; }
+AHA_HD inline uint32_t u_filter(uint32_t root_entry) { return (root_entry >> 21) & 0xFFu; }
 
 struct UnitImage {
   bool ok = false;

@@ -383,6 +383,10 @@ def main():
         # k2_traverse: corpus + doc offsets + automaton image in; its event records are scratch
         dom, dom_ms = "k2_traverse", avg["ms_count"]
         alg_bytes = n_bytes + 8 * (D + 1) + A
+    elif engine == 4:
+        # character-level engine: ku_traverse reads the corpus, the doc offsets and the unit image
+        dom, dom_ms = "ku_traverse", avg["ms_count"]
+        alg_bytes = n_bytes + 8 * (D + 1) + A
     elif engine == 3:
         # position-parallel engine: ms_count = k_pp_filter (one coalesced pass over the corpus + its two tables);
         # ms_scan = the exact pass (k_pp_walk + k_pp_deep + k_pp_order) is longer but is not one kernel

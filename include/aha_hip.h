@@ -101,9 +101,9 @@ typedef struct {
   uint32_t slot_bytes;      /* 4 (compact) or 8 (wide) */
   uint32_t lds_slots;       /* slots of the image cached in LDS by the match kernel */
   int32_t device;           /* device the image lives on, -1 if host only */
-  /* Character-level image (engine 4; aha_amd/csrc/unit.hpp): 1 when every key is a sequence of UTF-8-shaped units
-   * (and at least 30 % of the key bytes lie in multi-byte units): plain byte-offset matches then take one step per
-   * character instead of one per byte. */
+  /* Character-level image (engine 4; aha_amd/csrc/unit.hpp), built when AHA_ENGINE=unit and every key is a sequence
+   * of UTF-8-shaped units: plain byte-offset matches then take one step per character instead of one per byte
+   * (bit-exact; opt-in because it is not faster than engine 2 on the measured shapes). */
   uint32_t unit_enabled;
   uint32_t unit_slots;          /* 8-byte slots of its double array */
   uint32_t unit_lo3, unit_n3;   /* three-byte units with first byte 0xE0 + lo3 .. + n3 - 1: root transitions kept in LDS */

@@ -40,19 +40,22 @@ class UnitSim:
         n = len(t)
         out = []
         B, fb, ffr = 0, 0, True
+        flt = 0xFF  # filter of the current state (depth-1 states carry one, others pass everything)
         p = 0
         trips = 0
+        self.probes = 0
         while p < n:
             code, L = self.unit_at(t, p, n)
             if code == BAD:
-                B, fb, ffr = 0, 0, True
+                B, fb, ffr, flt = 0, 0, True, 0xFF
                 p += L
                 continue
             while True:  # the trips of this unit
                 trips += 1
                 lo = hi = 0
                 hit = False
-                if B != 0:
+                if B != 0 and (flt >> ((code ^ (code >> 4) ^ (code >> 9)) & 7)) & 1:
+                    self.probes += 1
                     e = int(self.slots[B ^ code])
                     lo, hi = e & 0xFFFFFFFF, e >> 32
                     hit = (hi & 0x1FFFF) == code
@@ -61,12 +64,15 @@ class UnitSim:
                     fb = ((lo >> 21) & 0x3FF) | (((hi >> 17) & 0x7FF) << 10)
                     ffr = bool((hi >> 28) & 1)
                     end = bool(lo >> 31)
+                    flt = 0xFF
                     break
                 if B == 0 or fb == 0:  # the fail link is the root: its table
                     r = int(self.root[code])
                     B, fb, ffr = r & 0x1FFFFF, 0, True
+                    flt = (r >> 21) & 0xFF
                     end = bool(r >> 31)
                     break
+                flt = 0xFF
                 if ffr:  # fall to the fail state, whose own fail link is the root
                     B, fb, ffr = fb, 0, True
                     continue

@@ -1,7 +1,7 @@
 """Differential fuzzing of the HIP path against the CPU oracle (test tooling, run on the GPU box):
 random automata (small alphabets -> deep fail links, UTF-8-like bytes, nested keys), random batches
 (ragged documents, NUL bytes), random image variants (compact/wide, capped LDS prefix, shadow fail
-links on/off, two-pass and position-parallel engines), match_longest against the independent model.  python tools/fuzz_gpu.py [seconds] [seed]"""
+links on/off, two-pass, position-parallel and character-level engines), match_longest against the independent model.  python tools/fuzz_gpu.py [seconds] [seed]"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -25,6 +25,16 @@ while time.time() < t_end:
     lo, hi = rng.choice([(1, 3), (1, 8), (2, 12), (1, 24)])
     keys, seen = [], set()
     tries = 0
+    if rng.random() < 0.3:  # whole UTF-8 characters as the alphabet (eligible for the character-level engine); the
+        # text below is still cut anywhere and mixed with malformed sequences
+        units = [c.encode() for c in rng.sample("abcéжя中国人我是々 ", rng.randint(2, 8))]
+        while len(keys) < nk and tries < nk * 20:
+            tries += 1
+            k = b"".join(rng.choice(units) for _ in range(rng.randint(1, max(1, hi // 2))))
+            if k not in seen and len(k) <= 64:
+                seen.add(k)
+                keys.append(k)
+        alpha = b"".join(units) + b"\xe4\xb8\xf0"
     while len(keys) < nk and tries < nk * 20:
         tries += 1
         if keys and rng.random() < 0.3:  # nested / overlapping keys: suffixes and extensions of existing ones
@@ -37,7 +47,7 @@ while time.time() < t_end:
             keys.append(k)
     env = {"AHA_LDS_SLOTS": rng.choice([None, None, "512", "1024", "4096"]),
            "AHA_SHADOW_FAIL": rng.choice([None, None, None, "0"]),
-           "AHA_ENGINE": rng.choice([None, None, "pp", "pp", "v1"]),
+           "AHA_ENGINE": rng.choice([None, None, "pp", "pp", "v1", "unit", "unit"]),
            "AHA_DIRECT": rng.choice([None, None, "0"])}
     for k, v in env.items():
         if v is None:

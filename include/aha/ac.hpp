@@ -97,6 +97,40 @@ class AC {
     run(seq, nullptr, chars, [&](const Hit &h) { v.push_back(h); });
     return v;
   }
+  // AC#match_longest(seq, intersectable = false) -- src/aha/ac.cr:297-319 (String form: chars = true)
+  template <class F>
+  void match_longest(std::string_view seq, bool intersectable, F &&block, bool chars = false) const {
+    run(seq, nullptr, chars, std::forward<F>(block), intersectable ? 2 : 1);
+  }
+  // D documents in one call (new: the reference is one sequence per call): hits of all documents in document order,
+  // doc_hit_offsets[d] .. doc_hit_offsets[d + 1] are document d's
+  std::vector<Hit> match_batch(std::string_view corpus, const std::vector<uint64_t> &doc_offsets,
+                               std::vector<uint64_t> *doc_hit_offsets = nullptr, bool chars = false) const {
+    if (doc_offsets.empty()) throw Error(AHA_E_INVALID, "doc_offsets holds D + 1 entries");
+    aha_match_params p{};
+    p.struct_size = sizeof(p);
+    p.char_offsets = chars ? 1 : 0;
+    const uint64_t D = doc_offsets.size() - 1;
+    std::vector<uint64_t> dho(D + 1);
+    std::vector<Hit> out(corpus.size() / 8 + 64);
+    uint64_t n = 0;
+    for (;;) {
+      int32_t rc = aha_ac_match_batch(h_, reinterpret_cast<const uint8_t *>(corpus.data()), doc_offsets.data(), D, &p,
+                                      out.data(), out.size(), dho.data(), &n);
+      if (rc == AHA_E_CAPACITY) {
+        out.resize(n);
+        continue;
+      }
+      if (rc != AHA_OK) {
+        const char *m = aha_last_error(h_);
+        throw Error(rc, (m && *m) ? m : aha_strerror(rc));
+      }
+      break;
+    }
+    out.resize(n);
+    if (doc_hit_offsets) *doc_hit_offsets = std::move(dho);
+    return out;
+  }
 
   // AC#[](sid : Int) : String ;  AC#[](key) : Int (IndexError when absent)
   std::string operator[](int32_t id) const {
@@ -133,10 +167,11 @@ class AC {
  private:
   explicit AC(aha_ac *h) : h_(h) {}
   template <class F>
-  void run(std::string_view seq, const BitArray *sep, bool chars, F &&block) const {
+  void run(std::string_view seq, const BitArray *sep, bool chars, F &&block, int longest = 0) const {
     aha_match_params p{};
     p.struct_size = sizeof(p);
     p.char_offsets = chars ? 1 : 0;
+    p.longest = longest;
     if (sep) {
       p.sep_size = sep->size();
       std::memcpy(p.sep_bits, sep->bytes().data(), sep->bytes().size() < 32 ? sep->bytes().size() : 32);

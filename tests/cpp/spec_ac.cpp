@@ -50,6 +50,28 @@ int main() {
     matcher.match("a aaa", sep, [&](const aha::Hit &hit) { matched.push_back({hit.end, hit.value}); }, true);
     expect("ac with sep", matched, {{1, 0}});
   }
+  {  // spec/ac_longest_match_spec.cr:5-18 and :20-33
+    auto m1 = aha::AC::compile({"Ruby", "ruby", "rub"});
+    std::vector<Pair> got;
+    m1.match_longest("Ruby on rub", false, [&](const aha::Hit &hit) { got.push_back({hit.start, hit.end}); });
+    expect("match_longest", got, {{0, 4}, {8, 11}});
+    auto m2 = aha::AC::compile({"Ruby", "ruby", "uby "});
+    got.clear();
+    m2.match_longest("ruby ", true, [&](const aha::Hit &hit) { got.push_back({hit.start, hit.end}); });
+    expect("match_longest intersectable", got, {{0, 4}, {1, 5}});
+  }
+  {  // a batch of documents: the state is per sequence (ac.cr:177)
+    auto matcher = aha::AC::compile({"ab", "b"});
+    std::vector<uint64_t> dho;
+    auto hits = matcher.match_batch("abab", {0, 1, 1, 4}, &dho);  // "a", "", "bab"
+    std::vector<Pair> got;
+    for (auto &h : hits) got.push_back({h.end, h.value});
+    expect("match_batch", got, {{1, 1}, {3, 0}, {3, 1}});
+    if (dho != std::vector<uint64_t>{0, 0, 0, 3}) {
+      fails++;
+      std::printf("FAIL match_batch offsets\n");
+    }
+  }
   {  // error behaviour: raise "key:... appear twice."  ac.cr:66
     try {
       aha::AC::compile({"ab", "cd", "ab"});

@@ -803,7 +803,8 @@ def test_concurrent_calls_on_one_handle():
     keys = rand_keys(rng, 400, b"abcd", 1, 6)
     ac = AC.compile(keys)
     o = orc.AC.compile(keys)
-    texts = [bytes(rng.choice(b"abcd") for _ in range(rng.randint(1000, 60000))) for _ in range(6)]
+    # twelve threads: more than the eight scratch sets of a handle, so some calls wait for a set
+    texts = [bytes(rng.choice(b"abcd") for _ in range(rng.randint(1000, 60000))) for _ in range(12)]
     want = [as_list(o.match(t)) for t in texts]
     got = [None] * len(texts)
     errs = []

@@ -30,6 +30,7 @@ AHA_OPT_FORCE_WIDE = 2
 AHA_IMG_SLOTS, AHA_IMG_END_KEY, AHA_IMG_KEY_LN, AHA_IMG_KEY_CNT, AHA_IMG_KEY_KC = 0, 1, 2, 3, 4
 AHA_IMG_PP_T2, AHA_IMG_PP_BLOOM = 7, 8
 AHA_IMG_UNIT_SLOTS, AHA_IMG_UNIT_ROOT, AHA_IMG_UNIT_END_INFO = 9, 10, 11
+AHA_IMG_STALE_ENDS = 12
 
 
 class aha_options(C.Structure):

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "automaton.hpp"
+#include "cedar_replay.hpp"
 #include "image.hpp"
 #include "pp.hpp"
 #include "unit.hpp"
@@ -81,6 +82,13 @@ struct aha_ac {
   uint32_t pp_grid = 0;
   uint32_t pp_lds_slots = 0;
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
+  // match_longest only (cedar_replay.cpp): the states that carry one of Cedar's stale END flags, derived on the first
+  // match_longest call (it replays every insert: as long again as the rest of compile); dev_longest = dev + the bitmap
+  std::vector<uint32_t> state_base;  // [n_states] base of every state in the image
+  std::once_flag stale_once;
+  std::vector<uint32_t> stale_states;
+  int32_t stale_rc = AHA_OK;
+  DevAut dev_longest{};
 };
 
 namespace {
@@ -469,6 +477,22 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   }
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
+#ifdef AHA_DIAG
+  // lab build (make diag): time the traversal alone; its timing-only variants leave nothing the post passes may read
+  if (getenv("AHA_DIAG_TRAVERSE_ONLY")) {
+    HIPCHK(ac, hipStreamSynchronize(s));
+    aha_timing t;
+    memset(&t, 0, sizeof(t));
+    t.struct_size = sizeof(t);
+    t.engine = 2;
+    t.chunk_bytes = M.S;
+    t.n_chunks = M.n_chunks;
+    if (prof) (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], sc->ev[1]);
+    publish_timing(ac, t);
+    *n_hits = 0;
+    return AHA_OK;
+  }
+#endif
   if (direct) {
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
     v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr);
@@ -611,6 +635,25 @@ struct DeviceGuard {
   }
 };
 
+// match_longest asks is_end? like the reference does: "ends a key" OR one of Cedar's stale END flags
+// (cedar.cr:642-648, observable at ac.cr:126-128).  The set is derived once per handle, on first use, by replaying
+// Cedar's inserts (cedar_replay.cpp); the bitmap (one bit per slot, set at the base of a stale state) lives in HBM
+// beside the image and only the match_longest kernels read it.
+int32_t ensure_stale(aha_ac *ac) {
+  std::call_once(ac->stale_once, [ac]() {
+    cedar_stale_ends(ac->aut, ac->stale_states);
+    ac->dev_longest = ac->dev;
+    ac->dev_longest.stale_bits = nullptr;
+    if (ac->device < 0 || ac->stale_states.empty()) return;
+    std::vector<uint32_t> bits(((size_t)ac->n_slots + 31) / 32, 0u);
+    for (uint32_t s : ac->stale_states) bits[ac->state_base[s] >> 5] |= 1u << (ac->state_base[s] & 31);
+    DeviceGuard g(ac->device);
+    ac->stale_rc = upload(ac, bits, &ac->dev_longest.stale_bits);
+  });
+  return ac->stale_rc;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -692,6 +735,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     shadow = false;
   }
   ac->seg2 = pl.seg_start[2];
+  ac->state_base = pl.base;
   ac->s1_lo = shadow ? pl.seg_start[2] : 0;
   ac->s2_lo = shadow ? pl.seg_start[3] : 0;
   ac->s2_hi = shadow ? pl.deep_fail_start : 0;
@@ -941,6 +985,29 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
       src = ac->unit.end_info.data();
       bytes = ac->unit.end_info.size() * 4;
       break;
+    case AHA_IMG_STALE_ENDS: {
+      // {key id, prefix length} of every state with a stale END flag: the state is that prefix of that key
+      aha_ac *m = const_cast<aha_ac *>(ac);
+      if (ensure_stale(m) != AHA_OK) return AHA_E_HIP;
+      std::vector<uint8_t> is_stale(a.n_states, 0);
+      for (uint32_t st : ac->stale_states) is_stale[st] = 1;
+      size_t left = ac->stale_states.size();
+      for (uint32_t k = 0; k < a.n_keys && left; k++) {
+        uint32_t st = 0;
+        for (uint64_t i = a.offs[k]; i < a.offs[k + 1]; i++) {
+          st = a.child(st, a.blob[i]);
+          if (is_stale[st]) {
+            is_stale[st] = 0;
+            left--;
+            tmp.push_back(k);
+            tmp.push_back((uint32_t)(i - a.offs[k] + 1));
+          }
+        }
+      }
+      src = tmp.data();
+      bytes = tmp.size() * 4;
+      break;
+    }
     default:
       return AHA_E_INVALID;
   }
@@ -1090,11 +1157,12 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
     M.docg = sc->d_docg;
     M.totals = sc->d_totals;
     const int chars = M.chars;
-    launch_longest(ac->dev, M, mode, false, s);
+    if ((rc = ensure_stale(ac))) return rc;
+    launch_longest(ac->dev_longest, M, mode, false, s);
     M.chars = 0;  // the block scan has no lead counts to scan here
     launch_scan_blocks(M, n_blocks, s);
     M.chars = chars;
-    launch_longest(ac->dev, M, mode, true, s);
+    launch_longest(ac->dev_longest, M, mode, true, s);
     HIPCHK(ac, hipGetLastError());
     HIPCHK(ac, hipMemcpyAsync(sc->h_totals, sc->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(ac, hipStreamSynchronize(s));

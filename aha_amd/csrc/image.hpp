@@ -24,6 +24,9 @@ struct DevAut {
   uint32_t s1_lo;            // [s1_lo, s2_lo): depth-2 states; their fail target is the depth-1 state of the last byte
   uint32_t s2_lo;
   uint32_t s2_hi;
+  // match_longest only: bit B set <=> the state with base B carries one of Cedar's stale END flags (cedar_replay.cpp);
+  // null when there is none
+  const uint32_t *stale_bits;
 };
 
 struct MatchArgs {

@@ -222,10 +222,11 @@ __global__ __launch_bounds__(kBlock) void k_write(DevAut A, MatchArgs M) {
 // pending end is yielded (its own key: fetch_one stops at the first live chain entry), cleared, and -- unless
 // `intersectable` -- the state is reset to the root, where the byte is NOT tried again (ac.cr:131-136).  Whatever is
 // pending at the end of the sequence is yielded last.
-// is_end? here means "really ends a key".  The reference's END bit can be stale on a slot reused inside
-// Cedar's resolve (cedar.cr:642-648): such a node would overwrite the pending end with one that yields nothing.
-// That depends on Cedar's slot history, which this build does not reproduce (own placement): documents whose walk
-// crosses a stale node are outside the parity contract of match_longest.
+// is_end? (cedar.cr:657-660) is true for a state that ends a key AND for a state whose Cedar node kept the END flag of
+// an evicted node (a slot reused inside resolve, cedar.cr:642-648): such a stale end replaces the pending end by one
+// for which fetch_one yields nothing, and still resets the state when it is "yielded".  Which states are stale follows
+// from Cedar's slot history, replayed on the host (cedar_replay.cpp): A.stale_bits, one bit per slot at the state's base.
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;  // a pending end that yields nothing
 struct Pending {
   int64_t p = -1;      // absolute position of the pending end (-1: none)
   uint32_t key = 0;
@@ -245,6 +246,10 @@ __device__ __forceinline__ bool longest_step(const DevAut &A, uint32_t &B, const
       if (r == 2) {
         pend.p = p;
         pend.key = key;
+        pend.endc = lc;
+      } else if (A.stale_bits && ((A.stale_bits[B >> 5] >> (B & 31)) & 1u)) {
+        pend.p = p;
+        pend.key = kNoKey;
         pend.endc = lc;
       }
       break;
@@ -295,12 +300,13 @@ __global__ __launch_bounds__(kBlock) void k_longest_docs(DevAut A, MatchArgs M, 
     Pending pend, out;
     for (uint64_t p = a; p < e; p++) {
       if (M.chars) lc += (M.text[p] & 0xC0u) != 0x80u;
-      if (longest_step<COMPACT>(A, B, M.text + p, (int64_t)p, lc, intersectable != 0, pend, &out)) {
+      if (longest_step<COMPACT>(A, B, M.text + p, (int64_t)p, lc, intersectable != 0, pend, &out) &&
+          out.key != kNoKey) {
         if (WRITE) longest_emit(A, M, out, a, idx);
         hits++;
       }
     }
-    if (pend.p >= 0) {
+    if (pend.p >= 0 && pend.key != kNoKey) {
       if (WRITE) longest_emit(A, M, pend, a, idx);
       hits++;
     }
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_longest_chunks(DevAut A, MatchArgs M
     auto mine = [&](const Pending &h) { return (uint64_t)h.p >= a && (uint64_t)h.p < e; };
     for (;;) {
       if (p == nb) {  // end of a document: its pending end is yielded, the next one starts at the root
-        if (pend.p >= 0 && mine(pend)) {
+        if (pend.p >= 0 && mine(pend) && pend.key != kNoKey) {
           if (WRITE) longest_emit(A, M, pend, doc_start, idx);
           hits++;
         }
@@ -361,7 +367,8 @@ __global__ __launch_bounds__(kBlock) void k_longest_chunks(DevAut A, MatchArgs M
         if (p >= N) break;
       }
       if (p >= e && (pend.p < 0 || !mine(pend))) break;  // nothing of this chunk is pending any more
-      if (longest_step<COMPACT>(A, B, M.text + p, (int64_t)p, lc, true, pend, &out) && mine(out)) {
+      if (longest_step<COMPACT>(A, B, M.text + p, (int64_t)p, lc, true, pend, &out) && mine(out) &&
+          out.key != kNoKey) {
         if (WRITE) longest_emit(A, M, out, doc_start, idx);
         hits++;
       }

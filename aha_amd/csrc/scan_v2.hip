@@ -71,8 +71,39 @@ struct Slot<false> {
 constexpr int kInStride = kV2Piece + 4;           // bytes per lane in the LDS input window (odd dword stride)
 constexpr int kWaveIn2 = 64 * kInStride;
 
+// Lab variants of the partial-prefix trip (tools/lab_traverse.py, `make diag`): the product instantiates DG = 0 only
+// and every `if constexpr (DG == ...)` below disappears from it.  Variants marked (T) break the walk on purpose
+// (timing only): the lab build stops after the traversal and reads nothing it wrote.
+enum : int {
+  kDgNone = 0,
+  kDgNoFar = 1,         // (T) every probe beyond the LDS prefix is answered from LDS
+  kDgFarHalf = 2,       // (T) half of them (hash of the slot index)
+  kDgNoStore = 3,       // (T) events are counted but not stored
+  kDgNoFarNoStore = 4,  // (T)
+  kDgAddFar = 5,        // exact walk; every far lane issues a second, independent far load
+  kDgAddValu = 6,       // exact walk; 16 more dependent VALU instructions per trip
+  kDgAddLds = 7,        // exact walk; one more random ds_read_b32 per trip
+  kDgStamp = 8,         // exact walk; s_memtime stamps around the segments of the trip
+  kDgSplit = 9,         // exact walk; ds_read for the near lanes + global_load for the far lanes instead of one flat_load
+  kDgFarL1 = 10,        // (T) far probes go to an 8 KiB window of the global image (L1 hits): the flat path without L2
+  kDgStorePlain = 11,   // exact walk; plain instead of non-temporal event stores
+  kDgCount = 12
+};
+#ifdef AHA_DIAG
+// per wave: 16 words = cycles of the segments A..E for wave-trips without / with a far lane, then the two trip counts
+__device__ uint32_t g_diag_stamps[256 * (kV2Threads / 64) * 16];
+#define AHA_STAMP(t)                                                               \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");      \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
+#else
+#define AHA_STAMP(t) (void)(t)
+#endif
+
 // ALL_LDS: the whole image fits the LDS budget (cfg 2): no HBM probe path at all.
-template <bool COMPACT, bool CHARS, bool ALL_LDS>
+template <bool COMPACT, bool CHARS, bool ALL_LDS, int DG = kDgNone>
 __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   using S_ = Slot<COMPACT>;
@@ -138,6 +169,10 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
     slab_left -= n;
     slab_used_n += n;
   };
+
+  [[maybe_unused]] uint32_t dg_dummy = 0;             // lab: keeps the added loads / instructions alive
+  [[maybe_unused]] uint32_t dg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // lab: stamp sums (wave-uniform)
+  [[maybe_unused]] const uint32_t dg_shift = 32u - (31u - (uint32_t)__clz((int)A.n_slots));
 
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -265,6 +300,8 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
         if (!__any(act)) break;
         bool ev = false;
         uint32_t en_keep = 0;
+        [[maybe_unused]] unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dt3 = 0, dt4 = 0, dt5 = 0;
+        [[maybe_unused]] bool dg_anyfar = false;
         if (act) {
           if constexpr (ALL_LDS) {
             const uint32_t b = inl[rel];
@@ -334,9 +371,14 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             // the byte comes from a register: the next one was loaded during the previous trip (nearly every trip
             // consumes), which takes the LDS round trip of the byte out of the dependent chain
             const uint32_t b = bcur;
+            if constexpr (DG == kDgStamp) AHA_STAMP(dt0);
             const uint32_t bnext = inl[rel + 1];                    // rows are padded: rel + 1 <= piece + 3
             const uint32_t c = b & hm;
-            const uint32_t idx = B ^ c;
+            uint32_t idx = B ^ c;
+            if constexpr (DG == kDgNoFar || DG == kDgNoFarNoStore) idx = idx < T ? idx : (idx & 16383u);
+            if constexpr (DG == kDgFarHalf) idx = (idx >= T && ((idx * 0x9E3779B1u) >> 31)) ? (idx & 16383u) : idx;
+            if constexpr (DG == kDgFarL1) idx = idx < T ? idx : T + (idx & 2047u);
+            if constexpr (DG == kDgStamp) dg_anyfar = __any(idx >= T);
             const slot_t e0 = lt[root ^ b];                         // root row: always LDS resident
             const slot_t e2 = lt[S_::base(r1) ^ b];                 // depth-1 rows: always LDS resident
             const slot_t sx = B < A.s2_lo ? r1 : s2;                // shadow fail target of B (if B has one)
@@ -344,25 +386,52 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             const bool near3 = i3 < T;
             const slot_t e3 = lt[near3 ? i3 : 0u];                  // sx's row (depth <= 2: mostly LDS resident)
             slot_t en;
-            if (idx < T)
-              en = lt[idx];
-            else
-              en = gt[idx];
+            if constexpr (DG == kDgSplit) {
+              en = lt[idx < T ? idx : 0u];
+              if (idx >= T) en = gt[idx];
+            } else {
+              if (idx < T)
+                en = lt[idx];
+              else
+                en = gt[idx];
+            }
+            if constexpr (DG == kDgAddFar) {
+              if (idx >= T) dg_dummy ^= (uint32_t)gt[(idx * 2654435761u) >> dg_shift];
+            }
+            if constexpr (DG == kDgAddLds) dg_dummy ^= (uint32_t)lt[(idx ^ 0x1555u) & 16383u];
+            if constexpr (DG == kDgStamp) AHA_STAMP(dt1);           // the LDS reads are back (the stamp waits lgkmcnt(0))
             const bool nz = b != 0;
             const bool probe = hm != 0;
             const bool bzp = !nz && probe;                          // NUL contract: state := root, byte consumed
-            const bool t = S_::match(en, c) && !bzp;                // goto (cedar.cr:441-447), or the header itself
             const bool atroot = B == root || fr != 0 || bzp;        // fails[nid] = root: probe the root row now
             const bool mr = nz && S_::match(e0, b);                 // b has a depth-1 state
             // fails[nid] of a state in [s1_lo, s2_hi) follows from the last bytes: sx = r1 (depth-2 state) or s2.
             // Its row, the row of ITS fail target (r1: e2) and the root row (e0) are probed in this same trip, so
             // the whole rest of the fail chain is resolved here and the byte is consumed (1.19 -> 1.02 trips per
             // byte); only when sx's row lies beyond the LDS prefix the walk continues in sx without consuming.
-            const bool sgo = !t && !atroot && (B - A.s1_lo) < (A.s2_hi - A.s1_lo);
-            const bool sres = sgo && near3;
             const bool m3 = nz && S_::match(e3, b);
             const bool m2 = nz && S_::match(e2, b);
             const slot_t chain = m3 ? e3 : (m2 ? e2 : (mr ? e0 : slot_t{}));   // first goto along sx -> r1 -> root
+            // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
+            const slot_t r1n = mr ? e0 : slot_t{};
+            const slot_t s2n = m2 ? e2 : r1n;
+            const bool shadow = !atroot && (B - A.s1_lo) < (A.s2_hi - A.s1_lo);
+            if constexpr (DG == kDgAddValu) {
+              asm volatile("v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
+                           "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
+                           "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
+                           "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
+                           : "+v"(dg_dummy)
+                           : "v"(b));
+            }
+            if constexpr (DG == kDgStamp) {
+              AHA_STAMP(dt2);                                       // everything that does not need the probe is done
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(en)::"memory");
+              AHA_STAMP(dt3);                                       // the probe (and the previous trip's event store) is back
+            }
+            const bool t = S_::match(en, c) && !bzp;                // goto (cedar.cr:441-447), or the header itself
+            const bool sgo = !t && shadow;
+            const bool sres = sgo && near3;
             const slot_t ex = t ? en : (sgo ? (near3 ? chain : sx) : (mr ? e0 : slot_t{}));
             const bool land = t || atroot || sgo;                   // else: the next trip loads fails[nid] (ac.cr:189)
             const bool consumed = (t && probe) || (!t && atroot) || sres;  // at root a miss consumes (ac.cr:188)
@@ -370,9 +439,6 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             fr = land ? S_::failroot(ex) : fr;
             hm = land ? 0xFFu : 0u;
             ev = consumed && S_::end(ex) && emit_ok;                // is_end? -> fetch later (ac.cr:183-185)
-            // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
-            const slot_t r1n = mr ? e0 : slot_t{};
-            const slot_t s2n = m2 ? e2 : r1n;
             s2 = consumed ? s2n : s2;
             r1 = consumed ? r1n : r1;
             if (CHARS) {
@@ -382,6 +448,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             }
             rel += consumed ? 1u : 0u;
             bcur = consumed ? bnext : bcur;
+            if constexpr (DG == kDgStamp) AHA_STAMP(dt4);
             en_keep = S_::payload(ex);
           }
         }
@@ -394,10 +461,13 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
                 const v2u rec = {en_keep, CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel)};
                 // sparse events are streamed past L2 (it keeps the image); dense ones (the previous call had more
                 // than one hit per 4 bytes) fill whole lines quickly and are better merged in L2
-                if (M.dense_hits)
+                if constexpr (DG == kDgNoStore || DG == kDgNoFarNoStore) {
+                  dg_dummy ^= rec.x ^ rec.y;
+                } else if (M.dense_hits || DG == kDgStorePlain) {
                   *reinterpret_cast<v2u *>(evreg + seq) = rec;
-                else
+                } else {
                   __builtin_nontemporal_store(rec, reinterpret_cast<v2u *>(evreg + seq));
+                }
               } else {
                 M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
               }
@@ -416,6 +486,16 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
               seq++;
             }
           }
+        }
+        if constexpr (DG == kDgStamp) {
+          AHA_STAMP(dt5);
+          const int o = dg_anyfar ? 6 : 0;
+          dg_acc[o + 0] += (uint32_t)(dt1 - dt0);  // A: addresses, issue of the probe and the four LDS reads, LDS round trip
+          dg_acc[o + 1] += (uint32_t)(dt2 - dt1);  // B: selects that need no probe result
+          dg_acc[o + 2] += (uint32_t)(dt3 - dt2);  // C: rest of the wait for the probe (vmcnt(0): previous event store too)
+          dg_acc[o + 3] += (uint32_t)(dt4 - dt3);  // D: selects on the probe result
+          dg_acc[o + 4] += (uint32_t)(dt5 - dt4);  // E: event store
+          dg_acc[o + 5] += 1u;
         }
       }
         if (!__any(rel < lim)) break;
@@ -436,6 +516,15 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
     }
   }
   if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
+#ifdef AHA_DIAG
+  if constexpr (DG == kDgStamp) {
+    if (lane == 0)
+      for (int k = 0; k < 12; k++) g_diag_stamps[(blockIdx.x * (kV2Threads / 64) + wave) * 16 + k] = dg_acc[k];
+  }
+  if constexpr (DG != kDgNone && DG != kDgStamp) {
+    if (dg_dummy == 0x9E3779B9u) M.cursor[15] = dg_dummy;  // never true in practice: keeps the lab's extra work alive
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- scans
@@ -859,11 +948,48 @@ int v2_prepare(bool compact, size_t lds_bytes) {
   return rc;
 }
 
+#ifdef AHA_DIAG
+// Lab build only (make diag): which variant of the headline kernel the next launches run, and the stamp sums.
+int g_diag_knob = 0;
+template <int DG>
+static void diag_launch_one(const DevAut &A, const V2Args &M, uint32_t grid, size_t lds, hipStream_t s) {
+  (void)hipFuncSetAttribute((const void *)k2_traverse<true, false, false, DG>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k2_traverse<true, false, false, DG>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
+}
+static void diag_launch(const DevAut &A, const V2Args &M, uint32_t grid, size_t lds, hipStream_t s) {
+  switch (g_diag_knob) {
+    case 1: diag_launch_one<1>(A, M, grid, lds, s); break;
+    case 2: diag_launch_one<2>(A, M, grid, lds, s); break;
+    case 3: diag_launch_one<3>(A, M, grid, lds, s); break;
+    case 4: diag_launch_one<4>(A, M, grid, lds, s); break;
+    case 5: diag_launch_one<5>(A, M, grid, lds, s); break;
+    case 6: diag_launch_one<6>(A, M, grid, lds, s); break;
+    case 7: diag_launch_one<7>(A, M, grid, lds, s); break;
+    case 8: diag_launch_one<8>(A, M, grid, lds, s); break;
+    case 9: diag_launch_one<9>(A, M, grid, lds, s); break;
+    case 10: diag_launch_one<10>(A, M, grid, lds, s); break;
+    case 11: diag_launch_one<11>(A, M, grid, lds, s); break;
+    default: break;
+  }
+}
+extern "C" __attribute__((visibility("default"))) void aha_diag_set(int knob) { g_diag_knob = knob; }
+extern "C" __attribute__((visibility("default"))) int aha_diag_read_stamps(uint32_t *dst, uint64_t n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_diag_stamps), n_words * 4, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = v2_lds_bytes(M.lds_slots, A.compact != 0);
   {
     const bool all = M.lds_slots >= A.n_slots && A.s2_hi == 0;  // whole image in LDS and a header for every state
+#ifdef AHA_DIAG
+    if (g_diag_knob != kDgNone && A.compact && !M.chars && !all) {
+      diag_launch(A, M, grid, lds, s);
+      return;
+    }
+#endif
 #define AHA_LAUNCH_K2(C, H, L) \
   hipLaunchKernelGGL((k2_traverse<C, H, L>), dim3(grid), dim3(kV2Threads), lds, s, A, M)
     if (A.compact) {

@@ -227,7 +227,10 @@ enum {
   AHA_IMG_PP_BLOOM = 8, /* uint32[pp_bloom_words] */
   AHA_IMG_UNIT_SLOTS = 9,     /* uint64[unit_slots]: lo = base | END << 31 | FAILROOT << 30, hi = unit code (unit.hpp) */
   AHA_IMG_UNIT_ROOT = 10,     /* uint32[0x10880]: the root's transitions, indexed by unit code */
-  AHA_IMG_UNIT_END_INFO = 11  /* uint32[unit_slots]: key id | min(chain length, 255) << 24, or 0xFFFFFFFF */
+  AHA_IMG_UNIT_END_INFO = 11, /* uint32[unit_slots]: key id | min(chain length, 255) << 24, or 0xFFFFFFFF */
+  AHA_IMG_STALE_ENDS = 12     /* {uint32 key id, uint32 prefix length}[]: the states (a prefix of a key each) whose node in
+                                 the reference's Cedar keeps a stale END flag (src/aha/cedar.cr:642-648); match_longest
+                                 treats them as ends that yield nothing (src/aha/ac.cr:126-128, 249-263) */
 };
 int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_bytes);
 

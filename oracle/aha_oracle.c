@@ -797,6 +797,36 @@ int32_t orc_ac_stale_ends(const orc_ac *a) {
   return n;
 }
 
+/* The same nodes as byte strings: for each one a 4-byte little-endian length, then the labels on its path from the
+ * root (parent = check, label = id ^ base(parent): cedar.cr:441-447 read backwards).  Returns the bytes needed; writes
+ * only when they fit cap.  Test infrastructure: the product derives the same set by its own replay of Cedar's inserts
+ * (aha_amd/csrc/cedar_replay.cpp) and tests/test_host_logic.py compares set against set. */
+int64_t orc_ac_stale_paths(const orc_ac *a, uint8_t *buf, int64_t cap) {
+  int64_t need = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    int64_t w = 0;
+    for (int32_t id = 1; id < a->da->array_size; id++) {
+      if (a->fails[id] < 0 || a->da->array[id].check < 0) continue;
+      if (!(cedar_is_end(a->da, id) && a->output[id].value < 0)) continue;
+      uint32_t len = 0;
+      for (int32_t x = id; x != 0; x = a->da->array[x].check) len++;
+      if (pass == 1) {
+        memcpy(buf + w, &len, 4);
+        int32_t x = id;
+        for (uint32_t k = len; k > 0; k--) {
+          const int32_t par = a->da->array[x].check;
+          buf[w + 4 + k - 1] = (uint8_t)(x ^ nbase(&a->da->array[par]));
+          x = par;
+        }
+      }
+      w += 4 + len;
+    }
+    need = w;
+    if (pass == 0 && (!buf || need > cap)) return need;
+  }
+  return need;
+}
+
 /* match_longest_ ac.cr:118-143 + match_longest :297-310 */
 int64_t orc_ac_match_longest(const orc_ac *a, const uint8_t *text, int64_t n, int intersectable,
                              int char_offsets, orc_hit *out, int64_t cap) {

@@ -79,6 +79,8 @@ int64_t orc_ac_match(const orc_ac *a, const uint8_t *text, int64_t n, int char_o
                      const uint8_t *sep_bits, int32_t sep_size, orc_hit *out, int64_t cap);
 /* match_longest(Bytes, intersectable) :297-303 (+ String overload :305-310). */
 int32_t orc_ac_stale_ends(const orc_ac *a); /* nodes with a stale END flag (cedar.cr:642-648) */
+/* the same nodes as [u32 length][path bytes] records; returns the bytes needed, writes when they fit cap */
+int64_t orc_ac_stale_paths(const orc_ac *a, uint8_t *buf, int64_t cap);
 int64_t orc_ac_match_longest(const orc_ac *a, const uint8_t *text, int64_t n, int intersectable,
                              int char_offsets, orc_hit *out, int64_t cap);
 /* One `match` call per document (the reference has no batch entry; this is

@@ -56,6 +56,7 @@ def lib():
         "orc_ac_match": (i64, [vp, vp, i64, C.c_int, vp, i32, vp, i64]),
         "orc_ac_match_longest": (i64, [vp, vp, i64, C.c_int, C.c_int, vp, i64]),
         "orc_ac_stale_ends": (i32, [vp]),
+        "orc_ac_stale_paths": (i64, [vp, vp, i64]),
         "orc_ac_match_batch": (i64, [vp, vp, vp, u64, C.c_int, vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
@@ -213,6 +214,18 @@ class AC:
     def stale_ends(self):
         """Nodes with a stale END flag (cedar.cr:642-648): only match_longest can observe them."""
         return int(lib().orc_ac_stale_ends(self._h))
+
+    def stale_paths(self):
+        """The stale END nodes as the byte strings that lead to them (a set)."""
+        need = int(lib().orc_ac_stale_paths(self._h, None, 0))
+        buf = np.zeros(max(need, 1), dtype=np.uint8)
+        lib().orc_ac_stale_paths(self._h, _ptr(buf), need)
+        raw, out, i = buf.tobytes(), set(), 0
+        while i < need:
+            n = int.from_bytes(raw[i:i + 4], "little")
+            out.add(raw[i + 4:i + 4 + n])
+            i += 4 + n
+        return out
 
     def match_longest(self, text, intersectable=False, chars=None):
         if chars is None:

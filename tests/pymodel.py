@@ -108,25 +108,34 @@ class ModelAC:
             out = [(cmap[a], cmap[e - 1] + 1, v) for (a, e, v) in out]
         return out
 
-    def match_longest(self, text, intersectable=False, chars=None):
-        """match_longest_ / fetch_one restated from src/aha/ac.cr:118-143, 249-263 with is_end? = "really ends a
-        key" (no stale END flags: cedar.cr:642-648 is a property of Cedar's slot history, not of the key set)."""
+    def match_longest(self, text, intersectable=False, chars=None, stale=()):
+        """match_longest_ / fetch_one restated from src/aha/ac.cr:118-143, 249-263.  is_end? = "really ends a key" or
+        the state's string is in `stale`: Cedar's stale END flags (cedar.cr:642-648) are a property of its slot
+        history, not of the key set, so the model takes them as an input -- the set of byte strings whose node holds
+        one -- and treats such a state as an end for which fetch_one yields nothing."""
         if chars is None:
             chars = isinstance(text, str)
         t = _b(text)
         out = []
         nid, prev_i, prev_nid = 0, -1, -1
+        stale_nodes = set()
+        for path in stale:
+            n = 0
+            for b in path:
+                n = self.children[n][b]
+            stale_nodes.add(n)
 
         def fetch_one(i, n):
             k = self.key_of[n]
-            out.append((i - len(self.keys[k]) + 1, i + 1, k))
+            if k >= 0:
+                out.append((i - len(self.keys[k]) + 1, i + 1, k))
 
         for i, b in enumerate(t):
             while True:
                 nxt = self.children[nid].get(b) if b else None
                 if nxt is not None:
                     nid = nxt
-                    if self.key_of[nid] >= 0:
+                    if self.key_of[nid] >= 0 or nid in stale_nodes:
                         prev_i, prev_nid = i, nid
                     break
                 if prev_i != -1:

@@ -43,6 +43,12 @@ def gpu_list(h):
     return [tuple(int(v) for v in x) for x in h.tolist()]
 
 
+def stale_paths_of(ac, keys):
+    """The library's own replay of Cedar's stale END flags (AHA_IMG_STALE_ENDS), as a set of byte strings."""
+    a = ac.export(N.AHA_IMG_STALE_ENDS, np.uint32).reshape(-1, 2)
+    return set(bytes(keys[int(k)][:int(n)]) for k, n in a)
+
+
 # ---- the reference's own specs, run against the HIP path --------------------
 
 def test_spec_ac():  # spec/ac_spec.cr:5-12
@@ -125,14 +131,17 @@ def test_reference_match_longest_kats(kat):  # spec/ac_longest_match_spec.cr:5-6
 def test_match_longest_random(seed):
     """Random automata and ragged batches, both forms, byte and char offsets (three device paths: a thread per
     document for intersectable = false and for char offsets, a thread per chunk with a 2 * Lmax warm-up for
-    intersectable = true), against the independent model; against the oracle too where its Cedar image has no
-    stale END flag (cedar.cr:642-648 -- outside the GPU path's contract, see kernels.hip)."""
+    intersectable = true), against the ORACLE on every seed: the library replays Cedar's slot history
+    (cedar_replay.cpp), so the stale END flags of cedar.cr:642-648 -- five of the six seeds hold some -- are
+    reproduced, not exempted.  The independent model (given the oracle's stale set) must agree as well."""
     rng = random.Random(600 + seed)
     alphabet = [b"ab", b"abc", "abж中".encode(), bytes(range(0x61, 0x6B))][seed % 4]
     keys = rand_keys(rng, rng.randint(1, 80), alphabet, 1, [4, 9, 30][seed % 3])
     g = AC.compile(keys)
     m = ModelAC(keys)
     o = orc.AC.compile(keys)
+    stale = o.stale_paths()
+    assert stale_paths_of(g, keys) == stale
     docs = [bytes(rng.choice(alphabet + b" ") for _ in range(rng.choice([0, 1, 2, 7, 100, 1023, 1024, 1025, 5000])))
             for _ in range(40)] + [bytes(rng.choice(alphabet) for _ in range(40000))]
     offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
@@ -146,20 +155,39 @@ def test_match_longest_random(seed):
                     continue  # char offsets are defined for valid UTF-8 only
             want, want_off = [], [0]
             for d in docs:
-                want += m.match_longest(d, inter, chars=chars)
+                want += as_list(o.match_longest(d, inter, chars=chars))
                 want_off.append(len(want))
             gh, gd = g.match_batch(corpus, offs, chars=chars, longest=2 if inter else 1)
-            assert gpu_list(gh) == want, (inter, chars)
+            assert gpu_list(gh) == want, (inter, chars, len(stale))
             assert gd.tolist() == want_off
-            if o.stale_ends() == 0:
-                assert want == [t for d in docs for t in as_list(o.match_longest(d, inter, chars=chars))]
+            assert want == [t for d in docs for t in m.match_longest(d, inter, chars=chars, stale=stale)]
     # the single-sequence entry and the capacity protocol
     t = docs[-1]
-    assert [tuple(h) for h in g.match_longest(t, True)] == m.match_longest(t, True)
+    assert [tuple(h) for h in g.match_longest(t, True)] == as_list(o.match_longest(t, True))
     with pytest.raises(AhaError) as e:  # no separator overload of match_longest in the reference
         sep = BitArray(256)
         g.match_array(t, sep, longest=1)
     assert e.value.code == N.AHA_E_INVALID
+
+
+def test_match_longest_config2_keys_with_stale_ends():
+    """BASELINE cfg 2's own key set (1 000 keys: 121 stale END nodes in the reference's Cedar) on 512 KiB of cfg 2 text
+    cut into 16 documents, both forms, against the oracle."""
+    blob, offs, nf = synth.keys(2)
+    corpus, doc = synth.corpus(2, blob, offs, nf, n_bytes=512 << 10, doc_bytes=32 << 10)
+    g = AC.compile_packed(blob, offs)
+    o = orc.AC.compile_packed(blob, offs)
+    keys = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(offs.size - 1)]
+    stale = o.stale_paths()
+    assert len(stale) == 121 and stale_paths_of(g, keys) == stale
+    for inter in (False, True):
+        want, want_off = [], [0]
+        for d in range(doc.size - 1):
+            want += as_list(o.match_longest(corpus[int(doc[d]):int(doc[d + 1])].tobytes(), inter, chars=False))
+            want_off.append(len(want))
+        gh, gd = g.match_batch(corpus, doc, longest=2 if inter else 1)
+        assert gpu_list(gh) == want, inter
+        assert gd.tolist() == want_off
 
 
 def test_byte_level_triples():

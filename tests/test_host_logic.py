@@ -255,3 +255,36 @@ def test_c_abi_rejects_bad_arguments():
     # a host-only handle has no device: pack/unpack and profiling refuse it
     assert L.aha_ac_hits_pack_device(a._h, None, 0, None, None) == N.AHA_E_INVALID
     assert L.aha_ac_set_profiling(a._h, 1) == N.AHA_E_NO_DEVICE
+
+
+def _stale_paths_of(ac, keys):
+    a = ac.export(N.AHA_IMG_STALE_ENDS, np.uint32).reshape(-1, 2)
+    return set(bytes(keys[int(k)][:int(n)]) for k, n in a)
+
+
+def test_stale_end_replay_matches_the_oracles_cedar():
+    """Row f4: match_longest observes Cedar's stale END flags (cedar.cr:642-648 via ac.cr:126-128).  The library
+    derives them by its own replay of Cedar's inserts (aha_amd/csrc/cedar_replay.cpp); the oracle holds the faithful
+    Cedar.  Same set of nodes -- compared as byte strings -- on random key sets over small and full alphabets (insert
+    order shuffled: the set depends on it) and on BASELINE cfg 2's keys (121 stale nodes)."""
+    rng = random.Random(5)
+    with_stale = 0
+    for _ in range(400):
+        alpha = rng.choice([b"abc", b"ab", b"abcdefgh", bytes(range(1, 256))])
+        ks = set()
+        while len(ks) < rng.randint(1, 60):
+            ks.add(bytes(rng.choice(alpha) for _ in range(rng.randint(1, 7))))
+        keys = list(ks)
+        rng.shuffle(keys)
+        want = orc.AC.compile(keys).stale_paths()
+        assert _stale_paths_of(AC.compile(keys, host_only=True), keys) == want, keys
+        with_stale += bool(want)
+    assert with_stale >= 100
+    from aha_amd import synth
+
+    for cfg, K, n_stale in ((2, None, 121), (3, 20000, 2108)):
+        blob, offs, _nf = synth.keys(cfg, K=K)
+        keys = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(offs.size - 1)]
+        want = orc.AC.compile_packed(blob, offs).stale_paths()
+        assert len(want) == n_stale
+        assert _stale_paths_of(AC.compile_packed(blob, offs, host_only=True), keys) == want

@@ -24,6 +24,7 @@ AHA_E_HIP = -8
 AHA_E_TOO_LONG = -9
 AHA_E_NOT_FOUND = -10
 AHA_E_TOO_LARGE = -11
+AHA_E_NOMEM = -12
 
 AHA_OPT_HOST_ONLY = 1
 AHA_OPT_FORCE_WIDE = 2
@@ -61,6 +62,10 @@ class aha_timing(C.Structure):
                 ("chunk_bytes", C.c_uint32)]
 
 
+class aha_stream_seg(C.Structure):
+    _fields_ = [("word_offset", C.c_uint64), ("n_hits", C.c_uint64), ("out_offset", C.c_uint64)]
+
+
 class aha_group_timing(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_devices", C.c_uint32), ("ms_match", C.c_float),
                 ("ms_match_max_shard", C.c_float), ("ms_exchange", C.c_float), ("ms_download", C.c_float),
@@ -89,6 +94,7 @@ SIGNATURES = {
     "aha_ac_hits_unpack_device": (_i32, [_vp, _vp, _u64, _i32, _vp, _vp]),
     "aha_ac_hits_pack4_device": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp, _vp]),
     "aha_ac_hits_unpack4_device": (_i32, [_vp, _vp, _u64, _i32, _vp, _vp]),
+    "aha_ac_hits_unpack4_segs_device": (_i32, [_vp, _vp, _vp, _u32, _i32, _vp, _vp]),
     "aha_ac_save": (C.c_int64, [_vp, _vp, _u64]),
     "aha_ac_load": (_i32, [_vp, _u64, C.POINTER(aha_options), C.POINTER(_vp)]),
     "aha_ac_release_scratch": (_i32, [_vp]),
@@ -101,6 +107,7 @@ SIGNATURES = {
     "aha_group_match_batch": (_i32, [_vp, _vp, _vp, _u64, C.POINTER(aha_match_params), _vp, _u64, _vp,
                                      C.POINTER(_u64)]),
     "aha_group_last_timing": (_i32, [_vp, C.POINTER(aha_group_timing)]),
+    "aha_group_download_shard": (_i32, [_vp, _i32, _vp, _u64, C.POINTER(_u64)]),
     "aha_ac_set_profiling": (_i32, [_vp, _i32]),
     "aha_ac_last_timing": (_i32, [_vp, C.POINTER(aha_timing)]),
 }

@@ -349,6 +349,21 @@ class AC:
         self._check(N.lib().aha_ac_hits_unpack4_device(self._h, words.data_ptr(), n, 1 if chars else 0,
                                                        hits.data_ptr(), C.c_void_p(s)))
 
+    def hits_unpack4_segs_device(self, words, segs, hits, chars=False, stream=None):
+        """Several 4-byte streams inside `words` -> their places in `hits`, ONE launch: segs = [(word offset of the
+        stream, its hit count, row offset in hits), ...] (at most 64)."""
+        import torch
+
+        assert hits.is_cuda and words.is_cuda and hits.dtype == words.dtype == torch.int32
+        assert hits.is_contiguous() and words.is_contiguous()
+        arr = (N.aha_stream_seg * max(len(segs), 1))()
+        for k, (wo, n, oo) in enumerate(segs):
+            assert hits.numel() >= 3 * (oo + n)
+            arr[k].word_offset, arr[k].n_hits, arr[k].out_offset = int(wo), int(n), int(oo)
+        s = stream if stream is not None else torch.cuda.current_stream(hits.device).cuda_stream
+        self._check(N.lib().aha_ac_hits_unpack4_segs_device(self._h, words.data_ptr(), arr, len(segs),
+                                                            1 if chars else 0, hits.data_ptr(), C.c_void_p(s)))
+
     @property
     def n_keys(self):
         return self.info["n_keys"]
@@ -450,6 +465,16 @@ class ACGroup:
             if rc != N.AHA_OK:
                 raise AhaError(rc, N.lib().aha_group_last_error(self._h).decode() or None)
             return out[: n.value], dho
+
+    def download_shard(self, shard):
+        """The gathered hit stream as device `shard` holds it after the last match_batch (every device holds it all)."""
+        n = C.c_uint64(0)
+        N.lib().aha_group_download_shard(self._h, shard, None, 0, C.byref(n))
+        out = np.zeros(max(int(n.value), 1), dtype=HIT_DTYPE)
+        rc = N.lib().aha_group_download_shard(self._h, shard, _ptr(out), out.size, C.byref(n))
+        if rc != N.AHA_OK:
+            raise AhaError(rc, N.lib().aha_group_last_error(self._h).decode() or None)
+        return out[: n.value]
 
     def last_timing(self):
         t = N.aha_group_timing()

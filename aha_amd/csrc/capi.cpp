@@ -672,6 +672,7 @@ const char *aha_strerror(int32_t code) {
     case AHA_E_TOO_LONG: return "sequence longer than Int32 offsets allow";
     case AHA_E_NOT_FOUND: return "not found";
     case AHA_E_TOO_LARGE: return "automaton too large for the device image";
+    case AHA_E_NOMEM: return "out of host memory";
   }
   return "unknown error";
 }
@@ -824,6 +825,25 @@ int32_t aha_ac_hits_unpack4_device(aha_ac *ac, const uint32_t *d_words, uint64_t
   if (!ac || ac->device < 0 || (n && (!d_hits || !d_words))) return AHA_E_INVALID;
   DeviceGuard g(ac->device);
   launch_hits_unpack4(ac->dev, d_words, n, char_offsets ? 1 : 0, reinterpret_cast<int32_t *>(d_hits), stream);
+  HIPCHK(ac, hipGetLastError());
+  return AHA_OK;
+}
+
+int32_t aha_ac_hits_unpack4_segs_device(aha_ac *ac, const uint32_t *d_words, const aha_stream_seg *segs, uint32_t n_segs,
+                                        int32_t char_offsets, aha_hit *d_hits, void *stream) {
+  if (!ac || ac->device < 0 || n_segs > kMaxSegs || (n_segs && !segs)) return AHA_E_INVALID;
+  uint64_t woff[kMaxSegs], nh[kMaxSegs], ooff[kMaxSegs];
+  bool any = false;
+  for (uint32_t k = 0; k < n_segs; k++) {
+    woff[k] = segs[k].word_offset;
+    nh[k] = segs[k].n_hits;
+    ooff[k] = segs[k].out_offset;
+    any = any || nh[k] != 0;
+  }
+  if (any && (!d_words || !d_hits)) return AHA_E_INVALID;
+  DeviceGuard g(ac->device);
+  launch_hits_unpack4_segs(ac->dev, d_words, woff, nh, ooff, n_segs, char_offsets ? 1 : 0,
+                           reinterpret_cast<int32_t *>(d_hits), stream);
   HIPCHK(ac, hipGetLastError());
   return AHA_OK;
 }

@@ -8,13 +8,20 @@
 // its xGMI links at once -- a ring would be bound by one link); RCCL is loaded with dlopen on first use so that
 // single-GPU users do not pay for it.  Entries of the device list that name the SAME device (several shards on one
 // GPU, each with its own handle and stream) exchange with device-to-device copies instead: that is the form the
-// 1-GPU development box can execute.
+// 1-GPU development box can execute.  AHA_GROUP_RCCL=self (read by aha_group_compile) makes such a group send every
+// shard's OWN stream to itself through RCCL -- one communicator of one rank per shard, a grouped ncclSend/ncclRecv
+// pair through the same payload()/landing() code -- so that the library loading, the symbol signatures, the datatype
+// constant, ncclCommInitAll and the stream ordering behind the pack kernels are executed on a 1-GPU box; the peers'
+// streams still arrive by copies.  What only a node with several GPUs can exercise is the topology (n > 1 ranks).
+// Calls on one group are serialised (a mutex); a worker thread never lets an exception cross the C boundary.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -102,11 +109,14 @@ double ms_since(std::chrono::steady_clock::time_point t0) {
 
 struct aha_group {
   std::vector<Shard> shards;
-  bool distinct = true;  // no device named twice: the exchange is RCCL
+  bool distinct = true;   // no device named twice: the exchange is RCCL
+  bool self_rccl = false;  // AHA_GROUP_RCCL=self: every shard's own stream travels through RCCL (rehearsal on one GPU)
   Rccl rccl;
-  std::vector<ncclComm_t> comms;
+  std::vector<ncclComm_t> comms;  // distinct: rank r of ONE communicator of n ranks; self: n communicators of one rank
   aha_group_timing last{};
   std::string err;
+  std::mutex mu;  // calls on one group are serialised
+  uint64_t gathered = 0;  // hits every shard's `all` buffer holds since the last successful exchange
 };
 
 extern "C" {
@@ -117,6 +127,8 @@ int32_t aha_group_compile(const uint8_t *key_bytes, const uint64_t *key_offsets,
   *out = nullptr;
   aha_group *g = new aha_group();
   g->shards.resize((size_t)n_devices);
+  const char *rc_env = getenv("AHA_GROUP_RCCL");
+  g->self_rccl = rc_env && strcmp(rc_env, "self") == 0;
   for (int32_t r = 0; r < n_devices; r++) {
     for (int32_t q = 0; q < r; q++)
       if (devices[q] == devices[r]) g->distinct = false;
@@ -192,6 +204,12 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   }
   const uint64_t N = doc_offsets[n_docs];
   if ((N && !corpus) || (cap && !out)) return AHA_E_INVALID;
+  std::lock_guard<std::mutex> lk(g->mu);
+  auto fail = [g](int32_t rc, const std::string &what) {
+    g->err = what;
+    return rc;
+  };
+  g->gathered = 0;
   const size_t n = g->shards.size();
   *n_hits = 0;
   std::vector<uint64_t> bounds(n + 1);
@@ -204,54 +222,81 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   // ---- every shard: upload its range, match on its device (one host thread per shard: the calls block)
   const auto t_all = std::chrono::steady_clock::now();
   std::vector<std::thread> th;
+  auto work = [&](size_t r) {
+    Shard &s = g->shards[r];
+    s.rc = AHA_OK;
+    s.n_hits = 0;
+    s.err.clear();
+    const uint64_t D = s.d1 - s.d0, b0 = doc_offsets[s.d0], nb = doc_offsets[s.d1] - b0;
+    s.h_dho.assign(D + 1, 0);
+    if (hipSetDevice(s.device) != hipSuccess) {
+      s.rc = AHA_E_HIP;
+      s.err = "hipSetDevice failed";
+      return;
+    }
+    std::vector<uint64_t> rel(D + 1);
+    for (uint64_t d = 0; d <= D; d++) rel[d] = doc_offsets[s.d0 + d] - b0;
+    // room for the shard's share of the caller's capacity plus half; never more than one hit per 4 input bytes up
+    // front (a denser shard reports its exact count and is matched once more)
+    uint64_t want = N ? (uint64_t)((__uint128_t)cap * nb / N) * 3 / 2 + 1024 : 1024;
+    want = std::max<uint64_t>(1024, std::min<uint64_t>(want, nb / 4 + 4096));
+    if (!s.corpus.reserve(nb + 64) || !s.doc.reserve((D + 1) * 8) || !s.dho.reserve((D + 1) * 8) ||
+        !s.out.reserve(want * sizeof(aha_hit))) {
+      s.rc = AHA_E_HIP;
+      s.err = "hipMalloc failed for the shard's buffers";
+      return;
+    }
+    if ((nb && hipMemcpyAsync(s.corpus.p, corpus + b0, nb, hipMemcpyHostToDevice, s.stream) != hipSuccess) ||
+        hipMemcpyAsync(s.doc.p, rel.data(), (D + 1) * 8, hipMemcpyHostToDevice, s.stream) != hipSuccess ||
+        hipStreamSynchronize(s.stream) != hipSuccess) {
+      s.rc = AHA_E_HIP;
+      s.err = "upload failed";
+      return;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int attempt = 0; attempt < 2; attempt++) {
+      uint64_t nh = 0;
+      s.rc = aha_ac_match_batch_device(s.ac, (const uint8_t *)s.corpus.p, (const uint64_t *)s.doc.p, D, nb, params,
+                                       (aha_hit *)s.out.p, s.out.bytes / sizeof(aha_hit), (uint64_t *)s.dho.p, &nh,
+                                       s.stream);
+      s.n_hits = nh;
+      if (s.rc != AHA_E_CAPACITY) break;
+      if (!s.out.reserve(nh * sizeof(aha_hit))) {  // the call told the exact count: once more with room
+        s.rc = AHA_E_HIP;
+        s.err = "hipMalloc failed for the shard's hits";
+        return;
+      }
+    }
+    s.ms_match = ms_since(t0);
+    if (s.rc != AHA_OK) {
+      s.err = aha_last_error(s.ac);  // the text is the calling thread's: take it along
+      return;
+    }
+    if (hipMemcpy(s.h_dho.data(), s.dho.p, (D + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+      s.rc = AHA_E_HIP;
+      s.err = "download of the document offsets failed";
+    }
+  };
   for (size_t r = 0; r < n; r++) {
     Shard &s = g->shards[r];
     s.d0 = bounds[r];
     s.d1 = bounds[r + 1];
-    th.emplace_back([&, r]() {
-      Shard &s = g->shards[r];
-      s.rc = AHA_OK;
-      s.n_hits = 0;
-      const uint64_t D = s.d1 - s.d0, b0 = doc_offsets[s.d0], nb = doc_offsets[s.d1] - b0;
-      s.h_dho.assign(D + 1, 0);
-      if (hipSetDevice(s.device) != hipSuccess) {
-        s.rc = AHA_E_HIP;
-        return;
-      }
-      std::vector<uint64_t> rel(D + 1);
-      for (uint64_t d = 0; d <= D; d++) rel[d] = doc_offsets[s.d0 + d] - b0;
-      uint64_t want = std::max<uint64_t>(1024, N ? (uint64_t)((__uint128_t)cap * nb / N) * 3 / 2 + 1024 : 1024);
-      if (!s.corpus.reserve(nb + 64) || !s.doc.reserve((D + 1) * 8) || !s.dho.reserve((D + 1) * 8) ||
-          !s.out.reserve(want * sizeof(aha_hit))) {
-        s.rc = AHA_E_HIP;
-        return;
-      }
-      if ((nb && hipMemcpyAsync(s.corpus.p, corpus + b0, nb, hipMemcpyHostToDevice, s.stream) != hipSuccess) ||
-          hipMemcpyAsync(s.doc.p, rel.data(), (D + 1) * 8, hipMemcpyHostToDevice, s.stream) != hipSuccess ||
-          hipStreamSynchronize(s.stream) != hipSuccess) {
-        s.rc = AHA_E_HIP;
-        return;
-      }
-      const auto t0 = std::chrono::steady_clock::now();
-      for (int attempt = 0; attempt < 2; attempt++) {
-        uint64_t nh = 0;
-        s.rc = aha_ac_match_batch_device(s.ac, (const uint8_t *)s.corpus.p, (const uint64_t *)s.doc.p, D, nb, params,
-                                         (aha_hit *)s.out.p, s.out.bytes / sizeof(aha_hit), (uint64_t *)s.dho.p, &nh,
-                                         s.stream);
-        s.n_hits = nh;
-        if (s.rc != AHA_E_CAPACITY) break;
-        if (!s.out.reserve(nh * sizeof(aha_hit))) {  // the call told the exact count: once more with room
-          s.rc = AHA_E_HIP;
-          return;
+    s.rc = AHA_E_NOMEM;
+    s.err = "worker thread not started";
+  }
+  for (size_t r = 0; r < n; r++) {
+    try {
+      th.emplace_back([&, r]() {
+        try {
+          work(r);
+        } catch (...) {  // bad_alloc of a host vector: no exception crosses the C boundary (or a thread's top frame)
+          g->shards[r].rc = AHA_E_NOMEM;
+          g->shards[r].err = "out of host memory";
         }
-      }
-      s.ms_match = ms_since(t0);
-      if (s.rc != AHA_OK) {
-        s.err = aha_last_error(s.ac);  // the text is the calling thread's: take it along
-        return;
-      }
-      if (hipMemcpy(s.h_dho.data(), s.dho.p, (D + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) s.rc = AHA_E_HIP;
-    });
+      });
+    } catch (...) {
+      break;  // thread creation failed: the shards started so far are joined below, the rest keep AHA_E_NOMEM
+    }
   }
   for (auto &t : th) t.join();
   T.ms_match = (float)ms_since(t_all);
@@ -259,16 +304,14 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   std::vector<uint64_t> base(n + 1, 0);
   for (size_t r = 0; r < n; r++) {
     Shard &s = g->shards[r];
-    if (s.rc != AHA_OK) {
-      g->err = std::string("shard ") + std::to_string(r) + ": " + s.err;
-      return s.rc;
-    }
+    if (s.rc != AHA_OK) return fail(s.rc, std::string("shard ") + std::to_string(r) + ": " + s.err);
     T.ms_match_max_shard = std::max(T.ms_match_max_shard, (float)s.ms_match);
     base[r] = total;
     total += s.n_hits;
   }
   base[n] = total;
   *n_hits = total;
+  T.n_hits = total;
   if (doc_hit_offsets) {
     for (size_t r = 0; r < n; r++) {
       const Shard &s = g->shards[r];
@@ -276,42 +319,42 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     }
     doc_hit_offsets[n_docs] = total;
   }
+  // the caller's buffer is too small: say so before anything is exchanged (count and offsets are already final)
+  if (total > cap) return fail(AHA_E_CAPACITY, "output buffer too small");
 
   // ---- all-gatherv of the hit buffers: every device gets the whole ordered stream
   const auto t_x = std::chrono::steady_clock::now();
   for (size_t r = 0; r < n; r++) {
     Shard &s = g->shards[r];
-    if (hipSetDevice(s.device) != hipSuccess || !s.all.reserve(std::max<uint64_t>(total, 1) * sizeof(aha_hit))) {
-      g->err = "hipMalloc failed for the gathered hits";
-      return AHA_E_HIP;
-    }
+    if (hipSetDevice(s.device) != hipSuccess || !s.all.reserve(std::max<uint64_t>(total, 1) * sizeof(aha_hit)))
+      return fail(AHA_E_HIP, "hipMalloc failed for the gathered hits");
   }
+  enum Transport { kCopies = 0, kRccl = 1, kSelfRccl = 2 };
+  const Transport via = (g->distinct && n > 1) ? kRccl : (g->self_rccl ? kSelfRccl : kCopies);
   // What travels: the 4-byte stream of include/aha_hip.h (aha_ac_hits_pack4_device) when the key ids fit 20 bits,
-  // else the 12-byte triples.  Same code for both transports, so the packed path runs on a one-GPU box too.
+  // else the 12-byte triples.  Same code for every transport, so the packed path runs on a one-GPU box too.
   aha_ac_info_t info{};
   info.struct_size = sizeof(info);
   (void)aha_ac_info(g->shards[0].ac, &info);
-  const bool words = n > 1 && info.n_keys <= (1u << 20);
+  const bool words = (n > 1 || via == kSelfRccl) && info.n_keys <= (1u << 20);
   const int chars = (params && params->char_offsets) ? 1 : 0;
   std::vector<uint64_t> ebase(n + 1, 0);  // in 32-bit elements
   if (words) {
     for (size_t r = 0; r < n; r++) {
       Shard &s = g->shards[r];
       const uint64_t capw = 2 * s.n_hits + (s.n_hits + 1023) / 1024 + 16;
-      if (hipSetDevice(s.device) != hipSuccess || !s.pk.reserve(capw * 4) || !s.nw.reserve(8)) return AHA_E_HIP;
+      if (hipSetDevice(s.device) != hipSuccess || !s.pk.reserve(capw * 4) || !s.nw.reserve(8))
+        return fail(AHA_E_HIP, "hipMalloc failed for the packed stream");
       int32_t rc = aha_ac_hits_pack4_device(s.ac, (const aha_hit *)s.out.p, s.n_hits, (uint32_t *)s.pk.p, capw,
                                             (uint64_t *)s.nw.p, s.stream);
-      if (rc != AHA_OK) {
-        g->err = std::string("pack: ") + aha_last_error(s.ac);
-        return rc;
-      }
+      if (rc != AHA_OK) return fail(rc, std::string("pack: ") + aha_last_error(s.ac));
     }
     for (size_t r = 0; r < n; r++) {
       Shard &s = g->shards[r];
       if (hipSetDevice(s.device) != hipSuccess ||
           hipMemcpyAsync(&s.n_words, s.nw.p, 8, hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
           hipStreamSynchronize(s.stream) != hipSuccess)
-        return AHA_E_HIP;
+        return fail(AHA_E_HIP, "reading the stream length failed");
     }
   } else {
     for (size_t r = 0; r < n; r++) g->shards[r].n_words = g->shards[r].n_hits * 3;
@@ -321,83 +364,115 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   if (words)
     for (size_t r = 0; r < n; r++) {
       Shard &s = g->shards[r];
-      if (hipSetDevice(s.device) != hipSuccess || !s.land.reserve(std::max<uint64_t>(ebase[n], 1) * 4)) return AHA_E_HIP;
+      if (hipSetDevice(s.device) != hipSuccess || !s.land.reserve(std::max<uint64_t>(ebase[n], 1) * 4))
+        return fail(AHA_E_HIP, "hipMalloc failed for the landing area");
     }
   // payload of shard p as shard r sees it arrive: triples land in place, words in the landing area
   auto landing = [&](Shard &s, size_t p) -> void * {
     return words ? (void *)((uint32_t *)s.land.p + ebase[p]) : (void *)((aha_hit *)s.all.p + base[p]);
   };
   auto payload = [&](const Shard &q) -> const void * { return words ? q.pk.p : q.out.p; };
-  if (g->distinct && n > 1) {
+  if (via != kCopies) {
     if (g->comms.empty()) {
       if (!g->rccl.load(g->err)) return AHA_E_HIP;
-      std::vector<int> devs;
-      for (const Shard &s : g->shards) devs.push_back(s.device);
       g->comms.assign(n, nullptr);
-      if (g->rccl.CommInitAll(g->comms.data(), (int)n, devs.data()) != 0) {
+      bool ok = true;
+      if (via == kRccl) {  // one communicator, rank r on devices[r]
+        std::vector<int> devs;
+        for (const Shard &s : g->shards) devs.push_back(s.device);
+        ok = g->rccl.CommInitAll(g->comms.data(), (int)n, devs.data()) == 0;
+      } else {  // rehearsal: one communicator of ONE rank per shard
+        for (size_t r = 0; r < n && ok; r++) {
+          const int dev = g->shards[r].device;
+          ok = g->rccl.CommInitAll(&g->comms[r], 1, &dev) == 0;
+        }
+      }
+      if (!ok) {
+        for (ncclComm_t c : g->comms)
+          if (c) (void)g->rccl.CommDestroy(c);
         g->comms.clear();
-        g->err = "ncclCommInitAll failed";
-        return AHA_E_HIP;
+        return fail(AHA_E_HIP, "ncclCommInitAll failed");
       }
     }
     bool ok = g->rccl.GroupStart() == 0;
     for (size_t r = 0; r < n && ok; r++) {
       Shard &s = g->shards[r];
+      ok = hipSetDevice(s.device) == hipSuccess;  // the calls of rank r are made with its device current
       for (size_t p = 0; p < n && ok; p++) {
-        if (p == r) continue;
-        if (s.n_words) ok = ok && g->rccl.Send(payload(s), s.n_words, kNcclInt32, (int)p, g->comms[r], s.stream) == 0;
+        if (via == kRccl ? p == r : p != r) continue;  // real exchange: every peer; rehearsal: the own stream only
+        const int peer = via == kRccl ? (int)p : 0;
+        if (s.n_words) ok = ok && g->rccl.Send(payload(s), s.n_words, kNcclInt32, peer, g->comms[r], s.stream) == 0;
         if (g->shards[p].n_words)
-          ok = ok && g->rccl.Recv(landing(s, p), g->shards[p].n_words, kNcclInt32, (int)p, g->comms[r], s.stream) == 0;
+          ok = ok && g->rccl.Recv(landing(s, p), g->shards[p].n_words, kNcclInt32, peer, g->comms[r], s.stream) == 0;
       }
     }
     ok = (g->rccl.GroupEnd() == 0) && ok;
-    if (!ok) {
-      g->err = "RCCL send/recv failed";
-      return AHA_E_HIP;
-    }
-  } else {
+    if (!ok) return fail(AHA_E_HIP, "RCCL send/recv failed");
+  }
+  if (via != kRccl) {  // shards on one device: the peers' payloads by device-to-device copies
     for (size_t r = 0; r < n; r++) {
       Shard &s = g->shards[r];
-      if (hipSetDevice(s.device) != hipSuccess) return AHA_E_HIP;
+      if (hipSetDevice(s.device) != hipSuccess) return fail(AHA_E_HIP, "hipSetDevice failed");
       for (size_t p = 0; p < n; p++) {
         const Shard &q = g->shards[p];
         if (p != r && q.n_words &&
             hipMemcpyAsync(landing(s, p), payload(q), q.n_words * 4, hipMemcpyDeviceToDevice, s.stream) != hipSuccess)
-          return AHA_E_HIP;
+          return fail(AHA_E_HIP, "device-to-device copy failed");
       }
     }
   }
-  for (size_t r = 0; r < n; r++) {  // the own part as it is; the peers' streams rebuilt into triples at their place
+  // the own part as it is (unless it came back through RCCL: then it is rebuilt like a peer's, so the test of the
+  // rehearsal checks the bytes RCCL delivered); all streams that arrived are rebuilt into triples by ONE launch
+  const bool own_via_rccl = via == kSelfRccl;
+  for (size_t r = 0; r < n; r++) {
     Shard &s = g->shards[r];
-    if (hipSetDevice(s.device) != hipSuccess) return AHA_E_HIP;
-    if (s.n_hits && hipMemcpyAsync((aha_hit *)s.all.p + base[r], s.out.p, s.n_hits * sizeof(aha_hit),
-                                   hipMemcpyDeviceToDevice, s.stream) != hipSuccess)
-      return AHA_E_HIP;
-    for (size_t p = 0; words && p < n; p++) {
-      if (p == r || !g->shards[p].n_hits) continue;
-      int32_t rc = aha_ac_hits_unpack4_device(s.ac, (const uint32_t *)s.land.p + ebase[p], g->shards[p].n_hits, chars,
-                                              (aha_hit *)s.all.p + base[p], s.stream);
-      if (rc != AHA_OK) return rc;
+    if (hipSetDevice(s.device) != hipSuccess) return fail(AHA_E_HIP, "hipSetDevice failed");
+    if (s.n_hits && !own_via_rccl &&
+        hipMemcpyAsync((aha_hit *)s.all.p + base[r], s.out.p, s.n_hits * sizeof(aha_hit), hipMemcpyDeviceToDevice,
+                       s.stream) != hipSuccess)
+      return fail(AHA_E_HIP, "device-to-device copy failed");
+    if (!words) continue;  // triples landed in place
+    std::vector<aha_stream_seg> segs;
+    for (size_t p = 0; p < n; p++) {
+      if ((p == r && !own_via_rccl) || !g->shards[p].n_hits) continue;
+      segs.push_back(aha_stream_seg{ebase[p], g->shards[p].n_hits, base[p]});
+    }
+    for (size_t k = 0; k < segs.size(); k += 64) {
+      int32_t rc = aha_ac_hits_unpack4_segs_device(s.ac, (const uint32_t *)s.land.p, segs.data() + k,
+                                                   (uint32_t)std::min<size_t>(64, segs.size() - k), chars,
+                                                   (aha_hit *)s.all.p, s.stream);
+      if (rc != AHA_OK) return fail(rc, std::string("rebuild: ") + aha_last_error(s.ac));
     }
   }
   for (size_t r = 0; r < n; r++) {
     Shard &s = g->shards[r];
-    if (hipSetDevice(s.device) != hipSuccess || hipStreamSynchronize(s.stream) != hipSuccess) {
-      g->err = "exchange failed";
-      return AHA_E_HIP;
-    }
+    if (hipSetDevice(s.device) != hipSuccess || hipStreamSynchronize(s.stream) != hipSuccess)
+      return fail(AHA_E_HIP, "exchange failed");
   }
   T.ms_exchange = (float)ms_since(t_x);
-  T.n_hits = total;
-  T.exchange = (g->distinct && n > 1) ? 1u : 0u;
+  T.exchange = (uint32_t)via;
   T.packed = words ? 1u : 0u;
-  if (total > cap) return AHA_E_CAPACITY;
+  g->gathered = total;
   const auto t_d = std::chrono::steady_clock::now();
   Shard &s0 = g->shards[0];
   if (total && (hipSetDevice(s0.device) != hipSuccess ||
                 hipMemcpy(out, s0.all.p, total * sizeof(aha_hit), hipMemcpyDeviceToHost) != hipSuccess))
-    return AHA_E_HIP;
+    return fail(AHA_E_HIP, "download of the gathered hits failed");
   T.ms_download = (float)ms_since(t_d);
+  return AHA_OK;
+}
+
+int32_t aha_group_download_shard(aha_group *g, int32_t shard, aha_hit *out, uint64_t cap, uint64_t *n_hits) {
+  if (!g || shard < 0 || (size_t)shard >= g->shards.size() || !n_hits) return AHA_E_INVALID;
+  std::lock_guard<std::mutex> lk(g->mu);
+  *n_hits = g->gathered;
+  if (g->gathered > cap) return AHA_E_CAPACITY;
+  Shard &s = g->shards[(size_t)shard];
+  if (g->gathered && (!out || !s.all.p || hipSetDevice(s.device) != hipSuccess ||
+                      hipMemcpy(out, s.all.p, g->gathered * sizeof(aha_hit), hipMemcpyDeviceToHost) != hipSuccess)) {
+    g->err = "download of a shard's gathered hits failed";
+    return AHA_E_HIP;
+  }
   return AHA_OK;
 }
 

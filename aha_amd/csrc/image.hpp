@@ -161,6 +161,10 @@ void launch_hits_unpack(const DevAut &A, const int32_t *pairs, uint64_t n, int c
 // 4-byte exchange stream (kernels.hip): stream_words holds n + ceil(n/1024) + exceptions words (capacity 2n + ceil(n/1024))
 void launch_hits_pack4(const int32_t *hits, uint64_t n, uint32_t *stream_words, unsigned long long *n_words, void *stream);
 void launch_hits_unpack4(const DevAut &A, const uint32_t *stream_words, uint64_t n, int chars, int32_t *hits, void *stream);
+// several streams in one launch: stream k starts at word word_off[k] of `land`, holds n_hits[k] hits, goes to hits[out_off[k]..]
+constexpr uint32_t kMaxSegs = 64;
+void launch_hits_unpack4_segs(const DevAut &A, const uint32_t *land, const uint64_t *word_off, const uint64_t *n_hits,
+                              const uint64_t *out_off, uint32_t n_segs, int chars, int32_t *hits, void *stream);
 
 // flag[0] |= 1: not the offsets of n_docs documents over n_bytes; |= 2: a document of 2^31 bytes or more
 void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_bytes, uint32_t *flag, void *stream);

@@ -525,15 +525,32 @@ __global__ __launch_bounds__(kPk4Block) void k_pack4_write(const int32_t *hits, 
   if (x) exc[(uint64_t)blk[blockIdx.x] + rank] = e;
 }
 
-__global__ __launch_bounds__(kPk4Block) void k_unpack4(const uint32_t *words, uint64_t n, const uint32_t *blk,
-                                                       const int32_t *exc, const uint2 *key_ln, const uint32_t *key_kc,
-                                                       int chars, int32_t *hits) {
+// Rebuilds the Hit triples of up to kMaxSegs streams in ONE launch (an 8-GPU step receives seven): the workgroups
+// [blk0[s], blk0[s+1]) belong to stream s, which starts at word woff[s] of `land`, holds nh[s] hits and is written
+// to hits[ooff[s]..].
+struct SegTab {
+  uint32_t n;
+  uint32_t blk0[kMaxSegs + 1];
+  uint64_t woff[kMaxSegs], nh[kMaxSegs], ooff[kMaxSegs];
+};
+
+__global__ __launch_bounds__(kPk4Block) void k_unpack4(const uint32_t *land, SegTab S, const uint2 *key_ln,
+                                                       const uint32_t *key_kc, int chars, int32_t *hits_all) {
   __shared__ uint32_t wcnt[16];
   __shared__ int32_t wagg[16];
   __shared__ uint32_t wflag[16];
   __shared__ int32_t stage[kPk4Block * 3];
+  uint32_t seg = 0;
+  while (seg + 1 < S.n && blockIdx.x >= S.blk0[seg + 1]) seg++;  // wave-uniform: a handful of scalar compares
+  const uint32_t bid = blockIdx.x - S.blk0[seg];
+  const uint64_t n = S.nh[seg];
+  const uint64_t nb = (n + kPk4Block - 1) / kPk4Block;
+  const uint32_t *words = land + S.woff[seg];
+  const uint32_t *blk = words + n;
+  const int32_t *exc = reinterpret_cast<const int32_t *>(words + n + nb);
+  int32_t *hits = hits_all + S.ooff[seg] * 3;
   const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const uint64_t i = (uint64_t)blockIdx.x * kPk4Block + t;
+  const uint64_t i = (uint64_t)bid * kPk4Block + t;
   const bool valid = i < n;
   const uint32_t wd = valid ? words[i] : 0u;
   const uint32_t step = wd & 0xFFFu, value = wd >> 12;
@@ -543,7 +560,7 @@ __global__ __launch_bounds__(kPk4Block) void k_unpack4(const uint32_t *words, ui
   __syncthreads();
   uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   for (uint32_t u = 0; u < w; u++) rank += wcnt[u];
-  int32_t x = f ? exc[(uint64_t)blk[blockIdx.x] + rank] : (int32_t)step;
+  int32_t x = f ? exc[(uint64_t)blk[bid] + rank] : (int32_t)step;
   // segmented inclusive scan inside the wave: an exception restarts the sum
   uint32_t fl = f ? 1u : 0u;
   for (int o = 1; o < 64; o <<= 1) {
@@ -570,7 +587,7 @@ __global__ __launch_bounds__(kPk4Block) void k_unpack4(const uint32_t *words, ui
   stage[t * 3 + 1] = x;
   stage[t * 3 + 2] = (int32_t)value;
   __syncthreads();
-  const uint64_t base = (uint64_t)blockIdx.x * kPk4Block * 3;
+  const uint64_t base = (uint64_t)bid * kPk4Block * 3;
   const uint64_t total = n * 3;
   for (uint32_t k = 0; k < 3; k++) {
     const uint64_t j = base + k * kPk4Block + t;
@@ -589,13 +606,29 @@ void launch_hits_pack4(const int32_t *hits, uint64_t n, uint32_t *stream_words, 
   if (nb) hipLaunchKernelGGL(k_pack4_write, dim3((uint32_t)nb), dim3(kPk4Block), 0, s, hits, n, words, blk, exc);
 }
 
+void launch_hits_unpack4_segs(const DevAut &A, const uint32_t *land, const uint64_t *word_off, const uint64_t *n_hits,
+                              const uint64_t *out_off, uint32_t n_segs, int chars, int32_t *hits, void *stream) {
+  SegTab S{};
+  uint32_t blocks = 0;
+  for (uint32_t k = 0; k < n_segs && S.n < kMaxSegs; k++) {
+    if (!n_hits[k]) continue;
+    S.blk0[S.n] = blocks;
+    S.woff[S.n] = word_off[k];
+    S.nh[S.n] = n_hits[k];
+    S.ooff[S.n] = out_off[k];
+    blocks += (uint32_t)((n_hits[k] + kPk4Block - 1) / kPk4Block);
+    S.n++;
+  }
+  S.blk0[S.n] = blocks;
+  if (!blocks) return;
+  hipLaunchKernelGGL(k_unpack4, dim3(blocks), dim3(kPk4Block), 0, (hipStream_t)stream, land, S, A.key_ln, A.key_kc,
+                     chars, hits);
+}
+
 void launch_hits_unpack4(const DevAut &A, const uint32_t *stream_words, uint64_t n, int chars, int32_t *hits,
                          void *stream) {
-  if (!n) return;
-  const uint64_t nb = (n + kPk4Block - 1) / kPk4Block;
-  hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)nb), dim3(kPk4Block), 0, (hipStream_t)stream, stream_words, n,
-                     stream_words + n, reinterpret_cast<const int32_t *>(stream_words + n + nb), A.key_ln, A.key_kc,
-                     chars, hits);
+  const uint64_t zero = 0;
+  launch_hits_unpack4_segs(A, stream_words, &zero, &n, &zero, 1, chars, hits, stream);
 }
 
 // -------------------------------------------------- device-resident doc offsets

@@ -87,7 +87,12 @@ enum : int {
   kDgSplit = 9,         // exact walk; ds_read for the near lanes + global_load for the far lanes instead of one flat_load
   kDgFarL1 = 10,        // (T) far probes go to an 8 KiB window of the global image (L1 hits): the flat path without L2
   kDgStorePlain = 11,   // exact walk; plain instead of non-temporal event stores
-  kDgCount = 12
+  kDgFarNt = 12,        // exact walk; split loads, the far load non-temporal (nt)
+  kDgFarSc1 = 13,       // exact walk; split loads, the far load agent-coherent (sc1: served by L2, no L1 allocation)
+  kDgFarWide = 14,      // exact walk; split loads, the far load 8 bytes wide (the slot and its neighbour)
+  kDgFar40 = 15,        // (T) 40 % of the far PROBES (not headers) answered from LDS as misses: a perfect 8-bit child filter
+  kDgStoreNt = 16,      // exact walk; event stores really non-temporal (buffer store, aux = nt; regions below 4 GiB only)
+  kDgCount = 17
 };
 #ifdef AHA_DIAG
 // per wave: 16 words = cycles of the segments A..E for wave-trips without / with a far lane, then the two trip counts
@@ -375,9 +380,14 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             const uint32_t bnext = inl[rel + 1];                    // rows are padded: rel + 1 <= piece + 3
             const uint32_t c = b & hm;
             uint32_t idx = B ^ c;
-            if constexpr (DG == kDgNoFar || DG == kDgNoFarNoStore) idx = idx < T ? idx : (idx & 16383u);
-            if constexpr (DG == kDgFarHalf) idx = (idx >= T && ((idx * 0x9E3779B1u) >> 31)) ? (idx & 16383u) : idx;
-            if constexpr (DG == kDgFarL1) idx = idx < T ? idx : T + (idx & 2047u);
+            // timing-only variants redirect PROBE trips only: a header trip (hm == 0) that never finds its header would
+            // repeat forever
+            if constexpr (DG == kDgNoFar || DG == kDgNoFarNoStore) idx = (idx < T || hm == 0) ? idx : (idx & 16383u);
+            if constexpr (DG == kDgFarHalf)
+              idx = (idx >= T && hm != 0 && ((idx * 0x9E3779B1u) >> 31)) ? (idx & 16383u) : idx;
+            if constexpr (DG == kDgFar40)
+              idx = (idx >= T && hm != 0 && ((idx * 0x9E3779B1u) >> 24) < 102u) ? (idx & 16383u) : idx;
+            if constexpr (DG == kDgFarL1) idx = (idx < T || hm == 0) ? idx : T + (idx & 2047u);
             if constexpr (DG == kDgStamp) dg_anyfar = __any(idx >= T);
             const slot_t e0 = lt[root ^ b];                         // root row: always LDS resident
             const slot_t e2 = lt[S_::base(r1) ^ b];                 // depth-1 rows: always LDS resident
@@ -386,9 +396,22 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             const bool near3 = i3 < T;
             const slot_t e3 = lt[near3 ? i3 : 0u];                  // sx's row (depth <= 2: mostly LDS resident)
             slot_t en;
-            if constexpr (DG == kDgSplit) {
+            if constexpr (DG == kDgSplit || DG == kDgFarNt || DG == kDgFarSc1 || DG == kDgFarWide) {
               en = lt[idx < T ? idx : 0u];
-              if (idx >= T) en = gt[idx];
+              if (idx >= T) {
+                if constexpr (DG == kDgFarNt) {  // hipcc drops __builtin_nontemporal_* on gfx950: buffer load with aux = nt
+                  en = __builtin_amdgcn_raw_buffer_load_b32(
+                      __builtin_amdgcn_make_buffer_rsrc(const_cast<slot_t *>(gt), 0, (int)(A.n_slots * 4u), 0x00020000),
+                      (int)(idx * 4u), 0, 2);
+                } else if constexpr (DG == kDgFarSc1) {
+                  en = __hip_atomic_load(gt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if constexpr (DG == kDgFarWide) {
+                  const uint2 w2 = *reinterpret_cast<const uint2 *>(gt + (idx & ~1u));
+                  en = (idx & 1u) ? w2.y : w2.x;
+                } else {
+                  en = gt[idx];
+                }
+              }
             } else {
               if (idx < T)
                 en = lt[idx];
@@ -463,6 +486,10 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
                 // than one hit per 4 bytes) fill whole lines quickly and are better merged in L2
                 if constexpr (DG == kDgNoStore || DG == kDgNoFarNoStore) {
                   dg_dummy ^= rec.x ^ rec.y;
+                } else if constexpr (DG == kDgStoreNt) {
+                  __builtin_amdgcn_raw_buffer_store_b64(
+                      rec, __builtin_amdgcn_make_buffer_rsrc(M.evd, 0, -1, 0x00020000),
+                      (int)(((uint32_t)chunk * ev_stride + seq) * 8u), 0, 2);
                 } else if (M.dense_hits || DG == kDgStorePlain) {
                   *reinterpret_cast<v2u *>(evreg + seq) = rec;
                 } else {
@@ -970,6 +997,11 @@ static void diag_launch(const DevAut &A, const V2Args &M, uint32_t grid, size_t 
     case 9: diag_launch_one<9>(A, M, grid, lds, s); break;
     case 10: diag_launch_one<10>(A, M, grid, lds, s); break;
     case 11: diag_launch_one<11>(A, M, grid, lds, s); break;
+    case 12: diag_launch_one<12>(A, M, grid, lds, s); break;
+    case 13: diag_launch_one<13>(A, M, grid, lds, s); break;
+    case 14: diag_launch_one<14>(A, M, grid, lds, s); break;
+    case 15: diag_launch_one<15>(A, M, grid, lds, s); break;
+    case 16: diag_launch_one<16>(A, M, grid, lds, s); break;
     default: break;
   }
 }

@@ -58,7 +58,8 @@ enum {
   AHA_E_HIP = -8,         /* a HIP runtime call failed; see aha_last_error */
   AHA_E_TOO_LONG = -9,    /* a sequence is >= 2^31 bytes (Int32 offsets, src/aha/matcher.cr:3-5) */
   AHA_E_NOT_FOUND = -10,  /* key / id lookup miss (IndexError in the reference, src/aha/cedar.cr:830-834) */
-  AHA_E_TOO_LARGE = -11   /* automaton exceeds the device image limits */
+  AHA_E_TOO_LARGE = -11,  /* automaton exceeds the device image limits */
+  AHA_E_NOMEM = -12       /* host memory exhausted (no exception crosses the boundary) */
 };
 
 /* Compile-time options.  Zero-initialise and set struct_size. */
@@ -213,6 +214,15 @@ int32_t aha_ac_hits_pack4_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, 
                                  uint64_t cap_words, uint64_t *d_n_words, void *stream);
 int32_t aha_ac_hits_unpack4_device(aha_ac *ac, const uint32_t *d_words, uint64_t n, int32_t char_offsets,
                                    aha_hit *d_hits, void *stream);
+/* Several streams rebuilt by ONE launch (an 8-GPU step receives seven peers' streams): stream k starts at word
+ * word_offset of d_words, holds n_hits hits and is written to d_hits[out_offset ..].  At most 64 segments. */
+typedef struct {
+  uint64_t word_offset;
+  uint64_t n_hits;
+  uint64_t out_offset;
+} aha_stream_seg;
+int32_t aha_ac_hits_unpack4_segs_device(aha_ac *ac, const uint32_t *d_words, const aha_stream_seg *segs,
+                                        uint32_t n_segs, int32_t char_offsets, aha_hit *d_hits, void *stream);
 
 /* Copies one array of the automaton image (as uploaded to HBM) into buf;
  * returns its size in bytes (call with cap_bytes = 0 to size the buffer).
@@ -267,7 +277,9 @@ int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t);
  * holds the whole ordered hit stream, and come back to the caller exactly as aha_ac_match_batch would return them.
  * Between distinct devices the exchange is RCCL over xGMI (all-pairs ncclSend/ncclRecv in one group; librccl.so is
  * loaded on first use); entries that name the same device twice -- several shards on one GPU, the form a 1-GPU box
- * can run -- exchange with device-to-device copies.  Buffers are host memory; the calls block. */
+ * can run -- exchange with device-to-device copies.  Buffers are host memory; the calls block; calls on one group
+ * are serialised inside the library.  The capacity is checked before the exchange: on AHA_E_CAPACITY the devices
+ * hold their own shards' hits only. */
 typedef struct aha_group aha_group;
 
 typedef struct {
@@ -278,7 +290,9 @@ typedef struct {
   float ms_exchange;         /* the all-gatherv of the hit buffers */
   float ms_download;         /* gathered hits -> caller's buffer */
   uint64_t n_hits;
-  uint32_t exchange;         /* 1 = RCCL between distinct devices, 0 = device-to-device copies on one device */
+  uint32_t exchange;         /* 1 = RCCL between distinct devices, 0 = device-to-device copies on one device,
+                                2 = the rehearsal AHA_GROUP_RCCL=self: every shard's own stream through RCCL (one
+                                communicator of one rank per shard), the peers' by copies */
   uint32_t packed;           /* 1 = the 4-byte exchange stream travelled, 0 = the 12-byte triples (2^20 keys or more) */
   uint64_t wire_bytes;       /* payload bytes of all shards together (each goes to every other shard) */
 } aha_group_timing;
@@ -295,6 +309,9 @@ int32_t aha_group_partition(const uint64_t *doc_offsets, uint64_t n_docs, int32_
 int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
                               const aha_match_params *params, aha_hit *out, uint64_t cap,
                               uint64_t *doc_hit_offsets, uint64_t *n_hits);
+/* The gathered hit stream as device `shard` holds it after the last aha_group_match_batch (every device holds the
+ * whole ordered stream: this is how a test, or a caller that wants a particular device's copy, reads it back). */
+int32_t aha_group_download_shard(aha_group *g, int32_t shard, aha_hit *out, uint64_t cap, uint64_t *n_hits);
 int32_t aha_group_last_timing(const aha_group *g, aha_group_timing *t);
 
 #ifdef __cplusplus

@@ -32,6 +32,10 @@ void launch_hits_pack(const int32_t *, uint64_t, int32_t *, void *) { no_gpu("la
 void launch_hits_unpack(const DevAut &, const int32_t *, uint64_t, int, int32_t *, void *) { no_gpu("launch_hits_unpack"); }
 void launch_hits_pack4(const int32_t *, uint64_t, uint32_t *, unsigned long long *, void *) { no_gpu("launch_hits_pack4"); }
 void launch_hits_unpack4(const DevAut &, const uint32_t *, uint64_t, int, int32_t *, void *) { no_gpu("launch_hits_unpack4"); }
+void launch_hits_unpack4_segs(const DevAut &, const uint32_t *, const uint64_t *, const uint64_t *, const uint64_t *, uint32_t,
+                              int, int32_t *, void *) {
+  no_gpu("launch_hits_unpack4_segs");
+}
 void launch_check_docs(const uint64_t *, uint64_t, uint64_t, uint32_t *, void *) { no_gpu("launch_check_docs"); }
 void launch_count(const DevAut &, const MatchArgs &, void *) { no_gpu("launch_count"); }
 void launch_scan_blocks(const MatchArgs &, uint64_t, void *) { no_gpu("launch_scan_blocks"); }

@@ -722,6 +722,20 @@ def test_exchange_words_round_trip(engine):
         g.hits_unpack4_device(words, n, back, chars=chars)
         torch.cuda.synchronize()
         assert torch.equal(back[:n], out[:n]) and bool((back[n:] == -7).all())
+        # several streams rebuilt by ONE launch (what an 8-GPU step does with its seven peers' streams): three copies
+        # of this stream and an empty one, at word offsets and in an order that have nothing to do with the output order
+        nw = int(n_words[0])
+        land = torch.full((3 * nw + 5,), -1, dtype=torch.int32, device=dev)
+        place = [2 * nw + 5, 0, nw + 2]
+        for q in place:
+            land[q:q + nw] = words[:nw]
+        multi = torch.full((3 * n + 3, 3), -7, dtype=torch.int32, device=dev)
+        g.hits_unpack4_segs_device(land, [(place[0], n, 2 * n), (0, 0, 0), (place[1], n, 0), (place[2], n, n)], multi,
+                                   chars=chars)
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert torch.equal(multi[k * n:(k + 1) * n], out[:n]), k
+        assert bool((multi[3 * n:] == -7).all())
         if n > 50_000 and not chars:
             assert want.numel() < n + n // 16  # about 4 bytes per hit where hits are dense
     with pytest.raises(AhaError):
@@ -793,14 +807,24 @@ def test_hit_gatherer_device_path(engine, exchange):
         assert per_hit < 4.2
 
 
-def test_group_of_shards_on_one_device(engine):
+@pytest.mark.parametrize("transport", ["copies", "self-rccl"])
+def test_group_of_shards_on_one_device(engine, transport, monkeypatch):
     """aha_group_match_batch with three shards on cuda:0 (device list [0, 0, 0]): partition, concurrent matches on
-    three handles / streams, all-gatherv by device-to-device copies -- the RCCL leg needs distinct devices and is
-    not executable on a 1-GPU box.  Same hits and offsets as the single handle and the oracle."""
+    three handles / streams, all-gatherv of the 4-byte stream, rebuild of all arrived streams by one launch.
+    "copies": the peers' streams travel by device-to-device copies.  "self-rccl" (AHA_GROUP_RCCL=self): every shard
+    also sends its OWN stream to itself through RCCL -- one communicator of one rank per shard, grouped
+    ncclSend/ncclRecv through the same payload()/landing() code as the real exchange -- and its part of the gathered
+    buffer is rebuilt from what RCCL delivered: dlopen of librccl.so, the symbol signatures, ncclInt32,
+    ncclCommInitAll and the ordering behind the pack kernels run on this one GPU (only the n > 1 topology does not).
+    Same hits and offsets as the single handle and the oracle, in EVERY shard's gathered buffer."""
     if engine != "v2":
         pytest.skip("once, on the default engine")
     from aha_amd import ACGroup
 
+    if transport == "self-rccl":
+        monkeypatch.setenv("AHA_GROUP_RCCL", "self")
+    else:
+        monkeypatch.delenv("AHA_GROUP_RCCL", raising=False)
     blob, offs, nf = synth.keys(3, K=20_000)
     corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 23, doc_bytes=1 << 16)
     grp = ACGroup.compile_packed(blob, offs, [0, 0, 0])
@@ -809,9 +833,17 @@ def test_group_of_shards_on_one_device(engine):
         oh, od = o.match_batch(corpus, doc, chars=chars)
         gh, gd = grp.match_batch(corpus, doc, chars=chars, cap=16)  # too small first: the capacity protocol
         assert np.array_equal(gd, od) and gh.tobytes() == oh.tobytes()
+        for shard in range(3):  # every device holds the whole ordered stream
+            assert grp.download_shard(shard).tobytes() == oh.tobytes(), (chars, shard)
     t = grp.last_timing()
-    assert t["n_devices"] == 3 and t["exchange"] == 0 and t["n_hits"] == len(oh)
+    assert t["n_devices"] == 3 and t["exchange"] == (2 if transport == "self-rccl" else 0) and t["n_hits"] == len(oh)
     assert t["packed"] == 1 and t["wire_bytes"] < 4.3 * len(oh)  # the 4-byte stream travelled between the shards
+    if transport == "self-rccl":  # a group of ONE shard has nothing to exchange -- except in this mode
+        g1 = ACGroup.compile_packed(blob, offs, [0])
+        gh, gd = g1.match_batch(corpus, doc)
+        oh, od = o.match_batch(corpus, doc)
+        assert np.array_equal(gd, od) and gh.tobytes() == oh.tobytes() and g1.download_shard(0).tobytes() == oh.tobytes()
+        assert g1.last_timing()["exchange"] == 2
     # ragged: fewer documents than shards, empty documents, an empty batch
     g2 = ACGroup.compile(["ab", "b"], [0, 0, 0, 0])
     o2 = orc.AC.compile(["ab", "b"])

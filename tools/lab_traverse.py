@@ -29,12 +29,17 @@ import torch  # noqa: E402
 KNOBS = [
     (0, "product kernel", "exact"),
     (11, "plain (not non-temporal) event stores", "exact"),
+    (16, "event stores really non-temporal (buffer store, aux nt)", "exact"),
     (9, "ds_read (near) + global_load (far) instead of one flat_load", "exact"),
+    (12, "split loads, far load non-temporal (nt)", "exact"),
+    (13, "split loads, far load sc1 (L2-served, no L1 allocation)", "exact"),
+    (14, "split loads, far load 8 bytes wide", "exact"),
     (5, "+1 independent far load per far lane", "exact"),
     (6, "+16 dependent VALU per trip", "exact"),
     (7, "+1 random ds_read_b32 per trip", "exact"),
     (3, "no event stores", "timing"),
     (1, "no far probes (answered from LDS)", "timing"),
+    (15, "40 % of the far probes answered from LDS as misses", "timing"),
     (2, "half of the far probes answered from LDS", "timing"),
     (10, "far probes answered by an 8 KiB window (L1 hits)", "timing"),
     (4, "no far probes, no event stores", "timing"),
@@ -56,6 +61,8 @@ def main():
     def say(s=""):
         print(s, flush=True)
         lines.append(s)
+        with open(args.out, "w") as f:  # partial results survive a killed run
+            f.write("\n".join(lines) + "\n")
 
     from aha_amd import AC, AhaError, synth
     from aha_amd import _native as N

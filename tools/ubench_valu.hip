@@ -33,15 +33,21 @@ constexpr int REPS = 2000;
 
 enum Kind {
   K_XOR, K_AND, K_ADD, K_LSHR, K_CNDMASK_VCC, K_CNDMASK_SGPR, K_CMP_CND, K_BFE, K_LSHL_ADD, K_BITOP3, K_CMP_SDWA,
-  K_MUL_LO, K_PERM, K_AND_OR, K_CMP_ONLY, K_MAD_U24, K_COUNT
+  K_MUL_LO, K_PERM, K_AND_OR, K_CMP_ONLY, K_MAD_U24,
+  K_CMP32_CND32, K_CND32_OTHER_DST, K_CND64_VCC, K_XOR_E64, K_MIX_23, K_MOV, K_SALU_MIX, K_XOR3, K_ADD3, K_CMP32_ONLY,
+  K_COUNT
 };
 static const char *kNames[K_COUNT] = {
     "v_xor_b32", "v_and_b32", "v_add_u32", "v_lshrrev_b32", "v_cndmask_b32 (vcc)", "v_cndmask_b32 (sgpr pair)",
     "v_cmp_eq_u32 + v_cndmask (pair, counted as 2)", "v_bfe_u32", "v_lshl_add_u32", "v_bitop3_b32",
     "v_cmp_eq_u32_sdwa + v_cndmask (2)", "v_mul_lo_u32", "v_perm_b32", "v_and_or_b32", "v_cmp_eq_u32 e64 (sgpr dst)",
-    "v_mad_u32_u24"};
+    "v_mad_u32_u24",
+    "v_cmp_eq_u32_e32 vcc + v_cndmask_b32_e32 vcc (2)", "v_cndmask_b32_e32 vcc, dst != src", "v_cndmask_b32_e64 ..., vcc",
+    "v_xor_b32_e64 (VOP3 encoding of a VOP2 op)", "v_xor_b32 / v_bfe_u32 alternating (VOP2, VOP3)", "v_mov_b32",
+    "v_xor_b32 + s_and_b64 alternating (VALU counted)", "v_or3_b32", "v_add3_u32", "v_cmp_eq_u32_e32 (vcc dst)"};
 // instructions per macro expansion (16 uses of the pattern)
-static const int kPerBlock[K_COUNT] = {16, 16, 16, 16, 16, 16, 32, 16, 16, 16, 32, 16, 16, 16, 16, 16};
+static const int kPerBlock[K_COUNT] = {16, 16, 16, 16, 16, 16, 32, 16, 16, 16, 32, 16, 16, 16, 16, 16,
+                                       32, 16, 16, 16, 32, 16, 16, 16, 16, 16};
 
 template <int KIND, bool DEP>
 __global__ __launch_bounds__(1024) void valu(unsigned long long *cyc, uint32_t *sink, uint32_t seed) {
@@ -85,6 +91,44 @@ __global__ __launch_bounds__(1024) void valu(unsigned long long *cyc, uint32_t *
     if (KIND == K_PERM) { BODY4(R16("v_perm_b32 %0, %0, %4, %4\n"), R4("v_perm_b32 %0, %0, %4, %4\nv_perm_b32 %1, %1, %4, %4\nv_perm_b32 %2, %2, %4, %4\nv_perm_b32 %3, %3, %4, %4\n")) }
     if (KIND == K_AND_OR) { BODY4(R16("v_and_or_b32 %0, %0, %4, %4\n"), R4("v_and_or_b32 %0, %0, %4, %4\nv_and_or_b32 %1, %1, %4, %4\nv_and_or_b32 %2, %2, %4, %4\nv_and_or_b32 %3, %3, %4, %4\n")) }
     if (KIND == K_CMP_ONLY) { BODY4(R16("v_cmp_eq_u32_e64 s[20:21], %0, %4\n"), R4("v_cmp_eq_u32_e64 s[20:21], %0, %4\nv_cmp_eq_u32_e64 s[20:21], %1, %4\nv_cmp_eq_u32_e64 s[20:21], %2, %4\nv_cmp_eq_u32_e64 s[20:21], %3, %4\n")) }
+    if (KIND == K_CMP32_CND32) {
+      BODY4(R16("v_cmp_eq_u32_e32 vcc, %0, %4\nv_cndmask_b32_e32 %0, %0, %4, vcc\n"),
+            R4("v_cmp_eq_u32_e32 vcc, %0, %4\nv_cndmask_b32_e32 %1, %1, %4, vcc\nv_cmp_eq_u32_e32 vcc, %1, %4\nv_cndmask_b32_e32 %2, %2, %4, vcc\n"
+               "v_cmp_eq_u32_e32 vcc, %2, %4\nv_cndmask_b32_e32 %3, %3, %4, vcc\nv_cmp_eq_u32_e32 vcc, %3, %4\nv_cndmask_b32_e32 %0, %0, %4, vcc\n"))
+    }
+    if (KIND == K_CND32_OTHER_DST) {
+      BODY4(R16("v_cndmask_b32_e32 %1, %0, %4, vcc\n"),
+            R4("v_cndmask_b32_e32 %1, %0, %4, vcc\nv_cndmask_b32_e32 %2, %0, %4, vcc\nv_cndmask_b32_e32 %3, %0, %4, vcc\nv_cndmask_b32_e32 %1, %0, %4, vcc\n"))
+    }
+    if (KIND == K_CND64_VCC) {
+      BODY4(R16("v_cndmask_b32_e64 %0, %0, %4, vcc\n"),
+            R4("v_cndmask_b32_e64 %0, %0, %4, vcc\nv_cndmask_b32_e64 %1, %1, %4, vcc\nv_cndmask_b32_e64 %2, %2, %4, vcc\nv_cndmask_b32_e64 %3, %3, %4, vcc\n"))
+    }
+    if (KIND == K_XOR_E64) {
+      BODY4(R16("v_xor_b32_e64 %0, %0, %4\n"),
+            R4("v_xor_b32_e64 %0, %0, %4\nv_xor_b32_e64 %1, %1, %4\nv_xor_b32_e64 %2, %2, %4\nv_xor_b32_e64 %3, %3, %4\n"))
+    }
+    if (KIND == K_MIX_23) {
+      BODY4(R4(R4("v_xor_b32 %0, %0, %4\nv_bfe_u32 %0, %0, 1, 31\n") ) ,
+            R4(R4("v_xor_b32 %0, %0, %4\nv_bfe_u32 %1, %1, 1, 31\n")))
+    }
+    if (KIND == K_MOV) {
+      BODY4(R16("v_mov_b32 %0, %4\n"), R4("v_mov_b32 %0, %4\nv_mov_b32 %1, %4\nv_mov_b32 %2, %4\nv_mov_b32 %3, %4\n"))
+    }
+    if (KIND == K_SALU_MIX) {
+      BODY4(R16("v_xor_b32 %0, %0, %4\ns_and_b64 s[20:21], s[20:21], s[20:21]\n"),
+            R4("v_xor_b32 %0, %0, %4\ns_and_b64 s[20:21], s[20:21], s[20:21]\nv_xor_b32 %1, %1, %4\ns_and_b64 s[20:21], s[20:21], s[20:21]\n"
+               "v_xor_b32 %2, %2, %4\ns_and_b64 s[20:21], s[20:21], s[20:21]\nv_xor_b32 %3, %3, %4\ns_and_b64 s[20:21], s[20:21], s[20:21]\n"))
+    }
+    if (KIND == K_XOR3) {
+      BODY4(R16("v_or3_b32 %0, %0, %4, %4\n"), R4("v_or3_b32 %0, %0, %4, %4\nv_or3_b32 %1, %1, %4, %4\nv_or3_b32 %2, %2, %4, %4\nv_or3_b32 %3, %3, %4, %4\n"))
+    }
+    if (KIND == K_ADD3) {
+      BODY4(R16("v_add3_u32 %0, %0, %4, %4\n"), R4("v_add3_u32 %0, %0, %4, %4\nv_add3_u32 %1, %1, %4, %4\nv_add3_u32 %2, %2, %4, %4\nv_add3_u32 %3, %3, %4, %4\n"))
+    }
+    if (KIND == K_CMP32_ONLY) {
+      BODY4(R16("v_cmp_eq_u32_e32 vcc, %0, %4\n"), R4("v_cmp_eq_u32_e32 vcc, %0, %4\nv_cmp_eq_u32_e32 vcc, %1, %4\nv_cmp_eq_u32_e32 vcc, %2, %4\nv_cmp_eq_u32_e32 vcc, %3, %4\n"))
+    }
     if (KIND == K_MAD_U24) { BODY4(R16("v_mad_u32_u24 %0, %0, %4, %4\n"), R4("v_mad_u32_u24 %0, %0, %4, %4\nv_mad_u32_u24 %1, %1, %4, %4\nv_mad_u32_u24 %2, %2, %4, %4\nv_mad_u32_u24 %3, %3, %4, %4\n")) }
   }
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -131,6 +175,16 @@ int main() {
   uint32_t *dsink;
   CK(hipMalloc(&dcyc, 256 * 16 * 8));
   CK(hipMalloc(&dsink, 64));
+  run_kind<K_CMP32_CND32>(dcyc, dsink);
+  run_kind<K_CND32_OTHER_DST>(dcyc, dsink);
+  run_kind<K_CND64_VCC>(dcyc, dsink);
+  run_kind<K_CMP32_ONLY>(dcyc, dsink);
+  run_kind<K_XOR_E64>(dcyc, dsink);
+  run_kind<K_MIX_23>(dcyc, dsink);
+  run_kind<K_MOV>(dcyc, dsink);
+  run_kind<K_SALU_MIX>(dcyc, dsink);
+  run_kind<K_XOR3>(dcyc, dsink);
+  run_kind<K_ADD3>(dcyc, dsink);
   run_kind<K_XOR>(dcyc, dsink);
   run_kind<K_AND>(dcyc, dsink);
   run_kind<K_ADD>(dcyc, dsink);

@@ -108,6 +108,17 @@ SIGNATURES = {
                                      C.POINTER(_u64)]),
     "aha_group_last_timing": (_i32, [_vp, C.POINTER(aha_group_timing)]),
     "aha_group_download_shard": (_i32, [_vp, _i32, _vp, _u64, C.POINTER(_u64)]),
+    "aha_buffer_alloc": (_i32, [_i32, _u64, C.POINTER(_vp)]),
+    "aha_buffer_free": (_i32, [_i32, _vp]),
+    "aha_buffer_upload": (_i32, [_i32, _vp, _vp, _u64]),
+    "aha_buffer_download": (_i32, [_i32, _vp, _vp, _u64]),
+    "aha_corpus_upload": (_i32, [_i32, _vp, _vp, _u64, C.POINTER(_vp)]),
+    "aha_corpus_free": (None, [_vp]),
+    "aha_corpus_bytes": (_vp, [_vp]),
+    "aha_corpus_doc_offsets": (_vp, [_vp]),
+    "aha_corpus_n_docs": (_u64, [_vp]),
+    "aha_corpus_n_bytes": (_u64, [_vp]),
+    "aha_corpus_device": (_i32, [_vp]),
     "aha_ac_set_profiling": (_i32, [_vp, _i32]),
     "aha_ac_last_timing": (_i32, [_vp, C.POINTER(aha_timing)]),
 }

@@ -308,6 +308,26 @@ class AC:
         self._check(rc)
         return int(n.value)
 
+    def match_corpus(self, corpus, cap=None, sep=None, chars=False, longest=0):
+        """Matches a batch that already lives in HBM (DeviceCorpus: uploaded once through the C ABI, no GPU framework
+        involved) and downloads the hits: -> (hits, doc_hit_offsets).  The upload is not repeated per call."""
+        D = corpus.n_docs
+        if cap is None:
+            cap = max(64, corpus.n_bytes // 8)
+        p = _params(chars, sep, longest)
+        dev = corpus.device
+        dho = DeviceBuffer(dev, (D + 1) * 8)
+        while True:
+            out = DeviceBuffer(dev, cap * 12)
+            n = C.c_uint64(0)
+            rc = N.lib().aha_ac_match_batch_device(self._h, corpus.ptr, corpus.doc_ptr, D, corpus.n_bytes, C.byref(p),
+                                                   out.ptr, cap, dho.ptr, C.byref(n), None)
+            if rc == N.AHA_E_CAPACITY:
+                cap = int(n.value)
+                continue
+            self._check(rc)
+            return out.download(np.zeros(int(n.value), dtype=HIT_DTYPE)), dho.download(np.zeros(D + 1, dtype=np.uint64))
+
     # -- exchange format of the multi-GPU all-gatherv: {end, value} pairs <-> Hit triples ------------
     def hits_pack_device(self, hits, n, pairs, stream=None):
         """hits [>=n,3] int32 -> pairs [>=n,2] int32, both on the handle's device (asynchronous)."""
@@ -400,6 +420,68 @@ class AC:
         t = N.aha_timing()
         self._check(N.lib().aha_ac_last_timing(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in t._fields_ if f != "struct_size"}
+
+
+class DeviceBuffer:
+    """HBM obtained through the C ABI (aha_buffer_alloc): what a caller without a GPU framework uses."""
+
+    def __init__(self, device, n_bytes):
+        self.device, self.n_bytes = device, int(n_bytes)
+        p = C.c_void_p()
+        rc = N.lib().aha_buffer_alloc(device, self.n_bytes, C.byref(p))
+        if rc != N.AHA_OK:
+            raise AhaError(rc, N.lib().aha_last_error(None).decode() or None)
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.n_bytes
+        rc = N.lib().aha_buffer_upload(self.device, self.ptr, _ptr(arr), arr.nbytes)
+        if rc != N.AHA_OK:
+            raise AhaError(rc, N.lib().aha_last_error(None).decode() or None)
+
+    def download(self, arr):
+        assert arr.flags["C_CONTIGUOUS"] and arr.nbytes <= self.n_bytes
+        rc = N.lib().aha_buffer_download(self.device, _ptr(arr), self.ptr, arr.nbytes)
+        if rc != N.AHA_OK:
+            raise AhaError(rc, N.lib().aha_last_error(None).decode() or None)
+        return arr
+
+    def __del__(self):
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p:
+            try:
+                N.lib().aha_buffer_free(self.device, p)
+            except Exception:  # interpreter shutdown
+                pass
+
+
+class DeviceCorpus:
+    """A batch resident in HBM (aha_corpus_upload): bytes of all documents + D + 1 offsets, validated on upload."""
+
+    def __init__(self, corpus, doc_offsets, device=0):
+        if isinstance(corpus, (bytes, bytearray)):
+            corpus = np.frombuffer(bytes(corpus), dtype=np.uint8)
+        corpus = np.ascontiguousarray(corpus, dtype=np.uint8)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        rc = N.lib().aha_corpus_upload(device, _ptr(corpus), _ptr(doc_offsets), doc_offsets.size - 1, C.byref(h))
+        if rc != N.AHA_OK:
+            raise AhaError(rc, N.lib().aha_last_error(None).decode() or None)
+        self._h = h
+        self.device = device
+        self.n_docs = int(N.lib().aha_corpus_n_docs(h))
+        self.n_bytes = int(N.lib().aha_corpus_n_bytes(h))
+        self.ptr = C.c_void_p(N.lib().aha_corpus_bytes(h))
+        self.doc_ptr = C.c_void_p(N.lib().aha_corpus_doc_offsets(h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                N.lib().aha_corpus_free(h)
+            except Exception:  # interpreter shutdown
+                pass
 
 
 class ACGroup:

@@ -9,8 +9,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -38,6 +41,7 @@ struct Scratch {
   bool ev_ready = false;
   Buf v2buf[24];
   Buf hostbuf[4];  // device staging of the host-buffer entry points (corpus, doc offsets, doc hit offsets, hits)
+  hipStream_t hs[3] = {};  // host-buffer entry: private non-blocking streams for upload, match, download
   unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
 };
 constexpr size_t kMaxScratch = 8;
@@ -162,6 +166,10 @@ void free_scratch(Scratch *sc, bool all) {
   if (sc->ev_ready)
     for (auto &e : sc->ev) (void)hipEventDestroy(e);
   sc->ev_ready = false;
+  for (auto &st : sc->hs) {
+    if (st) (void)hipStreamDestroy(st);
+    st = nullptr;
+  }
 }
 
 uint64_t scratch_bytes(const Scratch *sc) {
@@ -1272,6 +1280,40 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
   return AHA_OK;
 }
 
+// Host-buffer entry (what `Aha::AC#match(Bytes)`, src/aha/ac.cr:280-286, and a batch of them bind to).  The corpus is
+// cut into contiguous document ranges of about kHostRange bytes; three threads run them through a pipeline on three
+// private non-blocking streams of the leased scratch set -- upload of range k+1 beside the match of range k beside the
+// download of the hits of range k-1 -- so a large batch costs little more than its PCIe transfer, and no call touches
+// the NULL stream (concurrent callers on one handle really run side by side).  Documents are independent
+// (ac.cr:177), so the ranges are separate device batches whose hit lists concatenate.
+namespace {
+constexpr uint64_t kHostRange = 64ull << 20;
+
+struct HostPipe {
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t uploaded = 0, matched = 0;
+  bool failed = false;
+  int32_t rc = AHA_OK;
+  std::string err;
+  void fail(int32_t code, const std::string &what) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!failed) {
+      failed = true;
+      rc = code;
+      err = what;
+    }
+    cv.notify_all();
+  }
+};
+
+bool host_streams(Scratch *sc) {
+  for (auto &st : sc->hs)
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+  return true;
+}
+}  // namespace
+
 int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets,
                            uint64_t n_docs, const aha_match_params *params, aha_hit *out,
                            uint64_t cap, uint64_t *doc_hit_offsets, uint64_t *n_hits) {
@@ -1288,6 +1330,7 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
   const uint64_t n_bytes = doc_offsets[n_docs];
   if (n_bytes && !corpus) return AHA_E_INVALID;
   if (cap && !out) return AHA_E_INVALID;
+  *n_hits = 0;
   DeviceGuard g(ac->device);
   // device staging buffers are kept in the leased scratch set (grow-only): the reference's
   // usage is one #match per string, so per-call hipMalloc/hipFree would dominate
@@ -1305,36 +1348,265 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
     }
     return b.p;
   };
-  uint8_t *d_corpus = (uint8_t *)reserve(0, n_bytes + 64);
-  uint64_t *d_doc = (uint64_t *)reserve(1, (n_docs + 1) * sizeof(uint64_t));
-  uint64_t *d_dho = (uint64_t *)reserve(2, (n_docs + 1) * sizeof(uint64_t));
+  // ranges: document boundaries nearest to multiples of kHostRange (whole documents only)
+  std::vector<uint64_t> bounds;
+  try {
+    bounds.push_back(0);
+    const uint64_t parts = std::max<uint64_t>(1, std::min<uint64_t>((n_bytes + kHostRange - 1) / kHostRange, n_docs));
+    for (uint64_t r = 1; r < parts; r++) {
+      const uint64_t target = (uint64_t)(((__uint128_t)n_bytes * r) / parts);
+      uint64_t d = (uint64_t)(std::lower_bound(doc_offsets, doc_offsets + n_docs + 1, target) - doc_offsets);
+      if (d > 0 && (d > n_docs || target - doc_offsets[d - 1] < doc_offsets[d] - target)) d--;
+      d = std::min(std::max(d, bounds.back()), n_docs);
+      if (d > bounds.back()) bounds.push_back(d);
+    }
+    if (bounds.back() != n_docs || bounds.size() == 1) bounds.push_back(n_docs);
+  } catch (...) {
+    return AHA_E_NOMEM;
+  }
+  const size_t R = bounds.size() - 1;
+  // device layout: range k starts 256-byte aligned (the kernels read the corpus in aligned 16-byte pieces)
+  std::vector<uint64_t> dev_off(R + 1, 0), rel;
+  try {
+    for (size_t k = 0; k < R; k++)
+      dev_off[k + 1] = (dev_off[k] + (doc_offsets[bounds[k + 1]] - doc_offsets[bounds[k]]) + 255) & ~255ull;
+    rel.resize(n_docs + R + 1);  // range k's offsets, relative to its first byte, at rel[bounds[k] + k ..]
+    for (size_t k = 0; k < R; k++)
+      for (uint64_t d = bounds[k]; d <= bounds[k + 1]; d++) rel[d + k] = doc_offsets[d] - doc_offsets[bounds[k]];
+  } catch (...) {
+    return AHA_E_NOMEM;
+  }
+  uint8_t *d_corpus = (uint8_t *)reserve(0, dev_off[R] + 64);
+  uint64_t *d_doc = (uint64_t *)reserve(1, (n_docs + R + 1) * sizeof(uint64_t));
+  uint64_t *d_dho = (uint64_t *)reserve(2, (n_docs + R + 1) * sizeof(uint64_t));
   aha_hit *d_out = cap ? (aha_hit *)reserve(3, cap * sizeof(aha_hit)) : nullptr;
-  if (!d_corpus || !d_doc || !d_dho || (cap && !d_out)) {
-    tls_err = "hipMalloc failed for the staging buffers";
+  if (!d_corpus || !d_doc || !d_dho || (cap && !d_out) || !host_streams(sc)) {
+    tls_err = "hipMalloc / hipStreamCreate failed for the staging buffers";
     return AHA_E_HIP;
   }
-  int32_t rc = AHA_OK;
-#define HIPCHK2(call)                                                  \
-  do {                                                                 \
-    hipError_t e_ = (call);                                            \
-    if (e_ != hipSuccess) {                                            \
-      tls_err = std::string(#call) + ": " + hipGetErrorString(e_);     \
-      return AHA_E_HIP;                                                \
-    }                                                                  \
-  } while (0)
-  if (n_bytes) HIPCHK2(hipMemcpy(d_corpus, corpus, n_bytes, hipMemcpyHostToDevice));
-  HIPCHK2(hipMemcpy(d_doc, doc_offsets, (n_docs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-  rc = match_batch_device_impl(ac, sc, d_corpus, d_doc, n_docs, n_bytes, params, d_out, cap, d_dho, n_hits, nullptr,
-                               true);  // checked on the host above
-  if (rc == AHA_OK || rc == AHA_E_CAPACITY) {
-    uint64_t n = std::min<uint64_t>(*n_hits, cap);
-    if (n) HIPCHK2(hipMemcpy(out, d_out, n * sizeof(aha_hit), hipMemcpyDeviceToHost));
-    if (doc_hit_offsets)
-      HIPCHK2(hipMemcpy(doc_hit_offsets, d_dho, (n_docs + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  hipStream_t s_up = sc->hs[0], s_match = sc->hs[1], s_down = sc->hs[2];
+  if (hipMemcpyAsync(d_doc, rel.data(), (n_docs + R + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s_up) != hipSuccess ||
+      hipStreamSynchronize(s_up) != hipSuccess) {
+    tls_err = "upload of the document offsets failed";
+    return AHA_E_HIP;
   }
-#undef HIPCHK2
-  return rc;
+
+  HostPipe P;
+  std::vector<uint64_t> base(R + 1, 0), got(R, 0);  // hits before range k; hits of range k that are in d_out
+  const int device = ac->device;
+  auto uploader = [&]() {
+    if (hipSetDevice(device) != hipSuccess) return P.fail(AHA_E_HIP, "hipSetDevice failed");
+    for (size_t k = 0; k < R; k++) {
+      const uint64_t b0 = doc_offsets[bounds[k]], nb = doc_offsets[bounds[k + 1]] - b0;
+      if (nb && (hipMemcpyAsync(d_corpus + dev_off[k], corpus + b0, nb, hipMemcpyHostToDevice, s_up) != hipSuccess ||
+                 hipStreamSynchronize(s_up) != hipSuccess))
+        return P.fail(AHA_E_HIP, "upload of the corpus failed");
+      std::lock_guard<std::mutex> lk(P.mu);
+      if (P.failed) return;
+      P.uploaded = k + 1;
+      P.cv.notify_all();
+    }
+  };
+  auto downloader = [&]() {
+    if (hipSetDevice(device) != hipSuccess) return P.fail(AHA_E_HIP, "hipSetDevice failed");
+    std::vector<uint64_t> tmp;
+    for (size_t k = 0; k < R; k++) {
+      {
+        std::unique_lock<std::mutex> lk(P.mu);
+        P.cv.wait(lk, [&] { return P.failed || P.matched > k; });
+        if (P.failed) return;
+      }
+      const uint64_t D = bounds[k + 1] - bounds[k];
+      if (got[k] && hipMemcpyAsync(out + base[k], d_out + base[k], got[k] * sizeof(aha_hit), hipMemcpyDeviceToHost,
+                                   s_down) != hipSuccess)
+        return P.fail(AHA_E_HIP, "download of the hits failed");
+      if (doc_hit_offsets) {
+        try {
+          tmp.resize(D + 1);
+        } catch (...) {
+          return P.fail(AHA_E_NOMEM, "out of host memory");
+        }
+        if (hipMemcpyAsync(tmp.data(), d_dho + bounds[k] + k, (D + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           s_down) != hipSuccess)
+          return P.fail(AHA_E_HIP, "download of the document offsets failed");
+      }
+      if (hipStreamSynchronize(s_down) != hipSuccess) return P.fail(AHA_E_HIP, "download failed");
+      if (doc_hit_offsets)
+        for (uint64_t d = 0; d <= D; d++) doc_hit_offsets[bounds[k] + d] = base[k] + tmp[d];  // [.. + D] rewritten by k+1
+    }
+  };
+  std::thread t_up, t_down;
+  if (R == 1) {
+    uploader();  // one range (a single #match, a small batch): nothing to overlap, no threads
+  } else {
+    try {
+      t_up = std::thread(uploader);
+      t_down = std::thread(downloader);
+    } catch (...) {
+      P.fail(AHA_E_NOMEM, "thread creation failed");
+    }
+  }
+  // the matches, in order, on this thread (the error text of a match is this thread's)
+  uint64_t total = 0;
+  bool overflow = false;
+  for (size_t k = 0; k < R; k++) {
+    {
+      std::unique_lock<std::mutex> lk(P.mu);
+      P.cv.wait(lk, [&] { return P.failed || P.uploaded > k; });
+      if (P.failed) break;
+    }
+    const uint64_t D = bounds[k + 1] - bounds[k], nb = doc_offsets[bounds[k + 1]] - doc_offsets[bounds[k]];
+    const uint64_t room = (!overflow && cap > total) ? cap - total : 0;
+    uint64_t nh = 0;
+    int32_t rc = match_batch_device_impl(ac, sc, d_corpus + dev_off[k], d_doc + bounds[k] + k, D, nb, params,
+                                         room ? d_out + total : nullptr, room, d_dho + bounds[k] + k, &nh, s_match,
+                                         true);  // the offsets were checked on the host above
+    if (rc != AHA_OK && rc != AHA_E_CAPACITY) {
+      P.fail(rc, tls_err);
+      break;
+    }
+    base[k] = total;
+    got[k] = std::min(nh, room);
+    total += nh;
+    if (rc == AHA_E_CAPACITY) overflow = true;  // later ranges are only counted (their offsets stay valid)
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.matched = k + 1;
+    P.cv.notify_all();
+  }
+  base[R] = total;
+  if (R == 1) downloader();
+  if (t_up.joinable()) t_up.join();
+  if (t_down.joinable()) t_down.join();
+  if (P.failed) {
+    tls_err = P.err;
+    return P.rc;
+  }
+  *n_hits = total;
+  if (total > cap) {
+    tls_err = "output buffer too small";
+    return AHA_E_CAPACITY;
+  }
+  return AHA_OK;
 }
+
+// ---- device buffers behind the C ABI (include/aha_hip.h) ---------------------------------------------------------
+namespace {
+std::mutex g_copy_mu;
+std::vector<hipStream_t> g_copy_streams;  // one private non-blocking stream per device, created on first use
+
+int32_t copy_stream(int device, hipStream_t *out) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    tls_err = aha_strerror(AHA_E_NO_DEVICE);
+    return AHA_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    tls_err = "no such device";
+    return AHA_E_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(g_copy_mu);
+  if (g_copy_streams.size() < (size_t)n) g_copy_streams.resize((size_t)n, nullptr);
+  if (!g_copy_streams[device] && hipStreamCreateWithFlags(&g_copy_streams[device], hipStreamNonBlocking) != hipSuccess) {
+    tls_err = "hipStreamCreate failed";
+    return AHA_E_HIP;
+  }
+  *out = g_copy_streams[device];
+  return AHA_OK;
+}
+
+int32_t buffer_copy(int device, void *dst, const void *src, uint64_t bytes, hipMemcpyKind kind) {
+  if (bytes && (!dst || !src)) return AHA_E_INVALID;
+  DeviceGuard g(device);
+  hipStream_t st = nullptr;
+  int32_t rc = copy_stream(device, &st);
+  if (rc != AHA_OK || !bytes) return rc;
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    tls_err = std::string("copy: ") + hipGetErrorString(e);
+    return AHA_E_HIP;
+  }
+  return AHA_OK;
+}
+}  // namespace
+
+struct aha_corpus {
+  int device = -1;
+  void *bytes = nullptr;
+  void *doc = nullptr;
+  uint64_t n_docs = 0, n_bytes = 0;
+};
+
+int32_t aha_buffer_alloc(int32_t device, uint64_t bytes, void **d_ptr) {
+  if (!d_ptr) return AHA_E_INVALID;
+  *d_ptr = nullptr;
+  hipStream_t st = nullptr;
+  int32_t rc = copy_stream(device, &st);  // validates the device
+  if (rc != AHA_OK) return rc;
+  DeviceGuard g(device);
+  hipError_t e = hipMalloc(d_ptr, std::max<uint64_t>(bytes, 16));
+  if (e != hipSuccess) {
+    tls_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+    *d_ptr = nullptr;
+    return AHA_E_HIP;
+  }
+  return AHA_OK;
+}
+
+int32_t aha_buffer_free(int32_t device, void *d_ptr) {
+  if (!d_ptr) return AHA_OK;
+  DeviceGuard g(device);
+  return hipFree(d_ptr) == hipSuccess ? AHA_OK : AHA_E_HIP;
+}
+
+int32_t aha_buffer_upload(int32_t device, void *d_dst, const void *src, uint64_t bytes) {
+  return buffer_copy(device, d_dst, src, bytes, hipMemcpyHostToDevice);
+}
+
+int32_t aha_buffer_download(int32_t device, void *dst, const void *d_src, uint64_t bytes) {
+  return buffer_copy(device, dst, d_src, bytes, hipMemcpyDeviceToHost);
+}
+
+int32_t aha_corpus_upload(int32_t device, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                          aha_corpus **out) {
+  if (!out || !doc_offsets) return AHA_E_INVALID;
+  *out = nullptr;
+  if (doc_offsets[0] != 0) return AHA_E_INVALID;
+  for (uint64_t d = 0; d < n_docs; d++) {
+    if (doc_offsets[d + 1] < doc_offsets[d]) return AHA_E_INVALID;
+    if (doc_offsets[d + 1] - doc_offsets[d] >= 0x7FFFFFFFull) return AHA_E_TOO_LONG;
+  }
+  const uint64_t n_bytes = doc_offsets[n_docs];
+  if (n_bytes && !corpus) return AHA_E_INVALID;
+  aha_corpus *c = new (std::nothrow) aha_corpus();
+  if (!c) return AHA_E_NOMEM;
+  c->device = device;
+  c->n_docs = n_docs;
+  c->n_bytes = n_bytes;
+  int32_t rc = aha_buffer_alloc(device, n_bytes + 64, &c->bytes);
+  if (rc == AHA_OK) rc = aha_buffer_alloc(device, (n_docs + 1) * sizeof(uint64_t), &c->doc);
+  if (rc == AHA_OK) rc = aha_buffer_upload(device, c->bytes, corpus, n_bytes);
+  if (rc == AHA_OK) rc = aha_buffer_upload(device, c->doc, doc_offsets, (n_docs + 1) * sizeof(uint64_t));
+  if (rc != AHA_OK) {
+    aha_corpus_free(c);
+    return rc;
+  }
+  *out = c;
+  return AHA_OK;
+}
+
+void aha_corpus_free(aha_corpus *c) {
+  if (!c) return;
+  (void)aha_buffer_free(c->device, c->bytes);
+  (void)aha_buffer_free(c->device, c->doc);
+  delete c;
+}
+
+const uint8_t *aha_corpus_bytes(const aha_corpus *c) { return c ? (const uint8_t *)c->bytes : nullptr; }
+const uint64_t *aha_corpus_doc_offsets(const aha_corpus *c) { return c ? (const uint64_t *)c->doc : nullptr; }
+uint64_t aha_corpus_n_docs(const aha_corpus *c) { return c ? c->n_docs : 0; }
+uint64_t aha_corpus_n_bytes(const aha_corpus *c) { return c ? c->n_bytes : 0; }
+int32_t aha_corpus_device(const aha_corpus *c) { return c ? c->device : -1; }
 
 int32_t aha_ac_match_bytes(aha_ac *ac, const uint8_t *text, uint64_t n,
                            const aha_match_params *params, aha_hit *out, uint64_t cap,

@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--keys", type=int, default=None, help="override number of keys")
     ap.add_argument("--chars", action="store_true", help="String overload (char offsets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-entry / download legs after the timed run")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU baseline leg (five passes)")
     ap.add_argument("--parity-bytes", type=int, default=32 << 20,
                     help="bytes of the first documents compared with the oracle on every run (the parity gate)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "words", "packed", "triples"],
@@ -101,8 +102,9 @@ def parity_sample(blob, offs, corpus, doc, gpu_hits, gpu_dho, chars, max_bytes, 
 
 
 def cpu_baseline(blob, offs, corpus, doc, gpu_hits, gpu_dho, seconds, log):
-    """Times the oracle (C restatement of ac.cr:176-192,265-286 over reference-layout
-    arrays) on a prefix of the documents; also checks the GPU hits on that prefix."""
+    """Times the oracle (C restatement of ac.cr:176-192,265-286 over reference-layout arrays) on a bounded sample of
+    the same workload: the first documents up to 256 MiB (less when `seconds` would not cover five passes), FIVE passes,
+    the median (SURVEY.md section 8 d); the first pass also checks the GPU hits on that sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as orc  # checker / reported baseline only
 
@@ -110,23 +112,27 @@ def cpu_baseline(blob, offs, corpus, doc, gpu_hits, gpu_dho, seconds, log):
     o = orc.AC.compile_packed(blob, offs)
     t_compile = time.time() - t0
     D = doc.size - 1
-    done_docs, done_bytes, t_match, n_hits = 0, 0, 0.0, 0
-    exact = True
-    step = max(1, D // 64)
-    while done_docs < D and t_match < seconds:
-        d1 = min(D, done_docs + step)
-        sub = doc[done_docs:d1 + 1] - doc[done_docs]
-        seg = corpus[int(doc[done_docs]):int(doc[d1])]
+    # calibration: one document tells the rate; size the sample so that five passes fit `seconds`
+    d_cal = 1
+    t0 = time.time()
+    o.match_batch(corpus[:int(doc[d_cal])], doc[:d_cal + 1] - doc[0], cap=max(1024, int(doc[d_cal]) // 4))
+    rate = max(int(doc[d_cal]), 1) / max(time.time() - t0, 1e-6)
+    want = int(min(256 << 20, rate * seconds / 5))
+    done_docs = max(1, min(D, int(np.searchsorted(doc, want, side="right")) - 1))
+    done_bytes = int(doc[done_docs])
+    sub = doc[:done_docs + 1] - doc[0]
+    seg = corpus[:done_bytes]
+    exact, times, n_hits = True, [], 0
+    for p in range(5):
         t0 = time.time()
         oh, od = o.match_batch(seg, sub, cap=max(1024, seg.size // 4))
-        t_match += time.time() - t0
-        if gpu_hits is not None:
-            a, b = int(gpu_dho[done_docs]), int(gpu_dho[d1])
-            exact = exact and (b - a == len(oh)) and gpu_hits[a:b].tobytes() == oh.tobytes()
-            exact = exact and np.array_equal(gpu_dho[done_docs:d1 + 1] - gpu_dho[done_docs], od)
-        n_hits += len(oh)
-        done_bytes += seg.size
-        done_docs = d1
+        times.append(time.time() - t0)
+        n_hits = len(oh)
+        if p == 0 and gpu_hits is not None:
+            b = int(gpu_dho[done_docs])
+            exact = (b == len(oh)) and gpu_hits[:b].tobytes() == oh.tobytes() and \
+                np.array_equal(gpu_dho[:done_docs + 1], od)
+    t_match = float(np.median(times))
     log(f"cpu baseline: {done_bytes / 1e6:.1f} MB in {t_match:.2f}s, {n_hits} hits, compile {t_compile:.2f}s")
     # informational: the same loop on every host core, documents statically sharded;
     # ctypes releases the GIL, so plain threads run the C oracle in parallel
@@ -159,8 +165,9 @@ def cpu_baseline(blob, offs, corpus, doc, gpu_hits, gpu_dho, seconds, log):
         "unit": "GB/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {done_docs} of {D} documents ({done_bytes} bytes) of the same corpus, 1 thread, "
-                  f"C restatement of the reference CPU path (oracle/aha_oracle.c), Bytes overload",
+        "sample": f"first {done_docs} of {D} documents ({done_bytes} bytes) of the same corpus, 1 thread, median of 5 "
+                  f"passes, C restatement of the reference CPU path (oracle/aha_oracle.c), Bytes overload",
+        "passes_s": [round(t, 3) for t in times],
         "m_hits_per_s": round(n_hits / t_match / 1e6, 3),
         "parity_on_sample": "bit-exact" if exact else "MISMATCH",
         "all_cores": mt,
@@ -420,6 +427,43 @@ def main():
         "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
     }
 
+    # ---- end to end, outside the timed region (SURVEY.md section 8 d: "incl. PCIe upload and incl. D2H of hits as
+    # separate lines"): what the drop-in caller of the host-buffer entry point sees, next to the PCIe rate it is bound by
+    end_to_end = None
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        from aha_amd import DeviceBuffer
+
+        def best_of(fn, k=3):
+            ts = []
+            for _ in range(k):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            return min(ts)
+
+        probe = DeviceBuffer(local_rank, n_bytes)
+        probe.upload(corpus)  # warm: first touch of the pageable pages, stream creation
+        t_h2d = best_of(lambda: probe.upload(corpus))
+        del probe
+        host_out = np.zeros(n_hits + 1024, dtype=np.dtype([("start", "<i4"), ("end", "<i4"), ("value", "<i4")]))
+        ac.match_batch(corpus, doc, chars=args.chars, cap=n_hits + 1024)  # warm: staging buffers of the handle
+        t_host = best_of(lambda: ac.match_batch(corpus, doc, chars=args.chars, cap=n_hits + 1024))
+
+        def dev_plus_download():
+            n = ac.match_batch_device(d_corpus, d_doc, d_out, d_dho, chars=args.chars)
+            N.lib().aha_buffer_download(local_rank, host_out.ctypes.data, d_out.data_ptr(), 12 * n)
+
+        dev_plus_download()
+        t_dl = best_of(dev_plus_download)
+        end_to_end = {"host_entry_gbs": round(n_bytes / t_host / 1e9, 2), "host_entry_ms": round(t_host * 1e3, 2),
+                      "with_download_gbs": round(n_bytes / t_dl / 1e9, 2), "with_download_ms": round(t_dl * 1e3, 2),
+                      "pcie_h2d_gbs": round(n_bytes / t_h2d / 1e9, 2),
+                      "host_entry_vs_pcie": round(t_h2d / t_host, 3),
+                      "note": "host_entry = aha_ac_match_batch on pageable host buffers (upload, match and download "
+                              "pipelined over document ranges); with_download = device-resident match + D2H of the "
+                              "hits; pcie_h2d = one blocking upload of the same corpus; best of 3; never `value`"}
+        log(f"end to end: {end_to_end}")
+
     # ---- parity gate: no throughput figure without a bit-exact comparison on this run's hits.
     # Rank 0 checks its own shard once, outside the timed region, on every run (N > 1 and profiler runs included).
     cpu = None
@@ -462,6 +506,8 @@ def main():
             if strong["identical_to_one_gpu"] is False:
                 parity = "MISMATCH"
                 line["parity"], line["value"], line["m_hits_per_s"] = parity, None, None
+        if end_to_end is not None:
+            line["end_to_end"] = end_to_end
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line, ensure_ascii=False), flush=True)

@@ -51,6 +51,27 @@ class BitArray {
   std::vector<uint8_t> bits_;
 };
 
+// A batch resident in HBM (aha_corpus_upload): uploaded once, matched as often as wanted -- by AC::match_corpus.
+class Corpus {
+ public:
+  Corpus(std::string_view bytes, const std::vector<uint64_t> &doc_offsets, int device = 0) {
+    if (doc_offsets.empty()) throw Error(AHA_E_INVALID, "doc_offsets holds D + 1 entries");
+    int32_t rc = aha_corpus_upload(device, reinterpret_cast<const uint8_t *>(bytes.data()), doc_offsets.data(),
+                                   doc_offsets.size() - 1, &c_);
+    if (rc != AHA_OK) {
+      const char *m = aha_last_error(nullptr);
+      throw Error(rc, (m && *m) ? m : aha_strerror(rc));
+    }
+  }
+  Corpus(const Corpus &) = delete;
+  Corpus &operator=(const Corpus &) = delete;
+  ~Corpus() { aha_corpus_free(c_); }
+  const aha_corpus *handle() const { return c_; }
+
+ private:
+  aha_corpus *c_ = nullptr;
+};
+
 class AC {
  public:
   AC(const AC &) = delete;
@@ -128,6 +149,46 @@ class AC {
       break;
     }
     out.resize(n);
+    if (doc_hit_offsets) *doc_hit_offsets = std::move(dho);
+    return out;
+  }
+
+  // The same on a batch that already lives in HBM: the device entry point on the library's own buffers (no copy of
+  // the corpus per call; the hits are downloaded at the end).
+  std::vector<Hit> match_corpus(const Corpus &c, std::vector<uint64_t> *doc_hit_offsets = nullptr,
+                                bool chars = false) const {
+    const aha_corpus *h = c.handle();
+    const int dev = aha_corpus_device(h);
+    const uint64_t D = aha_corpus_n_docs(h);
+    aha_match_params p{};
+    p.struct_size = sizeof(p);
+    p.char_offsets = chars ? 1 : 0;
+    void *d_dho = nullptr, *d_out = nullptr;
+    uint64_t cap = aha_corpus_n_bytes(h) / 8 + 64, n = 0;
+    auto fail = [&](int32_t rc, const char *m) {
+      aha_buffer_free(dev, d_dho);
+      aha_buffer_free(dev, d_out);
+      throw Error(rc, (m && *m) ? m : aha_strerror(rc));
+    };
+    int32_t rc = aha_buffer_alloc(dev, (D + 1) * sizeof(uint64_t), &d_dho);
+    if (rc != AHA_OK) fail(rc, aha_last_error(nullptr));
+    for (;;) {
+      if ((rc = aha_buffer_alloc(dev, cap * sizeof(Hit), &d_out)) != AHA_OK) fail(rc, aha_last_error(nullptr));
+      rc = aha_ac_match_batch_device(h_, aha_corpus_bytes(h), aha_corpus_doc_offsets(h), D, aha_corpus_n_bytes(h), &p,
+                                     static_cast<Hit *>(d_out), cap, static_cast<uint64_t *>(d_dho), &n, nullptr);
+      if (rc != AHA_E_CAPACITY) break;
+      aha_buffer_free(dev, d_out);
+      d_out = nullptr;
+      cap = n;
+    }
+    if (rc != AHA_OK) fail(rc, aha_last_error(h_));
+    std::vector<Hit> out(n);
+    std::vector<uint64_t> dho(D + 1);
+    if ((rc = aha_buffer_download(dev, out.data(), d_out, n * sizeof(Hit))) != AHA_OK ||
+        (rc = aha_buffer_download(dev, dho.data(), d_dho, (D + 1) * sizeof(uint64_t))) != AHA_OK)
+      fail(rc, aha_last_error(nullptr));
+    aha_buffer_free(dev, d_dho);
+    aha_buffer_free(dev, d_out);
     if (doc_hit_offsets) *doc_hit_offsets = std::move(dho);
     return out;
   }

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AHA_ABI_VERSION 3
+#define AHA_ABI_VERSION 4
 
 /* Aha::Hit -- src/aha/matcher.cr:2-11.  Half-open [start,end) offsets
  * relative to the start of the sequence (document); value = key index in
@@ -269,6 +269,27 @@ int64_t aha_ac_scratch_bytes(aha_ac *ac);
  * engine (1), which is an order of magnitude slower than the single-traversal engine (2). */
 int32_t aha_ac_set_profiling(aha_ac *ac, int32_t enabled);
 int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t);
+
+/* ---- device memory for callers without a GPU framework (SURVEY.md section 8 b: aha_corpus_upload / _free) ----------
+ * aha_ac_match_batch_device takes HBM pointers; these give a C, C++ or Crystal caller a way to obtain them, so that a
+ * corpus is uploaded once and matched many times (or by several automata) and the hits stay on the device until they
+ * are wanted.  Copies run on a private stream of the library and block the calling thread only.  Buffers are 256-byte
+ * aligned.  Errors: AHA_E_HIP / AHA_E_INVALID / AHA_E_NO_DEVICE, text through aha_last_error(NULL). */
+int32_t aha_buffer_alloc(int32_t device, uint64_t bytes, void **d_ptr);
+int32_t aha_buffer_free(int32_t device, void *d_ptr);
+int32_t aha_buffer_upload(int32_t device, void *d_dst, const void *src, uint64_t bytes);
+int32_t aha_buffer_download(int32_t device, void *dst, const void *d_src, uint64_t bytes);
+/* A batch resident in HBM: the bytes of all documents and their D + 1 offsets (validated like aha_ac_match_batch
+ * validates them: ascending from 0, every document below 2^31 bytes). */
+typedef struct aha_corpus aha_corpus;
+int32_t aha_corpus_upload(int32_t device, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                          aha_corpus **out);
+void aha_corpus_free(aha_corpus *c);
+const uint8_t *aha_corpus_bytes(const aha_corpus *c);         /* device pointer */
+const uint64_t *aha_corpus_doc_offsets(const aha_corpus *c);  /* device pointer, n_docs + 1 entries */
+uint64_t aha_corpus_n_docs(const aha_corpus *c);
+uint64_t aha_corpus_n_bytes(const aha_corpus *c);
+int32_t aha_corpus_device(const aha_corpus *c);
 
 /* ---- several GPUs of one node behind one handle (SURVEY.md section 8 b / e) -------------------------------------
  * The batch is cut into contiguous, byte-balanced document ranges, one per entry of `devices` (documents are

@@ -72,6 +72,34 @@ int main() {
       std::printf("FAIL match_batch offsets\n");
     }
   }
+  {  // the same batch resident in HBM: uploaded once through the C ABI (aha_corpus_upload), matched by the device
+     // entry point on raw device pointers, hits downloaded with aha_buffer_download -- no GPU framework involved
+    auto matcher = aha::AC::compile({"ab", "b"});
+    aha::Corpus resident("abab", {0, 1, 1, 4});
+    for (int pass = 0; pass < 2; pass++) {  // matched twice: the upload is not repeated
+      std::vector<uint64_t> dho;
+      auto hits = matcher.match_corpus(resident, &dho);
+      std::vector<Pair> got;
+      for (auto &h : hits) got.push_back({h.end, h.value});
+      expect("match_corpus (device resident)", got, {{1, 1}, {3, 0}, {3, 1}});
+      if (dho != std::vector<uint64_t>{0, 0, 0, 3}) {
+        fails++;
+        std::printf("FAIL match_corpus offsets\n");
+      }
+    }
+    auto other = aha::AC::compile({"a"});  // another automaton over the same resident batch
+    auto hits = other.match_corpus(resident);
+    std::vector<Pair> got;
+    for (auto &h : hits) got.push_back({h.end, h.value});
+    expect("match_corpus, second automaton", got, {{1, 0}, {2, 0}});
+    try {
+      aha::Corpus bad("abab", {0, 3, 2, 4});
+      fails++;
+      std::printf("FAIL corpus offsets: no exception\n");
+    } catch (const aha::Error &e) {
+      std::printf("ok   corpus offsets rejected\n");
+    }
+  }
   {  // error behaviour: raise "key:... appear twice."  ac.cr:66
     try {
       aha::AC::compile({"ab", "cd", "ab"});

@@ -525,6 +525,46 @@ def test_device_resident_entry_point():
     assert e.value.code == N.AHA_E_CAPACITY and e.value.required == len(oh)
 
 
+def test_host_entry_pipeline_and_buffer_api(engine):
+    """The two ways a caller without a GPU framework reaches the device path.  (1) aha_ac_match_batch on host buffers:
+    a 160 MiB batch is cut into three document ranges that run through the upload / match / download pipeline on
+    private streams -- same hits and offsets as ONE device call on the whole batch, also when the capacity is too
+    small first (count and offsets must still be exact) and with char offsets.  (2) aha_corpus_upload +
+    aha_buffer_alloc / _download: the batch uploaded once through the C ABI, matched with the device entry point on
+    raw pointers (no torch), hits downloaded.  The oracle checks the first documents."""
+    if engine != "v2":
+        pytest.skip("once, on the default engine")
+    import torch
+
+    from aha_amd import DeviceCorpus
+
+    blob, offs, nf = synth.keys(3, K=20_000)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=160 << 20, doc_bytes=1 << 20)
+    g = AC.compile_packed(blob, offs)
+    o = orc.AC.compile_packed(blob, offs)
+    dc = torch.from_numpy(corpus).cuda()
+    dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+    dev_corpus = DeviceCorpus(corpus, doc, device=0)
+    assert dev_corpus.n_docs == doc.size - 1 and dev_corpus.n_bytes == corpus.size
+    for chars in (False, True):
+        out = torch.zeros((corpus.size // 8, 3), dtype=torch.int32, device="cuda")
+        dho = torch.zeros(doc.size, dtype=torch.int64, device="cuda")
+        n = g.match_batch_device(dc, dd, out, dho, chars=chars)
+        want = out[:n].cpu().numpy().tobytes()
+        want_off = dho.cpu().numpy().astype(np.uint64)
+        d8 = 8  # the oracle on the first documents
+        oh, od = o.match_batch(corpus[:int(doc[d8])], doc[:d8 + 1], chars=chars)
+        assert want[:oh.nbytes] == oh.tobytes() and np.array_equal(want_off[:d8 + 1], od)
+        gh, gd = g.match_batch(corpus, doc, chars=chars)          # host entry, generous capacity
+        assert gh.tobytes() == want and np.array_equal(gd, want_off)
+        gh, gd = g.match_batch(corpus, doc, chars=chars, cap=1000)  # too small first: AHA_E_CAPACITY, then again
+        assert gh.tobytes() == want and np.array_equal(gd, want_off)
+        ch, cd = g.match_corpus(dev_corpus, chars=chars)           # resident corpus, raw pointers, no torch
+        assert ch.tobytes() == want and np.array_equal(cd, want_off)
+    with pytest.raises(AhaError):
+        DeviceCorpus(corpus[:100], np.array([0, 50, 40, 100], dtype=np.uint64))  # offsets must ascend
+
+
 # ---- the headline configuration at FULL size ----------------------------------
 @pytest.mark.parametrize("cfg", [3])
 def test_full_size_properties(cfg, engine):

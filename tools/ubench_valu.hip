@@ -59,9 +59,9 @@ __global__ __launch_bounds__(1024) void valu(unsigned long long *cyc, uint32_t *
   for (int r = 0; r < REPS; r++) {
 #define BODY4(dep, ind)                                                                        \
   if (DEP)                                                                                     \
-    asm volatile(R4(dep) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(k) : "vcc", "s20", "s21"); \
+    asm volatile(R4(dep) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(k) : "vcc", "scc", "s20", "s21"); \
   else                                                                                         \
-    asm volatile(R4(ind) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(k) : "vcc", "s20", "s21");
+    asm volatile(R4(ind) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(k) : "vcc", "scc", "s20", "s21");
     if (KIND == K_XOR) { BODY4(OPS_DEP("v_xor_b32"), OPS_IND("v_xor_b32")) }
     if (KIND == K_AND) { BODY4(OPS_DEP("v_and_b32"), OPS_IND("v_and_b32")) }
     if (KIND == K_ADD) { BODY4(OPS_DEP("v_add_u32"), OPS_IND("v_add_u32")) }

@@ -29,9 +29,7 @@ AHA_E_NOMEM = -12
 AHA_OPT_HOST_ONLY = 1
 AHA_OPT_FORCE_WIDE = 2
 AHA_IMG_SLOTS, AHA_IMG_END_KEY, AHA_IMG_KEY_LN, AHA_IMG_KEY_CNT, AHA_IMG_KEY_KC = 0, 1, 2, 3, 4
-AHA_IMG_PP_T2, AHA_IMG_PP_BLOOM = 7, 8
-AHA_IMG_UNIT_SLOTS, AHA_IMG_UNIT_ROOT, AHA_IMG_UNIT_END_INFO = 9, 10, 11
-AHA_IMG_STALE_ENDS = 12
+AHA_IMG_STALE_ENDS = 5
 
 
 class aha_options(C.Structure):
@@ -48,11 +46,8 @@ class aha_ac_info_t(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_keys", C.c_uint32), ("n_states", C.c_uint64),
                 ("n_slots", C.c_uint64), ("image_bytes", C.c_uint64), ("max_key_len", C.c_uint32),
                 ("slot_bytes", C.c_uint32), ("lds_slots", C.c_uint32), ("device", C.c_int32),
-                ("unit_enabled", C.c_uint32), ("unit_slots", C.c_uint32), ("unit_lo3", C.c_uint32), ("unit_n3", C.c_uint32),
-                ("unit_multi_permille", C.c_uint32), ("reserved", C.c_uint32), ("fail_s1_lo", C.c_uint32),
-                ("fail_s2_lo", C.c_uint32), ("fail_hdr_lo", C.c_uint32), ("reserved2", C.c_uint32),
-                ("pp_enabled", C.c_uint32), ("pp_bloom_words", C.c_uint32), ("pp_entries", C.c_uint64),
-                ("pp_fill_permille", C.c_uint32), ("reserved3", C.c_uint32)]
+                ("fail_s1_lo", C.c_uint32), ("fail_s2_lo", C.c_uint32), ("fail_hdr_lo", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class aha_timing(C.Structure):

@@ -7,7 +7,6 @@
 #include <numeric>
 
 #include "../../include/aha_hip.h"
-#include "pp.hpp"
 
 namespace aha {
 
@@ -475,80 +474,6 @@ bool encode_image(const Automaton &a, const Placement &p, bool force_wide, Image
     }
   }
   return true;
-}
-
-}  // namespace aha
-
-// ---------------------------------------------------------------- pp tables
-namespace aha {
-
-void build_pp(const Automaton &a, bool compact, uint32_t words, PpTables &t) {
-  t = PpTables();
-  if (words == 0) words = kPpBloomWords;
-  if (!compact) {
-    t.why = "wide slot format";
-    return;
-  }
-  if (a.n_keys == 0) {
-    t.why = "no keys";
-    return;
-  }
-  if (a.max_key_len > kPpMaxKeyLen) {
-    t.why = "longest key exceeds the halo";
-    return;
-  }
-  if (words < 64 || words >= 65536) {
-    t.why = "bad Bloom size";
-    return;
-  }
-  t.t2.assign(kPpT2Words, 0u);
-  t.bloom.assign(words, 0u);
-  // the bytes of a state's path, from its parent chain (depth <= kPpGuard here)
-  auto window = [&](uint32_t s, uint32_t &lo, uint32_t &b4) {
-    uint8_t w[8] = {0};
-    for (uint32_t d = a.depth[s], x = s; d > 0; d--, x = a.parent[x]) w[d - 1] = a.in_label[x];
-    lo = (uint32_t)w[0] | ((uint32_t)w[1] << 8) | ((uint32_t)w[2] << 16) | ((uint32_t)w[3] << 24);
-    b4 = w[4];
-  };
-  auto add = [&](uint32_t h, uint32_t m1) {
-    t.bloom[pp_word(h, words)] |= pp_mask(m1);
-    t.n_entries++;
-  };
-  for (uint32_t s = 1; s < a.n_states; s++) {  // BFS order: ascending depth
-    const uint32_t d = a.depth[s];
-    if (d > kPpGuard) break;
-    const bool end = a.key_of[s] >= 0;
-    if (d == 1) {
-      if (end) {  // a 1-byte key would need an END1 class in T2
-        t = PpTables();
-        t.why = "1-byte key";
-        return;
-      }
-      continue;
-    }
-    uint32_t lo, b4;
-    window(s, lo, b4);
-    if (d == 2) {
-      const uint32_t code = (a.n_child[s] ? 1u : 0u) | (end ? 2u : 0u);
-      t.t2[pp_t2_word(lo & 0xFFu, (lo >> 8) & 0xFFu)] |= code << pp_t2_shift((lo >> 8) & 0xFFu);
-      continue;
-    }
-    const PpHash h = pp_hash(lo, b4);
-    if (d == 3 && end) add(h.h3, h.m1);
-    if (d == 4 && end) add(h.h4, h.m1);
-    if (d == 5) add(h.h5, h.m1);
-  }
-  uint64_t bits = 0;
-  for (uint32_t w : t.bloom) bits += (uint64_t)__builtin_popcount(w);
-  t.fill = (double)bits / (32.0 * words);
-  // one bit per byte of the word: a probe is a false positive with probability ~ (byte fill)^4; beyond a
-  // fill of 1/2 more than 6 % of the probes would go to the exact pass
-  if (t.fill > 0.5) {
-    t = PpTables();
-    t.why = "Bloom filter too full";
-    return;
-  }
-  t.ok = true;
 }
 
 }  // namespace aha

@@ -20,8 +20,6 @@
 #include "automaton.hpp"
 #include "cedar_replay.hpp"
 #include "image.hpp"
-#include "pp.hpp"
-#include "unit.hpp"
 
 using namespace aha;
 
@@ -74,17 +72,6 @@ struct aha_ac {
   uint32_t v2_grid = 0;
   uint32_t v2_bpc = 1;
   uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
-  // character-level image (unit.hpp, scan_unit.hip)
-  UnitImage unit;
-  bool unit_ok = false;  // uploaded and usable on the device
-  UnitDev udev{};
-  const uint32_t *d_unit_end_info = nullptr;
-  // position-parallel engine (scan_pp.hip)
-  PpTables pp;
-  bool pp_ok = false;
-  const uint32_t *d_pp_t2 = nullptr, *d_pp_bloom = nullptr;
-  uint32_t pp_grid = 0;
-  uint32_t pp_lds_slots = 0;
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
   // match_longest only (cedar_replay.cpp): the states that carry one of Cedar's stale END flags, derived on the first
   // match_longest call (it replays every insert: as long again as the rest of compile); dev_longest = dev + the bitmap
@@ -333,33 +320,6 @@ void v2_setup(aha_ac *ac) {
   if (reserve < 0 || reserve >= cus) reserve = 0;
   ac->v2_grid = (uint32_t)(cus - reserve) * ac->v2_bpc;
   ac->v2_ok = true;
-  // character-level engine (unit.hpp): one step per UTF-8-shaped unit (AHA_ENGINE=unit built the image)
-  if (ac->unit.ok) {
-    uint32_t n3_max = 0;
-    while (n3_max < 16 && unit_lds_bytes(n3_max + 1) <= kLdsPerCU) n3_max++;
-    uint32_t n3 = std::min(ac->unit.n3, n3_max);
-    const uint64_t *us = nullptr;
-    if (unit_prepare(n3) == 0 && upload(ac, ac->unit.slots, &us) == AHA_OK &&
-        upload(ac, ac->unit.root, &ac->udev.root) == AHA_OK && upload(ac, ac->unit.end_info, &ac->d_unit_end_info) == AHA_OK) {
-      ac->udev.slots = reinterpret_cast<const uint2 *>(us);
-      ac->udev.n_slots = ac->unit.n_slots;
-      ac->udev.lo3 = ac->unit.lo3;
-      ac->udev.n3 = n3;
-      ac->udev.max_len = ac->aut.max_key_len;
-      ac->unit_ok = true;
-    }
-  }
-  // position-parallel engine (pp.hpp): bit-exact, but on the BASELINE shapes still slower than the single-traversal
-  // engine (DESIGN.md section 4.5 has the measured budget), so it is opt-in: AHA_ENGINE=pp
-  if (ac->pp.ok && eng && strcmp(eng, "pp") == 0) {
-    ac->pp_lds_slots = std::min<uint32_t>(pp_walk_max_slots(), ac->n_slots & ~3u);
-    if (ac->seg2 > ac->pp_lds_slots) return;  // the walk kernel reads the first two levels from LDS unconditionally
-    if (pp_prepare((uint32_t)ac->pp.bloom.size(), ac->pp_lds_slots) != 0) return;
-    if (upload(ac, ac->pp.t2, &ac->d_pp_t2) != AHA_OK) return;
-    if (upload(ac, ac->pp.bloom, &ac->d_pp_bloom) != AHA_OK) return;
-    ac->pp_grid = (uint32_t)(cus - reserve);
-    ac->pp_ok = true;
-  }
 }
 
 int32_t v2_reserve(aha_ac *ac, Scratch *sc, int i, size_t bytes) {
@@ -474,16 +434,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[0], s));
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
-  // byte offsets through the event regions: the character-level traversal where the key set has a unit image
-  const bool unit = ac->unit_ok && direct && !M.chars;
-  DevAut post = ac->dev;
-  if (unit) {
-    post.end_info = ac->d_unit_end_info;  // events carry bases of the unit image
-    post.compact = 1;
-    unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
-  } else {
-    v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
-  }
+  const DevAut &post = ac->dev;
+  v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
 #ifdef AHA_DIAG
   // lab build (make diag): time the traversal alone; its timing-only variants leave nothing the post passes may read
@@ -522,102 +474,9 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
-    t.engine = unit ? 4 : 2;
+    t.engine = 2;
     t.chunk_bytes = M.S;
     t.n_kernels = 9;
-    (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
-    (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], sc->ev[1]);
-    (void)hipEventElapsedTime(&t.ms_scan, sc->ev[1], sc->ev[2]);
-    (void)hipEventElapsedTime(&t.ms_aux, sc->ev[2], sc->ev[3]);
-    (void)hipEventElapsedTime(&t.ms_write, sc->ev[3], sc->ev[4]);
-    t.n_chunks = M.n_chunks;
-    t.n_hits = *n_hits;
-    publish_timing(ac, t);
-  }
-  return AHA_OK;
-}
-
-// Position-parallel engine (plain byte offsets only).  Returns AHA_OK, an error, or +1 when the caller must take
-// the single-traversal engine (an item list or an event region overflowed: hit-dense input).
-int32_t match_pp(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t *n_hits) {
-  const uint64_t N = M1.n_bytes;
-  V2Args M{};
-  M.text = M1.text;
-  M.doc_off = M1.doc_off;
-  M.n_docs = M1.n_docs;
-  M.n_bytes = N;
-  M.S = kPpChunk;
-  M.n_chunks = (N + kPpChunk - 1) / kPpChunk;
-  if (M.n_chunks > 0xFFFFFFFFull) return 1;
-  M.out = M1.out;
-  M.cap = M1.cap;
-  M.doc_hit_off = M1.doc_hit_off;
-  M.direct = 1;
-  M.dense_hits = 0;
-  M.ev_stride = kPpEvStride;
-  const uint64_t n_blk = (M.n_chunks + 255) / 256 + 2;
-  int32_t rc;
-  if (M.n_docs >= 0xFFFFFFFFull) return 1;
-  const uint32_t walk_grid = (uint32_t)std::min<uint64_t>(ac->pp_grid, std::max<uint64_t>((M.n_chunks + 15) / 16, 1));
-  const int idx[14] = {4, 5, 7, 9, 16, 18, 19, 20, 21, 22, 23, 0, 1, 2};
-  const size_t sizes[14] = {M.n_chunks * 4,      (M.n_docs + 1) * 4, n_blk * 8,
-                            16 * 8,              M.n_chunks * (size_t)kPpEvStride * 8,
-                            M.n_chunks * 4,      M.n_chunks * 8,     M.n_chunks * (size_t)kPpItemCap * 2,
-                            M.n_chunks * 8,      M.n_chunks * 8,     M.n_chunks * 4,
-                            M.n_chunks * (size_t)kPpDeepCap * 8, M.n_chunks * (size_t)kPpLongCap * 4,
-                            M.n_chunks * 4};
-  for (int i = 0; i < 14; i++)
-    if ((rc = v2_reserve(ac, sc, idx[i], sizes[i]))) return rc;
-  M.ev_cnt = (uint32_t *)sc->v2buf[4].p;
-  M.doc_ev_rank = (uint32_t *)sc->v2buf[5].p;
-  M.blk_a = (uint64_t *)sc->v2buf[7].p;
-  M.cursor = (unsigned long long *)sc->v2buf[9].p;
-  M.totals = (uint64_t *)sc->v2buf[9].p + 2;
-  M.evd = (uint2 *)sc->v2buf[16].p;
-  M.chunk_hits = (uint32_t *)sc->v2buf[18].p;
-  M.hit_base = (uint64_t *)sc->v2buf[19].p;
-  PpArgs P{};
-  P.text = M1.text;
-  P.n_bytes = N;
-  P.n_chunks = M.n_chunks;
-  P.t2 = ac->d_pp_t2;
-  P.bloom = ac->d_pp_bloom;
-  P.b_words = (uint32_t)ac->pp.bloom.size();
-  P.items = (uint16_t *)sc->v2buf[20].p;
-  P.tile_end = (unsigned long long *)sc->v2buf[21].p;
-  P.chunk_doc = (uint32_t *)sc->v2buf[22].p;
-  P.lds_slots = ac->pp_lds_slots;
-  P.long_cnt = (uint32_t *)sc->v2buf[23].p;
-  P.deep = (uint2 *)sc->v2buf[0].p;
-  P.longs = (uint32_t *)sc->v2buf[1].p;
-  P.deep_cnt = (uint32_t *)sc->v2buf[2].p;
-  P.flags = M.cursor;
-  if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
-  const bool prof = ac->profiling.load() && sc->ev_ready;
-  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[0], s));
-  HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
-  HIPCHK(ac, hipMemsetAsync(M.ev_cnt, 0, M.n_chunks * 4, s));       // raw candidate counts, then event counts
-  HIPCHK(ac, hipMemsetAsync(P.long_cnt, 0, M.n_chunks * 4, s));
-  HIPCHK(ac, hipMemsetAsync(P.deep_cnt, 0, M.n_chunks * 4, s));
-  const uint64_t waves = (M.n_chunks + 15) / 16;  // 16 waves (chunks) per filter workgroup
-  pp_launch_filter(P, (uint32_t)std::min<uint64_t>(ac->pp_grid, std::max<uint64_t>(waves, 1)), s);
-  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
-  pp_launch_resolve(ac->dev, M, P, walk_grid, s);
-  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
-  v2_launch_direct_post(ac->dev, M, s, prof ? (void *)sc->ev[3] : nullptr);
-  if (prof) HIPCHK(ac, hipEventRecord(sc->ev[4], s));
-  HIPCHK(ac, hipGetLastError());
-  HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(ac, hipStreamSynchronize(s));
-  if (sc->h_v2[1]) return 1;
-  *n_hits = sc->h_v2[2];
-  if (prof) {
-    aha_timing t;
-    memset(&t, 0, sizeof(t));
-    t.struct_size = sizeof(t);
-    t.engine = 3;
-    t.chunk_bytes = kPpChunk;
-    t.n_kernels = 8;
     (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
     (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], sc->ev[1]);
     (void)hipEventElapsedTime(&t.ms_scan, sc->ev[1], sc->ev[2]);
@@ -748,13 +607,6 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   ac->s1_lo = shadow ? pl.seg_start[2] : 0;
   ac->s2_lo = shadow ? pl.seg_start[3] : 0;
   ac->s2_hi = shadow ? pl.deep_fail_start : 0;
-  build_pp(ac->aut, ac->compact, 0, ac->pp);
-  {
-    // character-level image: opt-in (AHA_ENGINE=unit) -- bit-exact, but not faster than the single-traversal engine on
-    // the BASELINE shapes, and building it takes longer than the rest of compile
-    const char *eng = getenv("AHA_ENGINE");
-    if (eng && strcmp(eng, "unit") == 0) build_unit(ac->aut, ac->unit, true);
-  }
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     int n = aha_device_count();
     if (n <= 0) {
@@ -930,15 +782,6 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->fail_s1_lo = ac->s1_lo;
   info->fail_s2_lo = ac->s2_lo;
   info->fail_hdr_lo = ac->s2_hi;
-  info->unit_enabled = ac->unit.ok ? 1u : 0u;
-  info->unit_slots = ac->unit.n_slots;
-  info->unit_lo3 = ac->unit.lo3;
-  info->unit_n3 = ac->unit.n3;
-  info->unit_multi_permille = ac->unit.multi_permille;
-  info->pp_enabled = ac->pp.ok ? 1u : 0u;
-  info->pp_bloom_words = (uint32_t)ac->pp.bloom.size();
-  info->pp_entries = ac->pp.n_entries;
-  info->pp_fill_permille = (uint32_t)(ac->pp.fill * 1000.0 + 0.5);
   return AHA_OK;
 }
 
@@ -992,26 +835,6 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
     case AHA_IMG_KEY_KC:
       src = a.key_kc.data();
       bytes = a.key_kc.size() * 4;
-      break;
-    case AHA_IMG_PP_T2:
-      src = ac->pp.t2.data();
-      bytes = ac->pp.t2.size() * 4;
-      break;
-    case AHA_IMG_PP_BLOOM:
-      src = ac->pp.bloom.data();
-      bytes = ac->pp.bloom.size() * 4;
-      break;
-    case AHA_IMG_UNIT_SLOTS:
-      src = ac->unit.slots.data();
-      bytes = ac->unit.slots.size() * 8;
-      break;
-    case AHA_IMG_UNIT_ROOT:
-      src = ac->unit.root.data();
-      bytes = ac->unit.root.size() * 4;
-      break;
-    case AHA_IMG_UNIT_END_INFO:
-      src = ac->unit.end_info.data();
-      bytes = ac->unit.end_info.size() * 4;
       break;
     case AHA_IMG_STALE_ENDS: {
       // {key id, prefix length} of every state with a stale END flag: the state is that prefix of that key
@@ -1200,18 +1023,6 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
       return AHA_E_CAPACITY;
     }
     return AHA_OK;
-  }
-  if (ac->pp_ok && !M.chars && !M.sep) {
-    rc = match_pp(ac, sc, M, s, n_hits);
-    if (rc < 0) return rc;
-    if (rc == AHA_OK) {
-      if (*n_hits > cap) {
-        tls_err = "output buffer too small";
-        return AHA_E_CAPACITY;
-      }
-      return AHA_OK;
-    }
-    *n_hits = 0;  // rc == 1: hit-dense or unaligned input -> single-traversal engine
   }
   if (ac->v2_ok) {
     rc = match_v2(ac, sc, M, s, n_hits, kRegions);

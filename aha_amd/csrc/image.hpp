@@ -97,7 +97,7 @@ struct V2Args {
   // direct event regions (plain mode): chunk c stores its events in order at evd[c * ev_stride + seq], so the
   // post passes need no sort: count (wave per chunk) -> scan -> expand (wave per chunk)
   int32_t direct;
-  int32_t dense_hits;        // the previous call produced more than one hit per 4 input bytes (or none is known)
+  int32_t dense_hits;        // THIS call's capacity allows for more than one hit per 4 input bytes (capi.cpp match_v2)
   uint32_t ev_stride;        // events a chunk may store (S / 4); more -> overflow flag, slab pipeline instead
   uint2 *evd;                // [n_chunks * ev_stride] {state base (compact) or key id, end offset in the document}
   uint32_t *chunk_hits;      // [n_chunks]
@@ -106,44 +106,6 @@ struct V2Args {
   uint64_t cap;
   uint64_t *doc_hit_off;
 };
-
-// ---- character-level engine (scan_unit.hip, unit.hpp) ---------------------------
-struct UnitDev {
-  const uint2 *slots;    // [n_slots] {lo, hi} entries
-  const uint32_t *root;  // [kUCodes] the root's transitions by unit code
-  uint32_t n_slots;
-  uint32_t lo3, n3;      // three-byte units of the lead bytes 0xE0 + lo3 .. + n3 - 1: root transitions in LDS
-  uint32_t max_len;      // longest key, bytes
-};
-size_t unit_lds_bytes(uint32_t n3);
-int unit_prepare(uint32_t n3);  // raises the dynamic-LDS limit; hipError_t as int
-void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream);
-
-// ---- position-parallel engine (scan_pp.hip, pp.hpp) ---------------------------
-struct PpArgs {
-  const uint8_t *text;       // 16-byte aligned
-  uint64_t n_bytes;
-  uint64_t n_chunks;         // chunks of kPpChunk bytes
-  const uint32_t *t2;        // [kPpT2Words]
-  const uint32_t *bloom;     // [b_words]
-  uint32_t b_words;
-  uint16_t *items;           // [n_chunks * kPpItemCap] position in the chunk | probe flags
-  unsigned long long *tile_end;  // [n_chunks] 4 x 16 bit: items of the chunk up to the end of each 1 KiB tile
-  uint32_t *chunk_doc;       // [2 * n_chunks] first document that starts at or after the chunk / after its halo
-  uint32_t lds_slots;        // slots of the image the walk kernel keeps in LDS
-  uint2 *deep;               // [n_chunks * kPpDeepCap] walks alive at depth kPpGuard: {pos | limit << 16, state}
-  uint32_t *deep_cnt;        // [n_chunks]
-  uint32_t *longs;           // [n_chunks * kPpLongCap] start (+ kPpHalo, chunk relative) | reach << 16
-  uint32_t *long_cnt;        // [n_chunks]
-  unsigned long long *flags; // = V2Args::cursor; [1] = 3: an item list or an event region overflowed
-};
-size_t pp_filter_lds(uint32_t b_words);
-uint32_t pp_walk_max_slots();
-// raises the dynamic-LDS limits of the two kernels; hipError_t as int
-int pp_prepare(uint32_t b_words, uint32_t lds_slots);
-void pp_launch_filter(const PpArgs &P, uint32_t grid, void *stream);
-// events of every chunk in position order -> M.evd / M.ev_cnt / M.doc_ev_rank (then v2_launch_direct_post)
-void pp_launch_resolve(const DevAut &A, const V2Args &M, const PpArgs &P, uint32_t grid, void *stream);
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int

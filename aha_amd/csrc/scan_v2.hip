@@ -86,13 +86,16 @@ enum : int {
   kDgStamp = 8,         // exact walk; s_memtime stamps around the segments of the trip
   kDgSplit = 9,         // exact walk; ds_read for the near lanes + global_load for the far lanes instead of one flat_load
   kDgFarL1 = 10,        // (T) far probes go to an 8 KiB window of the global image (L1 hits): the flat path without L2
-  kDgStorePlain = 11,   // exact walk; plain instead of non-temporal event stores
+  kDgStorePlain = 11,   // (the product since round 3: plain event stores; kept so that the variant numbers stay)
   kDgFarNt = 12,        // exact walk; split loads, the far load non-temporal (nt)
   kDgFarSc1 = 13,       // exact walk; split loads, the far load agent-coherent (sc1: served by L2, no L1 allocation)
   kDgFarWide = 14,      // exact walk; split loads, the far load 8 bytes wide (the slot and its neighbour)
   kDgFar40 = 15,        // (T) 40 % of the far PROBES (not headers) answered from LDS as misses: a perfect 8-bit child filter
   kDgStoreNt = 16,      // exact walk; event stores really non-temporal (buffer store, aux = nt; regions below 4 GiB only)
-  kDgCount = 17
+  kDgNoNul = 17,        // exact on NUL-free text: the trip without the NUL contract's instructions
+  kDgPackE = 18,        // + the state kept as its whole entry (base and "fail is root" flag in one register)
+  kDgSplitMin = 19,     // + ds_read of slot[min(idx, T)] and an exec-masked global_load instead of one flat_load
+  kDgCount = 20
 };
 #ifdef AHA_DIAG
 // per wave: 16 words = cycles of the segments A..E for wave-trips without / with a far lane, then the two trip counts
@@ -108,8 +111,11 @@ __device__ uint32_t g_diag_stamps[256 * (kV2Threads / 64) * 16];
 #endif
 
 // ALL_LDS: the whole image fits the LDS budget (cfg 2): no HBM probe path at all.
+#ifndef AHA_V2_WAVES_PER_SIMD
+#define AHA_V2_WAVES_PER_SIMD 4  // one 1024-thread workgroup per CU; 8 = two (lab: does the occupancy pay?)
+#endif
 template <bool COMPACT, bool CHARS, bool ALL_LDS, int DG = kDgNone>
-__global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
+__global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse(DevAut A, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   using S_ = Slot<COMPACT>;
   using slot_t = typename S_::type;
@@ -175,6 +181,9 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
     slab_used_n += n;
   };
 
+  constexpr bool kLeanNoNul = DG >= kDgNoNul && DG <= kDgSplitMin;
+  constexpr bool kLeanPack = DG >= kDgPackE && DG <= kDgSplitMin;
+  constexpr bool kLeanSplit = DG == kDgSplitMin;
   [[maybe_unused]] uint32_t dg_dummy = 0;             // lab: keeps the added loads / instructions alive
   [[maybe_unused]] uint32_t dg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // lab: stamp sums (wave-uniform)
   [[maybe_unused]] const uint32_t dg_shift = 32u - (31u - (uint32_t)__clz((int)A.n_slots));
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
     uint64_t dn = 0;
     int64_t nb = INT64_MAX, doc_start = a, pos = e;
     uint32_t B = root, fr = 0, seq = 0;
+    [[maybe_unused]] uint32_t E = C_FAILROOT;  // lab (kDgPackE): the state as its entry; the root (base 0) fails to the root
     bool hdr = false;  // the next lookup fetches the fail header of B (no byte consumed)
     // shadow fail (A.s2_lo < A.s2_hi): r1 = root-row entry of the last consumed byte (0 = none), s2 = entry of the
     // depth<=2 state of the last two consumed bytes.  A miss in a state whose base lies in [s2_lo, s2_hi) continues
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             nb_rel = (nb < pb + kV2Piece) ? (uint32_t)(nb - pb) : ~0u;
             B = root;
             fr = 0;
+            E = C_FAILROOT;
             hdr = false;
             r1 = slot_t{};
             s2 = slot_t{};
@@ -379,6 +390,7 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             if constexpr (DG == kDgStamp) AHA_STAMP(dt0);
             const uint32_t bnext = inl[rel + 1];                    // rows are padded: rel + 1 <= piece + 3
             const uint32_t c = b & hm;
+            if constexpr (kLeanPack) B = (uint32_t)S_::base((slot_t)E);
             uint32_t idx = B ^ c;
             // timing-only variants redirect PROBE trips only: a header trip (hm == 0) that never finds its header would
             // repeat forever
@@ -412,6 +424,9 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
                   en = gt[idx];
                 }
               }
+            } else if constexpr (kLeanSplit) {
+              en = lt[min(idx, T)];                                 // slot[T] is the first input row: readable, never used
+              if (idx >= T) en = gt[idx];
             } else {
               if (idx < T)
                 en = lt[idx];
@@ -423,10 +438,11 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             }
             if constexpr (DG == kDgAddLds) dg_dummy ^= (uint32_t)lt[(idx ^ 0x1555u) & 16383u];
             if constexpr (DG == kDgStamp) AHA_STAMP(dt1);           // the LDS reads are back (the stamp waits lgkmcnt(0))
-            const bool nz = b != 0;
+            const bool nz = kLeanNoNul ? true : b != 0;
             const bool probe = hm != 0;
             const bool bzp = !nz && probe;                          // NUL contract: state := root, byte consumed
-            const bool atroot = B == root || fr != 0 || bzp;        // fails[nid] = root: probe the root row now
+            bool atroot = B == root || fr != 0 || bzp;              // fails[nid] = root: probe the root row now
+            if constexpr (kLeanPack) atroot = (E & C_FAILROOT) != 0;
             const bool mr = nz && S_::match(e0, b);                 // b has a depth-1 state
             // fails[nid] of a state in [s1_lo, s2_hi) follows from the last bytes: sx = r1 (depth-2 state) or s2.
             // Its row, the row of ITS fail target (r1: e2) and the root row (e0) are probed in this same trip, so
@@ -455,11 +471,20 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
             const bool t = S_::match(en, c) && !bzp;                // goto (cedar.cr:441-447), or the header itself
             const bool sgo = !t && shadow;
             const bool sres = sgo && near3;
-            const slot_t ex = t ? en : (sgo ? (near3 ? chain : sx) : (mr ? e0 : slot_t{}));
+            slot_t ex = t ? en : (sgo ? (near3 ? chain : sx) : (mr ? e0 : slot_t{}));
+            if constexpr (kLeanPack) {  // "no state" is the root's entry: base 0, fails to the root
+              const slot_t re = (slot_t)C_FAILROOT;
+              const slot_t chain_r = m3 ? e3 : (m2 ? e2 : (mr ? e0 : re));
+              ex = t ? en : (sgo ? (near3 ? chain_r : sx) : (mr ? e0 : re));
+            }
             const bool land = t || atroot || sgo;                   // else: the next trip loads fails[nid] (ac.cr:189)
             const bool consumed = (t && probe) || (!t && atroot) || sres;  // at root a miss consumes (ac.cr:188)
-            B = land ? S_::base(ex) : B;
-            fr = land ? S_::failroot(ex) : fr;
+            if constexpr (kLeanPack) {
+              E = land ? (uint32_t)ex : E;
+            } else {
+              B = land ? S_::base(ex) : B;
+              fr = land ? S_::failroot(ex) : fr;
+            }
             hm = land ? 0xFFu : 0u;
             ev = consumed && S_::end(ex) && emit_ok;                // is_end? -> fetch later (ac.cr:183-185)
             s2 = consumed ? s2n : s2;
@@ -482,18 +507,16 @@ __global__ __launch_bounds__(kV2Threads) void k2_traverse(DevAut A, V2Args M) {
               if (seq < ev_stride) {
                 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
                 const v2u rec = {en_keep, CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel)};
-                // sparse events are streamed past L2 (it keeps the image); dense ones (the previous call had more
-                // than one hit per 4 bytes) fill whole lines quickly and are better merged in L2
+                // a plain 8-byte store: hipcc ignores __builtin_nontemporal_store on gfx950, and a real non-temporal
+                // store (buffer store, aux = nt: lab variant kDgStoreNt) is worth under 1 % (profiles/r03_trip_anatomy.txt)
                 if constexpr (DG == kDgNoStore || DG == kDgNoFarNoStore) {
                   dg_dummy ^= rec.x ^ rec.y;
                 } else if constexpr (DG == kDgStoreNt) {
                   __builtin_amdgcn_raw_buffer_store_b64(
                       rec, __builtin_amdgcn_make_buffer_rsrc(M.evd, 0, -1, 0x00020000),
                       (int)(((uint32_t)chunk * ev_stride + seq) * 8u), 0, 2);
-                } else if (M.dense_hits || DG == kDgStorePlain) {
-                  *reinterpret_cast<v2u *>(evreg + seq) = rec;
                 } else {
-                  __builtin_nontemporal_store(rec, reinterpret_cast<v2u *>(evreg + seq));
+                  *reinterpret_cast<v2u *>(evreg + seq) = rec;
                 }
               } else {
                 M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
@@ -1002,6 +1025,9 @@ static void diag_launch(const DevAut &A, const V2Args &M, uint32_t grid, size_t 
     case 14: diag_launch_one<14>(A, M, grid, lds, s); break;
     case 15: diag_launch_one<15>(A, M, grid, lds, s); break;
     case 16: diag_launch_one<16>(A, M, grid, lds, s); break;
+    case 17: diag_launch_one<17>(A, M, grid, lds, s); break;
+    case 18: diag_launch_one<18>(A, M, grid, lds, s); break;
+    case 19: diag_launch_one<19>(A, M, grid, lds, s); break;
     default: break;
   }
 }

@@ -102,14 +102,6 @@ typedef struct {
   uint32_t slot_bytes;      /* 4 (compact) or 8 (wide) */
   uint32_t lds_slots;       /* slots of the image cached in LDS by the match kernel */
   int32_t device;           /* device the image lives on, -1 if host only */
-  /* Character-level image (engine 4; aha_amd/csrc/unit.hpp), built when AHA_ENGINE=unit and every key is a sequence
-   * of UTF-8-shaped units: plain byte-offset matches then take one step per character instead of one per byte
-   * (bit-exact; opt-in because it is not faster than engine 2 on the measured shapes). */
-  uint32_t unit_enabled;
-  uint32_t unit_slots;          /* 8-byte slots of its double array */
-  uint32_t unit_lo3, unit_n3;   /* three-byte units with first byte 0xE0 + lo3 .. + n3 - 1: root transitions kept in LDS */
-  uint32_t unit_multi_permille; /* key bytes in multi-byte units, per 1000 */
-  uint32_t reserved;
   /* Shadow fail links (all 0 = every state has a fail header at slot[base]).  Otherwise only the root and the
    * states with base >= fail_hdr_lo own one; for the others the fail target follows from the last input bytes:
    * base < fail_s1_lo: root; base < fail_s2_lo: the depth-1 state of the last byte; base < fail_hdr_lo: the
@@ -117,15 +109,7 @@ typedef struct {
   uint32_t fail_s1_lo;
   uint32_t fail_s2_lo;
   uint32_t fail_hdr_lo;
-  uint32_t reserved2;
-  /* Position-parallel engine (engine 3; aha_amd/csrc/pp.hpp): 1 when the automaton meets its preconditions (no
-   * 1-byte key, longest key <= 240 bytes, compact slots, Bloom filter at most half full).  Plain byte-offset
-   * matches then run: filter pass (every start position classified independently in LDS) -> exact resolve pass. */
-  uint32_t pp_enabled;
-  uint32_t pp_bloom_words;   /* 32-bit words of the LDS Bloom filter */
-  uint64_t pp_entries;       /* 3- and 4-byte keys + trie paths of depth 5 behind it */
-  uint32_t pp_fill_permille; /* bits set per 1000 */
-  uint32_t reserved3;
+  uint32_t reserved;
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded
@@ -134,18 +118,19 @@ typedef struct {
   uint32_t struct_size;
   uint32_t n_kernels;
   float ms_total;           /* first launch -> hits and offsets final in HBM */
-  float ms_count;           /* engine 3: the filter pass; engine 2: the traversal kernel; engine 1: traversal pass 1 */
-  float ms_scan;            /* engine 3: the resolve pass; engines 1, 2: scans of per-chunk counts */
-  float ms_write;           /* engines 2, 3: chain expansion + doc offsets; engine 1: traversal pass 2 */
-  float ms_aux;             /* engine 3: hits per chunk + scan; engine 2: event sort; engine 1: char-offset prefix pass */
+  float ms_count;           /* engine 2: the traversal kernel; engine 1: traversal pass 1 */
+  float ms_scan;            /* scans of per-chunk counts */
+  float ms_write;           /* engine 2: chain expansion + doc offsets; engine 1: traversal pass 2 */
+  float ms_aux;             /* engine 2: hits per chunk + scan (regions) or event sort (slabs); engine 1: char-offset prefix pass */
   uint64_t n_chunks;
   uint64_t n_hits;
-  uint32_t engine;          /* 3 = position-parallel engine, 2 = single-traversal engine, 1 = two-pass engine */
+  uint32_t engine;          /* 2 = single-traversal engine, 1 = two-pass engine */
   uint32_t chunk_bytes;     /* bytes per lane chunk */
 } aha_timing;
 
 const char *aha_strerror(int32_t code);
-/* Message of the last error on this handle (thread-unsafe snapshot). */
+/* Message of the last error of the CALLING THREAD (thread-local: calls on one handle may run concurrently; `ac` may be
+ * NULL, e.g. after aha_buffer_* / aha_corpus_upload). */
 const char *aha_last_error(const aha_ac *ac);
 uint32_t aha_abi_version(void);
 /* Number of visible HIP devices (0 when there is none / no driver). */
@@ -233,12 +218,7 @@ enum {
   AHA_IMG_KEY_LN = 2,  /* {uint32 len, int32 next}[K] */
   AHA_IMG_KEY_CNT = 3, /* uint32[K] */
   AHA_IMG_KEY_KC = 4,  /* uint32[K] */
-  AHA_IMG_PP_T2 = 7,   /* uint32[4096]: 2-bit entries of the position-parallel engine's pair table */
-  AHA_IMG_PP_BLOOM = 8, /* uint32[pp_bloom_words] */
-  AHA_IMG_UNIT_SLOTS = 9,     /* uint64[unit_slots]: lo = base | END << 31 | FAILROOT << 30, hi = unit code (unit.hpp) */
-  AHA_IMG_UNIT_ROOT = 10,     /* uint32[0x10880]: the root's transitions, indexed by unit code */
-  AHA_IMG_UNIT_END_INFO = 11, /* uint32[unit_slots]: key id | min(chain length, 255) << 24, or 0xFFFFFFFF */
-  AHA_IMG_STALE_ENDS = 12     /* {uint32 key id, uint32 prefix length}[]: the states (a prefix of a key each) whose node in
+  AHA_IMG_STALE_ENDS = 5     /* {uint32 key id, uint32 prefix length}[]: the states (a prefix of a key each) whose node in
                                  the reference's Cedar keeps a stale END flag (src/aha/cedar.cr:642-648); match_longest
                                  treats them as ends that yield nothing (src/aha/ac.cr:126-128, 249-263) */
 };

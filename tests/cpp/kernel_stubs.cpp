@@ -13,16 +13,8 @@ namespace aha {
   fprintf(stderr, "sanitizer build: %s reached (host-only library)\n", what);
   abort();
 }
-size_t pp_filter_lds(uint32_t) { return 0; }
-uint32_t pp_walk_max_slots() { return 1u << 14; }
-int pp_prepare(uint32_t, uint32_t) { return 0; }
-void pp_launch_filter(const PpArgs &, uint32_t, void *) { no_gpu("pp_launch_filter"); }
-void pp_launch_resolve(const DevAut &, const V2Args &, const PpArgs &, uint32_t, void *) { no_gpu("pp_launch_resolve"); }
 size_t v2_lds_bytes(uint32_t, bool) { return 0; }
 int v2_prepare(bool, size_t) { return 0; }
-size_t unit_lds_bytes(uint32_t) { return 0; }
-int unit_prepare(uint32_t) { return 0; }
-void unit_launch_traverse(const UnitDev &, const V2Args &, uint32_t, void *) { no_gpu("unit_launch_traverse"); }
 void v2_launch_traverse(const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("v2_launch_traverse"); }
 void v2_launch_chunk_scan(const V2Args &, void *) { no_gpu("v2_launch_chunk_scan"); }
 void v2_launch_sort(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("v2_launch_sort"); }

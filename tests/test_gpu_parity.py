@@ -17,17 +17,13 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["pp", "v2", "v1", "v2p", "u"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2p"], autouse=True)
 def engine(request, monkeypatch):
-    """Every parity test runs on the single-traversal engine (scan_v2.hip, the default), on the opt-in
-    position-parallel engine ("pp", scan_pp.hip: wherever the automaton meets its preconditions, else and for
-    char offsets / separators the single-traversal engine), on the two-pass engine (kernels.hip) and on the
-    single-traversal engine with its LDS prefix capped at 1024 slots ("v2p": small automata then also take
-    the partial-prefix kernel with the shadow fail links and the HBM probe path), and on the character-level engine
-    ("u", scan_unit.hip: AHA_ENGINE=unit builds the unit image for every eligible key set, also the mostly-ASCII
-    ones that would not get one by default; byte-offset calls through the event regions then run it, everything else
-    the single-traversal engine).  The variables are read when a handle is compiled."""
-    monkeypatch.setenv("AHA_ENGINE", {"pp": "pp", "v1": "v1", "u": "unit"}.get(request.param, "v2"))
+    """Every parity test runs on the single-traversal engine (scan_v2.hip, the default), on the two-pass engine
+    (kernels.hip: the fallback for tiny capacities and very long keys) and on the single-traversal engine with its LDS
+    prefix capped at 1024 slots ("v2p": small automata then also take the partial-prefix kernel with the shadow fail
+    links and the HBM probe path).  The variables are read when a handle is compiled."""
+    monkeypatch.setenv("AHA_ENGINE", "v1" if request.param == "v1" else "v2")
     if request.param == "v2p":
         monkeypatch.setenv("AHA_LDS_SLOTS", "1024")
     else:
@@ -429,18 +425,15 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
 
 
 def test_engine_selected(engine):
-    ac = AC.compile(["ab", "b"])  # a 1-byte key: outside the position-parallel engine's preconditions
+    ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine == "u" else (2,))
+    assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
     ac = AC.compile(["ab", "ba"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"ab ba " * 60))[:3] == [(0, 2, 0), (3, 5, 1), (6, 8, 0)]
-    assert ac.last_timing()["engine"] in {"pp": (3,), "v1": (1,), "u": (2, 4)}.get(engine, (2,))
-    # an item at every position overflows the per-chunk lists: the call is repeated on the single-traversal engine
-    assert gpu_list(ac.match_array(b"abab" * 400))[:3] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine == "u" else (2,))
-    # char offsets and the separator filter stay on the single-traversal engine
+    assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
+    # char offsets and the separator filter run on the same engine
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
     assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
 
@@ -456,16 +449,13 @@ def _keys_ge2(rng, n, alphabet, maxlen):
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_pp_random_batches(seed):
-    """Random automata inside the position-parallel engine's preconditions, ragged batches: empty and one-byte
-    documents, documents that end inside a key, NUL bytes, matches across the 4 KiB chunk and 1 KiB tile
-    boundaries, runs of tiny documents (more boundaries per window than the resolve pass caches)."""
+def test_ragged_random_batches(seed):
+    """Random automata (keys of two bytes and more), ragged batches: empty and one-byte documents, documents that end
+    inside a key, NUL bytes, matches across chunk boundaries, runs of tiny documents."""
     rng = random.Random(4000 + seed)
     alphabet = [b"ab", b"abc", b"abcd\xe4\xb8\xad", bytes(range(0x61, 0x7B)), b"ab\xd0\xb0\xb1"][seed % 5]
     keys = _keys_ge2(rng, rng.randint(1, 300), alphabet, [6, 12, 40][seed % 3])
     g = AC.compile(keys)
-    assert g.info["pp_enabled"]
-    g.set_profiling(True)
     o = orc.AC.compile(keys)
     fill = alphabet + (b"\x00 " if seed % 2 else b" ")
     lens = [0, 0, 1, 2, 3, 50, 255, 256, 257, 1000, 4095, 4096, 4097, 9000]
@@ -479,16 +469,10 @@ def test_pp_random_batches(seed):
     oh, od = o.match_batch(corpus, offs, cap=len(gh) + 16)
     assert np.array_equal(gd, od)
     assert gh.tobytes() == oh.tobytes()
-    if engine_is_default():  # hit-dense batches overflow the item lists and take the single-traversal engine
-        assert g.last_timing()["engine"] == (3 if len(gh) * 16 < corpus.size else g.last_timing()["engine"])
 
 
-def engine_is_default():
-    return os.environ.get("AHA_ENGINE") == "pp"
-
-
-def test_pp_long_and_nested_keys():
-    """Keys up to the engine's 240-byte limit, a suffix-closed family (every suffix a key: output chains) and a
+def test_long_and_nested_keys():
+    """Keys up to 240 bytes, a suffix-closed family (every suffix a key: output chains) and a
     broken chain, in one document that is several chunks long."""
     rng = random.Random(77)
     w = bytes(rng.choice(b"abcdefgh") for _ in range(16))
@@ -497,7 +481,6 @@ def test_pp_long_and_nested_keys():
     keys += [v, v[1:], v[2:] + b"#"] + [v[j:] for j in range(3, 15)]
     keys = list(dict.fromkeys(keys))
     g = AC.compile(keys)
-    assert g.info["pp_enabled"]
     o = orc.AC.compile(keys)
     text = b"".join(rng.choice([w, v, b"x" + w, keys[16], keys[17], b"ab", b" ", v[2:] + b"#"]) for _ in range(600))
     assert gpu_list(g.match_array(text)) == as_list(o.match(text))
@@ -572,8 +555,8 @@ def test_full_size_properties(cfg, engine):
     properties instead of a full oracle run -- ordering, every hit spells its
     key, document independence (any split of the batch gives the same hits),
     engine agreement by checksum -- plus the oracle on a sample of documents."""
-    if engine not in ("pp", "v2"):
-        pytest.skip("full-size run: the default engine selection and the single-traversal engine")
+    if engine != "v2":
+        pytest.skip("full-size run: the default engine")
     import hashlib
 
     import torch
@@ -672,8 +655,8 @@ def test_single_large_document_vs_oracle(engine):
     """SURVEY 8d single-document variant: one 256 MiB document, so every chunk
     but the first starts in the middle of a sequence (warm-up overlap at scale).
     Full comparison with the oracle."""
-    if engine not in ("pp", "v2"):
-        pytest.skip("run on the default engine selection and on the single-traversal engine")
+    if engine != "v2":
+        pytest.skip("once, on the default engine")
     import torch
 
     blob, offs, nf = synth.keys(3)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that gathers a round's evidence (run from the repo root on the GPU box):
 #   tools/collect_profiles.sh <tag>           headline config: bench JSON, rocprofv3 kernel stats, PMC passes
-#   + the other configurations as plain bench lines: cfg 2 (64 MiB and 1 GiB), cfg 5, String overload, pp / unit / v1 engines
+#   + the other configurations as plain bench lines: cfg 2 (64 MiB and 1 GiB), cfg 5, String overload, the two-pass engine
 # Usage: tools/collect_round.sh <tag>   -> gpurun_out/<tag>/...
 set -o pipefail
 tag=${1:-round}
@@ -19,6 +19,4 @@ run bench_cfg2_64MiB --config 2 --steps 20 --warmup 3
 run bench_cfg2_1GiB --config 2 --bytes 1073741824 --steps 10 --warmup 3
 run bench_cfg5 --config 5 --steps 5 --warmup 2
 run bench_cfg3_chars --chars --steps 10 --warmup 3
-AHA_ENGINE=pp run bench_cfg3_pp --steps 10 --warmup 3
-AHA_ENGINE=unit run bench_cfg3_unit --steps 10 --warmup 3
 AHA_ENGINE=v1 run bench_cfg3_v1 --steps 3 --warmup 1

@@ -47,7 +47,7 @@ while time.time() < t_end:
             keys.append(k)
     env = {"AHA_LDS_SLOTS": rng.choice([None, None, "512", "1024", "4096"]),
            "AHA_SHADOW_FAIL": rng.choice([None, None, None, "0"]),
-           "AHA_ENGINE": rng.choice([None, None, "pp", "pp", "v1", "unit", "unit"]),
+           "AHA_ENGINE": rng.choice([None, None, None, "v1"]),
            "AHA_DIRECT": rng.choice([None, None, "0"])}
     for k, v in env.items():
         if v is None:

@@ -21,7 +21,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["AHA_HIP_LIB"] = os.path.join(ROOT, "aha_amd", "libaha_hip_diag.so")
+os.environ["AHA_HIP_LIB"] = os.environ.get("AHA_LAB_LIB") or os.path.join(ROOT, "aha_amd", "libaha_hip_diag.so")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -34,6 +34,9 @@ KNOBS = [
     (12, "split loads, far load non-temporal (nt)", "exact"),
     (13, "split loads, far load sc1 (L2-served, no L1 allocation)", "exact"),
     (14, "split loads, far load 8 bytes wide", "exact"),
+    (17, "trip without the NUL contract's instructions (text has no NUL)", "exact"),
+    (18, "+ state kept as its whole entry (base + fail-is-root flag)", "exact"),
+    (19, "+ ds_read slot[min(idx,T)] and masked global_load", "exact"),
     (5, "+1 independent far load per far lane", "exact"),
     (6, "+16 dependent VALU per trip", "exact"),
     (7, "+1 random ds_read_b32 per trip", "exact"),
@@ -53,6 +56,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bytes", type=int, default=1 << 30)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
+    ap.add_argument("--keys", type=int, default=None)
+    ap.add_argument("--knobs", default=None, help="comma-separated variant numbers (default: all)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "lab", "trip_anatomy.txt"))
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
@@ -74,14 +80,15 @@ def main():
     L.aha_diag_read_stamps.restype = C.c_int
     dev = torch.device("cuda", 0)
     t0 = time.time()
-    blob, offs, nf = synth.keys(3)
-    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=args.bytes)
+    blob, offs, nf = synth.keys(args.config, K=args.keys)
+    corpus, doc = synth.corpus(args.config, blob, offs, nf, n_bytes=args.bytes)
     D = doc.size - 1
     ac = AC.compile_packed(blob, offs, device=0)
     ac.set_profiling(True)
     info = ac.info
-    say(f"# cfg 3: {offs.size - 1} keys, {args.bytes} bytes, {D} documents; image {info['n_slots']} slots, "
-        f"{info['lds_slots']} in LDS; setup {time.time() - t0:.1f}s")
+    say(f"# cfg {args.config}: {offs.size - 1} keys, {args.bytes} bytes, {D} documents; image {info['n_slots']} slots, "
+        f"{info['lds_slots']} in LDS; lib {os.path.basename(os.environ['AHA_HIP_LIB'])}, "
+        f"AHA_V2_BPC={os.environ.get('AHA_V2_BPC', '1')}; setup {time.time() - t0:.1f}s")
     d_corpus = torch.from_numpy(corpus).to(dev)
     d_doc = torch.from_numpy(doc.astype(np.int64)).to(dev)
     d_dho = torch.zeros(D + 1, dtype=torch.int64, device=dev)
@@ -97,7 +104,10 @@ def main():
     base_ms = None
     say(f"# {n_hits} hits per pass; traversal time = HIP events inside the library (ms_count), median of {args.steps}")
     say(f"{'variant':<62} {'walk':<7} {'traverse ms':>11} {'vs product':>10}  check")
+    want = None if args.knobs is None else [int(x) for x in args.knobs.split(",")]
     for knob, name, kind in KNOBS:
+        if want is not None and knob not in want:
+            continue
         L.aha_diag_set(knob)
         if kind == "timing":
             os.environ["AHA_DIAG_TRAVERSE_ONLY"] = "1"

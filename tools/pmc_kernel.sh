@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counters of one kernel of the bench (gpurun): tools/pmc_kernel.sh <tag> <kernel substring>
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/${1:-pmc}; kern=${2:-k_pp_walk}; shift; shift
+out=gpurun_out/${1:-pmc}; kern=${2:-k2_traverse}; shift; shift
 mkdir -p $out
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVES" \

@@ -20,7 +20,7 @@ out = {"_note": note, "config": 3, "bytes_per_gpu": 1 << 30, "git_head": head + 
 
 
 def short(k):
-    m = re.search(r"(k2?d?_[a-z_]+|k_pp_[a-z_]+|ku_[a-z_]+)", k)
+    m = re.search(r"(k2?d?_[a-z_]+)", k)
     return m.group(1) if m else None
 
 

@@ -195,6 +195,30 @@ int32_t upload_image(aha_ac *ac, const Image &img) {
   d.s2_lo = ac->s2_lo;
   d.s2_hi = ac->s2_hi;
   int32_t rc;
+  // flattened output chains (image.hpp): total length = sum of key_cnt; they need 24-bit offsets
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < a.n_keys; k++) total += a.key_cnt[k];
+  d.key_info = nullptr;
+  d.chain = nullptr;
+  d.chain_kc = nullptr;
+  std::vector<uint32_t> kinfo;
+  if (a.n_keys && total < (1ull << 24)) {
+    std::vector<uint32_t> kc;
+    std::vector<uint2> ch;
+    kinfo.resize(a.n_keys);
+    ch.reserve((size_t)total);
+    kc.reserve((size_t)total);
+    for (uint32_t k = 0; k < a.n_keys; k++) {
+      kinfo[k] = (uint32_t)ch.size() | (std::min<uint32_t>(a.key_cnt[k], 255u) << 24);
+      for (int32_t j = (int32_t)k; j >= 0; j = a.key_next[j]) {
+        ch.push_back(uint2{a.key_len[j], (uint32_t)j});
+        kc.push_back(a.key_kc[j] + 1u);
+      }
+    }
+    if ((rc = upload(ac, kinfo, &d.key_info))) return rc;
+    if ((rc = upload(ac, ch, &d.chain))) return rc;
+    if ((rc = upload(ac, kc, &d.chain_kc))) return rc;
+  }
   if (img.compact) {
     const uint32_t *p = nullptr;
     if ((rc = upload(ac, img.narrow, &p))) return rc;
@@ -203,7 +227,7 @@ int32_t upload_image(aha_ac *ac, const Image &img) {
     std::vector<uint32_t> info(img.end_key.size(), 0xFFFFFFFFu);
     for (size_t i = 0; i < info.size(); i++) {
       const int32_t k = img.end_key[i];
-      if (k >= 0) info[i] = (uint32_t)k | (std::min<uint32_t>(a.key_cnt[k], 255u) << 24);
+      if (k >= 0) info[i] = kinfo.empty() ? ((uint32_t)k | (std::min<uint32_t>(a.key_cnt[k], 255u) << 24)) : kinfo[k];
     }
     if ((rc = upload(ac, info, &d.end_info))) return rc;
   } else {

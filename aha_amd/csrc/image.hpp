@@ -11,10 +11,18 @@ namespace aha {
 struct DevAut {
   const void *slots;         // uint2[n_slots] (wide) or uint32[n_slots] (compact)
   const int32_t *end_key;    // compact only: key id at header slots of end states
-  const uint32_t *end_info;  // compact only: end_key | min(key_cnt, 255) << 24 (one gather in the count pass)
+  const uint32_t *end_info;  // compact only: end_key (or, with flattened chains, its chain offset) | min(key_cnt, 255) << 24
   const uint2 *key_ln;       // [K] {len, next}: ac.cr key_lens / output.next chain
   const uint32_t *key_cnt;   // [K] hits emitted when the key's state is reached
   const uint32_t *key_kc;    // [K] lead bytes in key[1..len)
+  // the output chains once more, flattened (null when their total length is unreasonable): key k's chain is
+  // chain[chain_off[k] .. + key_cnt[k]) = {len, key} of the key itself and of every key after it on the chain, so the
+  // expansion reads consecutive entries instead of chasing key_ln.next (cfg 5: 947 M dependent gathers otherwise)
+  // With the flattened chains an event record carries `chain offset | min(chain length, 255) << 24` instead of the key
+  // id (k2d_count takes it from end_info / key_info with the one gather it makes anyway); chains need 24-bit offsets.
+  const uint32_t *key_info;   // [K] chain_off[k] | min(key_cnt[k], 255) << 24 (wide format: gathered by the count pass)
+  const uint2 *chain;         // {len, key}
+  const uint32_t *chain_kc;   // lead bytes in key[1..len) + 1, same index (char offsets)
   uint32_t root;
   uint32_t n_slots;
   uint32_t max_len;

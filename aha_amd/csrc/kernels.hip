@@ -534,12 +534,18 @@ struct SegTab {
   uint64_t woff[kMaxSegs], nh[kMaxSegs], ooff[kMaxSegs];
 };
 
-__global__ __launch_bounds__(kPk4Block) void k_unpack4(const uint32_t *land, SegTab S, const uint2 *key_ln,
-                                                       const uint32_t *key_kc, int chars, int32_t *hits_all) {
-  __shared__ uint32_t wcnt[16];
-  __shared__ int32_t wagg[16];
-  __shared__ uint32_t wflag[16];
-  __shared__ int32_t stage[kPk4Block * 3];
+// 256 threads rebuild a block of 1024 hits, four consecutive hits per thread: one 16-byte load of the words, the
+// exception ranks from four ballots, a segmented scan over (restart, sum) pairs -- inside the thread, then across the
+// wave, then across the four waves --, and the 48 bytes of a thread's triples go through LDS so that every store
+// instruction writes 1 KiB of consecutive bytes (16 bytes per lane).
+constexpr uint32_t kUnpThreads = 256;
+
+__global__ __launch_bounds__(kUnpThreads) void k_unpack4(const uint32_t *land, SegTab S, const uint2 *key_ln,
+                                                         const uint32_t *key_kc, int chars, int32_t *hits_all) {
+  __shared__ uint32_t wcnt[4];
+  __shared__ int32_t wagg[4];
+  __shared__ uint32_t wflag[4];
+  __shared__ uint4 stage[kPk4Block * 3 / 4];
   uint32_t seg = 0;
   while (seg + 1 < S.n && blockIdx.x >= S.blk0[seg + 1]) seg++;  // wave-uniform: a handful of scalar compares
   const uint32_t bid = blockIdx.x - S.blk0[seg];
@@ -550,19 +556,55 @@ __global__ __launch_bounds__(kPk4Block) void k_unpack4(const uint32_t *land, Seg
   const int32_t *exc = reinterpret_cast<const int32_t *>(words + n + nb);
   int32_t *hits = hits_all + S.ooff[seg] * 3;
   const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const uint64_t i = (uint64_t)bid * kPk4Block + t;
-  const bool valid = i < n;
-  const uint32_t wd = valid ? words[i] : 0u;
-  const uint32_t step = wd & 0xFFFu, value = wd >> 12;
-  const bool f = valid && step == kPk4Exc;
-  const unsigned long long m = __ballot(f);
-  if (lane == 0) wcnt[w] = (uint32_t)__popcll(m);
+  const uint64_t i0 = (uint64_t)bid * kPk4Block + 4u * t;
+  const uint32_t left = i0 < n ? (uint32_t)min<uint64_t>(4, n - i0) : 0u;  // valid hits of this thread
+  uint32_t wd[4] = {0, 0, 0, 0};
+  const uint32_t *src = words + i0;
+  if (left == 4 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(src);
+    wd[0] = q.x; wd[1] = q.y; wd[2] = q.z; wd[3] = q.w;
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      if (k < left) wd[k] = src[k];
+  }
+  bool f[4];
+  uint32_t before = 0, mine = 0;  // exceptions of the wave before this thread; of this thread
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    f[k] = k < left && (wd[k] & 0xFFFu) == kPk4Exc;
+    const unsigned long long m = __ballot(f[k]);
+    before += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    mine += f[k] ? 1u : 0u;
+  }
+  {
+    // exceptions of the whole wave = those before the last lane + the last lane's own
+    const uint32_t tot = __shfl(before + mine, 63, 64);
+    if (lane == 0) wcnt[w] = tot;
+  }
   __syncthreads();
-  uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  uint32_t rank = before;
   for (uint32_t u = 0; u < w; u++) rank += wcnt[u];
-  int32_t x = f ? exc[(uint64_t)blk[bid] + rank] : (int32_t)step;
-  // segmented inclusive scan inside the wave: an exception restarts the sum
-  uint32_t fl = f ? 1u : 0u;
+  const uint64_t e0 = (uint64_t)blk[bid] + rank;
+  // inside the thread: pre[k] = end of hit k if nothing came before the thread, seen[k] = an exception at or before k
+  int32_t pre[4];
+  bool seen[4];
+  int32_t v = 0;
+  bool any = false;
+  uint32_t taken = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    const int32_t x = f[k] ? exc[e0 + taken] : (int32_t)(wd[k] & 0xFFFu);
+    taken += f[k] ? 1u : 0u;
+    v = f[k] ? x : v + x;
+    any = any || f[k];
+    pre[k] = v;
+    seen[k] = any;
+  }
+  // across the wave: inclusive segmented scan of the threads' (restart, sum) pairs
+  int32_t x = v;
+  uint32_t fl = any ? 1u : 0u;
+#pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int32_t ux = __shfl_up(x, o);
     const uint32_t uf = __shfl_up(fl, o);
@@ -575,23 +617,47 @@ __global__ __launch_bounds__(kPk4Block) void k_unpack4(const uint32_t *land, Seg
     wagg[w] = x;
     wflag[w] = fl;
   }
+  int32_t cx = __shfl_up(x, 1);  // what the threads before this one carry in
+  uint32_t cf = __shfl_up(fl, 1);
+  if (lane == 0) {
+    cx = 0;
+    cf = 0;
+  }
   __syncthreads();
-  if (!fl) {  // nothing restarted the sum inside this wave so far: carry what the earlier waves of the block hold
+  if (!cf) {  // nothing restarted the sum in this wave before the thread: add what the earlier waves hold
     int32_t c = 0;
     for (uint32_t u = 0; u < w; u++) c = wflag[u] ? wagg[u] : c + wagg[u];
-    x += c;
+    cx += c;
   }
-  int32_t len = 0;
-  if (valid) len = chars ? (int32_t)key_kc[value] + 1 : (int32_t)key_ln[value].x;
-  stage[t * 3 + 0] = x - len;
-  stage[t * 3 + 1] = x;
-  stage[t * 3 + 2] = (int32_t)value;
-  __syncthreads();
-  const uint64_t base = (uint64_t)bid * kPk4Block * 3;
-  const uint64_t total = n * 3;
-  for (uint32_t k = 0; k < 3; k++) {
-    const uint64_t j = base + k * kPk4Block + t;
-    if (j < total) hits[j] = stage[k * kPk4Block + t];
+  int32_t o12[12];
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    const uint32_t value = wd[k] >> 12;
+    const int32_t end = seen[k] ? pre[k] : pre[k] + cx;
+    int32_t len = 0;
+    if (k < left) len = chars ? (int32_t)key_kc[value] + 1 : (int32_t)key_ln[value].x;
+    o12[3 * k + 0] = end - len;
+    o12[3 * k + 1] = end;
+    o12[3 * k + 2] = (int32_t)value;
+  }
+  int32_t *dst = hits + (uint64_t)bid * kPk4Block * 3;
+  const uint64_t rest = n - (uint64_t)bid * kPk4Block;  // hits of this block and after
+  if (rest >= kPk4Block && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {  // block-uniform
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++)
+      stage[3 * t + j] = make_uint4((uint32_t)o12[4 * j], (uint32_t)o12[4 * j + 1], (uint32_t)o12[4 * j + 2],
+                                    (uint32_t)o12[4 * j + 3]);
+    __syncthreads();
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) d4[j * kUnpThreads + t] = stage[j * kUnpThreads + t];
+  } else {  // the last block of a stream, or an output that is not 16-byte aligned: dword stores through the same staging
+    int32_t *st = reinterpret_cast<int32_t *>(stage);
+#pragma unroll
+    for (uint32_t q = 0; q < 12; q++) st[12 * t + q] = o12[q];
+    __syncthreads();
+    const uint32_t total = (uint32_t)min<uint64_t>(rest, kPk4Block) * 3;
+    for (uint32_t j = t; j < total; j += kUnpThreads) dst[j] = st[j];
   }
 }
 
@@ -621,7 +687,7 @@ void launch_hits_unpack4_segs(const DevAut &A, const uint32_t *land, const uint6
   }
   S.blk0[S.n] = blocks;
   if (!blocks) return;
-  hipLaunchKernelGGL(k_unpack4, dim3(blocks), dim3(kPk4Block), 0, (hipStream_t)stream, land, S, A.key_ln, A.key_kc,
+  hipLaunchKernelGGL(k_unpack4, dim3(blocks), dim3(kUnpThreads), 0, (hipStream_t)stream, land, S, A.key_ln, A.key_kc,
                      chars, hits);
 }
 

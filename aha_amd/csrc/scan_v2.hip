@@ -856,9 +856,14 @@ __global__ __launch_bounds__(256) void k2d_count(DevAut A, V2Args M) {
       // the event record gets the key and (8 bits, 255 = look it up) the chain length: key ids fit 24 bits
       uint32_t x = reg[i].x, cnt;
       if (COMPACT) {
-        x = A.end_info[x];
+        x = A.end_info[x];  // key id, or (flattened chains) the offset of its chain, | min(chain length, 255) << 24
         cnt = x >> 24;
-        if (cnt == 255u) cnt = A.key_cnt[x & 0xFFFFFFu];
+        if (cnt == 255u) cnt = A.key_cnt[A.chain ? A.chain[x & 0xFFFFFFu].y : (x & 0xFFFFFFu)];
+      } else if (A.chain) {
+        const uint32_t key = x;
+        x = A.key_info[key];
+        cnt = x >> 24;
+        if (cnt == 255u) cnt = A.key_cnt[key];
       } else {
         cnt = A.key_cnt[x];
         x |= min(cnt, 255u) << 24;
@@ -874,13 +879,15 @@ __global__ __launch_bounds__(256) void k2d_count(DevAut A, V2Args M) {
 
 // One wave (= one 64-thread workgroup) per chunk: in-wave scan of hits per event, chains
 // assembled in LDS and streamed out with coalesced stores.
-// kWaveStage hits are staged per batch of 64 events: 1024 (12 KiB of LDS) for hit-dense input, 256 (3 KiB: more
+// kWaveStage hits are staged per batch of 64 events: 512 (6 KiB of LDS) for hit-dense input, 256 (3 KiB: more
 // workgroups per CU to hide the table gathers) otherwise; a batch with more hits takes the direct-store path.
 // CHARS (String overload, matcher.cr:34-39): the record's second word is the lead-byte count of the position
 // (<< 1 | "counted from the document start") instead of the byte offset; hits are char offsets.
 template <uint32_t kWaveStage, bool CHARS>
 __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
-  __shared__ uint32_t hbuf[kWaveStage * 3];
+  __shared__ __attribute__((aligned(16))) uint32_t hbuf[kWaveStage * 3 + 4];
+  __shared__ uint32_t s_excl[64], s_co[64], s_end[64];
+  const bool out16 = (reinterpret_cast<uintptr_t>(M.out) & 15u) == 0;
   if (M.cursor[1]) return;
   const int lane = threadIdx.x;
   for (uint64_t c = blockIdx.x; c < M.n_chunks; c += gridDim.x) {
@@ -895,45 +902,103 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
       const uint64_t dchunk = M.doc_off[d0] / M.S;
       lead_adj = (int32_t)(M.lead_base[c] - (M.lead_base[dchunk] + M.doc_lead_rank[d0]));
     }
+    uint2 rec_next = (uint32_t)lane < n ? reg[lane] : make_uint2(0, 0);
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
       const uint32_t i = i0 + lane;
       const bool live = i < n;
-      uint2 rec = make_uint2(0, 0);
+      uint2 rec = rec_next;
+      // the next batch's records are requested now: their HBM round trip runs beside this batch's expansion
+      rec_next = i + 64 < n ? reg[i + 64] : make_uint2(0, 0);
       uint32_t cnt = 0;
       if (live) {
-        rec = reg[i];
         cnt = rec.x >> 24;  // packed by k2d_count
-        rec.x &= 0xFFFFFFu;
-        if (cnt == 255u) cnt = A.key_cnt[rec.x];
+        rec.x &= 0xFFFFFFu;  // key id, or the offset of its flattened chain
+        if (cnt == 255u) cnt = A.key_cnt[A.chain ? A.chain[rec.x].y : rec.x];
         if (CHARS) rec.y = (rec.y >> 1) + ((rec.y & 1u) ? 0u : (uint32_t)lead_adj);  // end offset in chars
       }
       const uint32_t incl = wave_incl_scan(cnt);
       const uint32_t tot = __shfl(incl, 63, 64);
       const uint32_t off = incl - cnt;
-      if (tot <= kWaveStage) {
-        if (live) {
-          uint32_t w = off * 3;
-          int32_t k = (int32_t)rec.x;
-          do {  // fetch (ac.cr:265-278): own key, then the output chain
-            const uint2 ln = A.key_ln[k];
-            // Hit(idx-len+1, idx+1, value) ac.cr:271-273; chars: Hit(char_of_byte[start], char_of_byte[end-1]+1)
-            hbuf[w] = CHARS ? rec.y - A.key_kc[k] - 1u : rec.y - ln.x;
-            hbuf[w + 1] = rec.y;
-            hbuf[w + 2] = (uint32_t)k;
-            w += 3;
-            k = (int32_t)ln.y;
-          } while (k >= 0);
+      const uint32_t n_live = min(n - i0, 64u);
+      // Long chains (cfg 5: runs and suffix-closed families, 16 hits per event) or a batch beyond the stage: the
+      // flattened chains make every HIT addressable, so the batch is expanded by hit index -- lane h takes hits
+      // h, h + 64, ... of a window of kWaveStage hits, finds its event by a binary search over the events' exclusive
+      // hit counts (LDS) and reads chain[offset + rank in the event].  A loop per event would run as long as the
+      // wave's longest chain with most lanes idle, and a batch beyond the stage would store hit by hit.
+      // (the hit-dense instantiation only: with about one hit per event the loop per event is the cheaper one)
+      const bool by_hit = kWaveStage > 256 && A.chain && (tot >= 2 * n_live || tot > kWaveStage);
+      if (by_hit) {
+        s_excl[lane] = live ? off : tot;
+        s_co[lane] = rec.x;
+        s_end[lane] = rec.y;
+      }
+      if (by_hit || tot <= kWaveStage) {
+        for (uint32_t h0 = 0; h0 < tot; h0 += kWaveStage) {  // one window unless by_hit
+          const uint32_t nh = min(tot - h0, kWaveStage);
+          // the window is staged at the dword phase of its place in the output (hit index * 3 mod 4), so that LDS and
+          // global addresses are 16-byte aligned together and the body goes out as 16 bytes per lane
+          const uint64_t first = base + run + h0;
+          const uint32_t ph = out16 ? (uint32_t)((first * 3) & 3u) : 0u;
+          if (by_hit) {
+            __syncthreads();
+            for (uint32_t h = h0 + lane; h < h0 + nh; h += 64) {
+              uint32_t e = 0;
+#pragma unroll
+              for (uint32_t step = 32; step; step >>= 1)
+                if (s_excl[e + step] <= h) e += step;
+              const uint32_t at = s_co[e] + (h - s_excl[e]);
+              const uint2 ce = A.chain[at];
+              const uint32_t end = s_end[e];
+              const uint32_t w = ph + (h - h0) * 3;
+              // Hit(idx-len+1, idx+1, value) ac.cr:271-273; chars: Hit(char_of_byte[start], char_of_byte[end-1]+1)
+              hbuf[w] = CHARS ? end - A.chain_kc[at] : end - ce.x;
+              hbuf[w + 1] = end;
+              hbuf[w + 2] = ce.y;
+            }
+          } else if (live && A.chain) {
+            // fetch (ac.cr:265-278): own key, then the output chain -- from the flattened copy: consecutive loads
+            uint32_t w = ph + off * 3;
+            const uint32_t co = rec.x;
+            for (uint32_t j = 0; j < cnt; j++) {
+              const uint2 e = A.chain[co + j];
+              hbuf[w] = CHARS ? rec.y - A.chain_kc[co + j] : rec.y - e.x;
+              hbuf[w + 1] = rec.y;
+              hbuf[w + 2] = e.y;
+              w += 3;
+            }
+          } else if (live) {
+            uint32_t w = ph + off * 3;
+            int32_t k = (int32_t)rec.x;
+            do {
+              const uint2 ln = A.key_ln[k];
+              hbuf[w] = CHARS ? rec.y - A.key_kc[k] - 1u : rec.y - ln.x;
+              hbuf[w + 1] = rec.y;
+              hbuf[w + 2] = (uint32_t)k;
+              w += 3;
+              k = (int32_t)ln.y;
+            } while (k >= 0);
+          }
+          __syncthreads();
+          const uint64_t room = first < M.cap ? M.cap - first : 0;
+          const uint32_t nd = (uint32_t)(nh < room ? nh : room) * 3;
+          uint32_t *dst = reinterpret_cast<uint32_t *>(M.out + first);
+          if (out16 && nd >= 64) {
+            const uint32_t head = min(nd, (4u - ph) & 3u);
+            if ((uint32_t)lane < head) dst[lane] = hbuf[ph + lane];
+            const uint32_t nq = (nd - head) >> 2;
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(hbuf + ph + head);
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst + head);
+            for (uint32_t q = lane; q < nq; q += 64) d4[q] = s4[q];
+            const uint32_t done = head + (nq << 2);
+            if (done + (uint32_t)lane < nd) dst[done + lane] = hbuf[ph + done + lane];
+          } else {
+            for (uint32_t j = lane; j < nd; j += 64) dst[j] = hbuf[ph + j];
+          }
+          __syncthreads();
         }
-        __syncthreads();
-        const uint64_t first = base + run;
-        const uint64_t room = first < M.cap ? M.cap - first : 0;
-        const uint32_t nd = (uint32_t)(tot < room ? tot : room) * 3;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(M.out + first);
-        for (uint32_t j = lane; j < nd; j += 64) dst[j] = hbuf[j];
-        __syncthreads();
-      } else if (live) {
+      } else if (live) {  // a batch beyond the stage (and no expansion by hit index): hit by hit
         uint64_t idx = base + run + off;
-        int32_t k = (int32_t)rec.x;
+        int32_t k = (int32_t)(A.chain ? A.chain[rec.x].y : rec.x);
         do {
           const uint2 ln = A.key_ln[k];
           if (idx < M.cap) {
@@ -971,7 +1036,7 @@ __global__ __launch_bounds__(256) void k2d_doc_offsets(DevAut A, V2Args M) {
       for (uint32_t i = 0; i < rank; i++) {
         const uint32_t x = reg[i].x;
         const uint32_t cnt = x >> 24;
-        before += cnt == 255u ? A.key_cnt[x & 0xFFFFFFu] : cnt;
+        before += cnt == 255u ? A.key_cnt[A.chain ? A.chain[x & 0xFFFFFFu].y : (x & 0xFFFFFFu)] : cnt;
       }
       r = M.hit_base[c] + before;
     }
@@ -1150,11 +1215,11 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
                        M.totals + 1, abortf);
     hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.lead_cnt, M.n_chunks, M.blk_b, M.lead_base);
     if (M.dense_hits)
-      hipLaunchKernelGGL((k2d_expand<1024, true>), ge, dim3(64), 0, s, A, M);
+      hipLaunchKernelGGL((k2d_expand<512, true>), ge, dim3(64), 0, s, A, M);
     else
       hipLaunchKernelGGL((k2d_expand<256, true>), ge, dim3(64), 0, s, A, M);
   } else if (M.dense_hits) {
-    hipLaunchKernelGGL((k2d_expand<1024, false>), ge, dim3(64), 0, s, A, M);
+    hipLaunchKernelGGL((k2d_expand<512, false>), ge, dim3(64), 0, s, A, M);
   } else {
     hipLaunchKernelGGL((k2d_expand<256, false>), ge, dim3(64), 0, s, A, M);
   }

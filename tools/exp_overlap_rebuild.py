@@ -1,5 +1,6 @@
-"""Experiment: does the rebuild of the peers' exchange streams (7 x unpack4 of one rank's hits = what an 8-GPU step
-receives) hide under the match of the next step?  Two host threads, two streams, one GPU."""
+"""Experiment: what does an 8-GPU step cost ONE GPU in kernels -- the match of the next step beside the pack of the own
+hits and the rebuild of the seven peers' exchange streams (one launch over a segment table since round 3; pass
+--launches 7 for the round-2 form, one unpack launch per peer)?  Two host threads, two streams, one GPU."""
 import os
 import sys
 import threading
@@ -26,6 +27,8 @@ words = torch.zeros(2 * n + n // 1024 + 64, dtype=torch.int32, device=dev)
 nw = torch.zeros(1, dtype=torch.int64, device=dev)
 ac.hits_pack4_device(out, n, words, nw)
 allh = torch.zeros((8 * n, 3), dtype=torch.int32, device=dev)
+one_launch = "--launches" not in sys.argv
+nwords = None
 out2 = torch.zeros_like(out)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 K = 10
@@ -39,8 +42,11 @@ def match_loop():
 def rebuild_loop():
     for _ in range(K):
         ac.hits_pack4_device(out, n, words, nw, stream=sb.cuda_stream)
-        for p in range(1, 8):
-            ac.hits_unpack4_device(words, n, allh[p * n:(p + 1) * n], stream=sb.cuda_stream)
+        if one_launch:  # the seven peers' streams (here: seven times the own one) rebuilt by one launch
+            ac.hits_unpack4_segs_device(words, [(0, n, p * n) for p in range(1, 8)], allh, stream=sb.cuda_stream)
+        else:
+            for p in range(1, 8):
+                ac.hits_unpack4_device(words, n, allh[p * n:(p + 1) * n], stream=sb.cuda_stream)
     sb.synchronize()
 
 

@@ -20,6 +20,7 @@
 #include "automaton.hpp"
 #include "cedar_replay.hpp"
 #include "image.hpp"
+#include "unit.hpp"
 
 using namespace aha;
 
@@ -72,9 +73,16 @@ struct aha_ac {
   uint32_t v2_grid = 0;
   uint32_t v2_bpc = 1;
   uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
+  // character-level image (unit.hpp, scan_unit.hip): built for key sets of UTF-8-shaped units with mostly multi-byte
+  // characters; plain byte-offset matches through the event regions then take one step per character
+  UnitImage unit;
+  bool unit_ok = false;  // uploaded and usable on the device
+  UnitDev udev{};
+  const uint32_t *d_unit_end_info = nullptr;
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
   // match_longest only (cedar_replay.cpp): the states that carry one of Cedar's stale END flags, derived on the first
   // match_longest call (it replays every insert: as long again as the rest of compile); dev_longest = dev + the bitmap
+  std::vector<uint32_t> key_info;    // [K] flattened-chain offset | min(chain length, 255) << 24 (empty: no flat chains)
   std::vector<uint32_t> state_base;  // [n_states] base of every state in the image
   std::once_flag stale_once;
   std::vector<uint32_t> stale_states;
@@ -215,6 +223,7 @@ int32_t upload_image(aha_ac *ac, const Image &img) {
         kc.push_back(a.key_kc[j] + 1u);
       }
     }
+    ac->key_info = kinfo;
     if ((rc = upload(ac, kinfo, &d.key_info))) return rc;
     if ((rc = upload(ac, ch, &d.chain))) return rc;
     if ((rc = upload(ac, kc, &d.chain_kc))) return rc;
@@ -344,6 +353,26 @@ void v2_setup(aha_ac *ac) {
   if (reserve < 0 || reserve >= cus) reserve = 0;
   ac->v2_grid = (uint32_t)(cus - reserve) * ac->v2_bpc;
   ac->v2_ok = true;
+  // character-level engine: one step per UTF-8-shaped unit (unit.hpp).  One workgroup per CU: its LDS holds the root's
+  // transitions of the whole alphabet.
+  if (ac->unit.ok && ac->v2_bpc == 1 && unit_lds_bytes(ac->unit.n_syms) <= kLdsPerCU) {
+    const Automaton &a = ac->aut;
+    std::vector<uint32_t> info(ac->unit.end_key.size(), 0xFFFFFFFFu);
+    for (size_t i = 0; i < info.size(); i++) {
+      const int32_t k = ac->unit.end_key[i];
+      if (k >= 0) info[i] = ac->key_info.empty() ? ((uint32_t)k | (std::min<uint32_t>(a.key_cnt[k], 255u) << 24)) : ac->key_info[k];
+    }
+    const uint64_t *us = nullptr;
+    if (unit_prepare(ac->unit.n_syms) == 0 && upload(ac, ac->unit.slots, &us) == AHA_OK &&
+        upload(ac, ac->unit.root, &ac->udev.root) == AHA_OK && upload(ac, ac->unit.tables, &ac->udev.tables) == AHA_OK &&
+        upload(ac, info, &ac->d_unit_end_info) == AHA_OK) {
+      ac->udev.slots = reinterpret_cast<const uint2 *>(us);
+      ac->udev.n_slots = ac->unit.n_slots;
+      ac->udev.n_syms = ac->unit.n_syms;
+      ac->udev.max_len = a.max_key_len;
+      ac->unit_ok = true;
+    }
+  }
 }
 
 int32_t v2_reserve(aha_ac *ac, Scratch *sc, int i, size_t bytes) {
@@ -458,8 +487,16 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[0], s));
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
-  const DevAut &post = ac->dev;
-  v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+  // byte offsets through the event regions: the character-level traversal where the key set has a unit image
+  const bool unit = ac->unit_ok && direct && !M.chars;
+  DevAut post = ac->dev;
+  if (unit) {
+    post.end_info = ac->d_unit_end_info;  // events carry bases of the unit image
+    post.compact = 1;
+    unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+  } else {
+    v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+  }
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
 #ifdef AHA_DIAG
   // lab build (make diag): time the traversal alone; its timing-only variants leave nothing the post passes may read
@@ -498,7 +535,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
-    t.engine = 2;
+    t.engine = unit ? 4 : 2;
     t.chunk_bytes = M.S;
     t.n_kernels = 9;
     (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
@@ -631,6 +668,12 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   ac->s1_lo = shadow ? pl.seg_start[2] : 0;
   ac->s2_lo = shadow ? pl.seg_start[3] : 0;
   ac->s2_hi = shadow ? pl.deep_fail_start : 0;
+  {
+    // character-level image: built when the keys are UTF-8-shaped and at least 30 % of their bytes lie in multi-byte
+    // characters (AHA_ENGINE=unit forces it for every eligible key set, AHA_ENGINE=v2 / v1 never build it)
+    const char *eng = getenv("AHA_ENGINE");
+    if (!eng || strcmp(eng, "unit") == 0) build_unit(ac->aut, ac->unit, eng != nullptr);
+  }
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     int n = aha_device_count();
     if (n <= 0) {
@@ -806,6 +849,10 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->fail_s1_lo = ac->s1_lo;
   info->fail_s2_lo = ac->s2_lo;
   info->fail_hdr_lo = ac->s2_hi;
+  info->unit_enabled = ac->unit.ok ? 1u : 0u;
+  info->unit_slots = ac->unit.n_slots;
+  info->unit_syms = ac->unit.n_syms;
+  info->unit_multi_permille = ac->unit.multi_permille;
   return AHA_OK;
 }
 
@@ -859,6 +906,22 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
     case AHA_IMG_KEY_KC:
       src = a.key_kc.data();
       bytes = a.key_kc.size() * 4;
+      break;
+    case AHA_IMG_UNIT_SLOTS:
+      src = ac->unit.slots.data();
+      bytes = ac->unit.slots.size() * 8;
+      break;
+    case AHA_IMG_UNIT_ROOT:
+      src = ac->unit.root.data();
+      bytes = ac->unit.root.size() * 4;
+      break;
+    case AHA_IMG_UNIT_END_KEY:
+      src = ac->unit.end_key.data();
+      bytes = ac->unit.end_key.size() * 4;
+      break;
+    case AHA_IMG_UNIT_TABLES:
+      src = ac->unit.tables.data();
+      bytes = ac->unit.tables.size() * 4;
       break;
     case AHA_IMG_STALE_ENDS: {
       // {key id, prefix length} of every state with a stale END flag: the state is that prefix of that key

@@ -115,6 +115,19 @@ struct V2Args {
   uint64_t *doc_hit_off;
 };
 
+// ---- character-level engine (scan_unit.hip, unit.hpp) ---------------------------
+struct UnitDev {
+  const uint2 *slots;      // [n_slots] {lo, hi} entries
+  const uint32_t *root;    // [n_syms] the root's transitions by symbol
+  const uint32_t *tables;  // [kUTabWords] decode tables
+  uint32_t n_slots;
+  uint32_t n_syms;
+  uint32_t max_len;        // longest key, bytes
+};
+size_t unit_lds_bytes(uint32_t n_syms);
+int unit_prepare(uint32_t n_syms);  // raises the dynamic-LDS limit; hipError_t as int
+void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream);
+
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
 void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream);

@@ -1,0 +1,96 @@
+// unit.hpp -- the character-level ("unit") image of the same automaton (scan_unit.hip walks it).
+//
+// Why (profiles/r03_trip_anatomy.txt): the byte-level trip is bound by VALU issue -- 63 vector instructions per input
+// byte whatever the byte is.  UTF-8 text spends two of three trips inside a character, where nothing can be reported
+// and nothing can fail interestingly.  This image has one state per CHARACTER boundary and takes one step per character.
+//
+// A UNIT is what a position of the text offers as one symbol:
+//   b0 in 0x01..0x7F                                         the byte itself
+//   b0 in 0xC0..0xDF followed by one byte in 0x80..0xBF      a two-byte unit,   payload (b0 & 31) << 6 | b1 & 63
+//   b0 in 0xE0..0xEF followed by two bytes in 0x80..0xBF     a three-byte unit, payload (b0 & 15) << 12 | (b1 & 63) << 6 | b2 & 63
+//   anything else (NUL, a stray 0x80..0xBF, 0xF0.., a lead byte whose continuation bytes are missing or lie beyond
+//   the end of the document)                                 a one-byte unit that matches nothing ("bad")
+// Every byte that is not in 0x80..0xBF starts a unit, whatever precedes it.
+//
+// Eligibility: every key is a sequence of good units (valid UTF-8 up to U+FFFF always is).  Then
+//   * an occurrence of a key in ANY text starts at a byte outside 0x80..0xBF, i.e. at a unit start, and its units are
+//     segmented in the text exactly as in the key (a unit's length follows from its first byte);
+//   * a suffix of the text that is a trie path and ends at a unit boundary is therefore unit aligned, so the
+//     byte-level automaton's state at every unit boundary (src/aha/ac.cr:176-192: the longest suffix that is a trie
+//     path) is a state at a unit boundary of the keys, and its fail link -- the longest proper suffix that is a trie
+//     path -- is one as well (a suffix that starts inside a unit starts with a byte in 0x80..0xBF: no key does);
+//   * a state inside a unit ends no key, so no position inside a unit reports (ac.cr:183-185);
+//   * a bad unit reports nothing either (its byte-level states are the root or states inside a unit), and after it no
+//     trie path reaches back across it: a stray continuation byte or a byte >= 0xF0 is in no key, a lead byte without
+//     its continuation bytes is followed by a byte no key has in that place, NUL takes the reference to the root
+//     (ac.cr:188-189) -- so "state := root" gives the same states at all later unit boundaries.
+// So the automaton over units -- states = the byte-level states at unit boundaries, goto by whole units, the same
+// fail links, the same END states and output chains -- visits, at the unit boundaries, exactly the states the
+// reference visits there, and reports exactly the same hits.
+//
+// SYMBOLS.  The kernel does not walk over raw payloads but over a dense alphabet, so that the root's transitions are
+// one directly indexed LDS table: the one-byte units keep their byte (1..127; 0 = the bad unit), the two-byte payloads
+// the keys use lie in one window [c2lo, c2lo + w2) and become 129 + (payload - c2lo), the three-byte payloads in a
+// window [c3lo, c3lo + w3) become n2 + 1 + (payload - c3lo), n2 = 129 + w2.  A good unit outside its window is in no
+// key: it becomes the class's "other" symbol (128, n2), which has no transition anywhere.  A = n2 + 1 + w3 symbols.
+// Decoding is table driven (four LDS reads, a handful of adds and compares): T0[b0] gives the unit's length, where
+// to look up its second and third byte (A1, A2: the payload contribution of a valid continuation byte, a poison
+// value otherwise) and the class's first symbol and window width.
+//
+// Image: an XOR double array with unique bases over the symbols, 8-byte slots, at most 2^21 of them.  The entry that
+// leads to a state also carries where that state fails to, so a miss needs no header load:
+//   transition  lo = child base (21 bits) | low 10 bits of the child's fail base << 21 | END << 31
+//               hi = symbol (16 bits) | high 11 bits of the fail base << 16 | FFR << 27   (FFR: the fail state's own
+//                                                                                          fail link is the root)
+//   header      (same fields, symbol 0, no child)  only for a state that is some state's fail target and does not fail
+//               to the root itself: falling INTO it by a fail link is the one way to be in a state without having read
+//               the entry that leads to it
+// A fail base of 0 is the root (base 0, owns no slot).  The root's transitions: root[symbol] = child base |
+// filter << 21 | END << 31 (a depth-1 state fails to the root).  `filter` is an 8-bit Bloom filter over the symbols the
+// depth-1 state has transitions on (bit symbol & 7): most characters that follow a character do not continue a key,
+// and a clear bit answers that without the probe.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "automaton.hpp"
+
+namespace aha {
+
+constexpr uint32_t kUMaxSlots = 1u << 21;
+constexpr uint32_t kUMaxSyms = 29000;    // root table (4 bytes per symbol) + input rows + decode tables fit 160 KiB of LDS
+constexpr uint32_t kUBias = 1u << 17;    // decode sums are kept non-negative
+constexpr uint32_t kUPoison = 1u << 24;  // contribution of a byte that is not a continuation byte where one must be
+// decode tables, in 32-bit words: T0a[256] {a1 byte offset, a2 byte offset, biased base, biased first symbol},
+// T0b[256] {symbols in the class window, length}, A1[768], A2[512]
+constexpr uint32_t kUT0a = 0, kUT0b = 1024, kUA1 = 1536, kUA2 = 2304, kUTabWords = 2816;
+
+// decoding of an entry (device code and the CPU twin in tests/ use the same arithmetic)
+AHA_HD inline uint32_t u_child(uint32_t lo) { return lo & 0x1FFFFFu; }
+AHA_HD inline bool u_end(uint32_t lo) { return (lo >> 31) != 0; }
+AHA_HD inline uint32_t u_sym(uint32_t hi) { return hi & 0xFFFFu; }
+AHA_HD inline uint32_t u_fail(uint32_t lo, uint32_t hi) { return ((lo >> 21) & 0x3FFu) | (((hi >> 16) & 0x7FFu) << 10); }
+AHA_HD inline bool u_ffr(uint32_t hi) { return ((hi >> 27) & 1u) != 0; }
+AHA_HD inline uint32_t u_filter(uint32_t root_entry) { return (root_entry >> 21) & 0xFFu; }
+
+struct UnitImage {
+  bool ok = false;
+  const char *why = "";
+  uint32_t n_slots = 0;             // a multiple of 2^16 (a base and base ^ symbol share a block of 2^16 slots)
+  std::vector<uint64_t> slots;      // [n_slots]
+  std::vector<int32_t> end_key;     // [n_slots] key id at the base of an END state, else -1
+  std::vector<uint32_t> root;       // [n_syms]
+  std::vector<uint32_t> tables;     // [kUTabWords] decode tables
+  uint32_t n_syms = 0;              // A
+  uint32_t n1 = 128, n2 = 0;        // "other" symbols of the two- and three-byte classes (0 is the bad unit)
+  uint32_t c2lo = 0, w2 = 0, c3lo = 0, w3 = 0;
+  uint32_t n_states = 0, n_trans = 0, n_headers = 0;
+  uint32_t multi_permille = 0;      // share of the key bytes that lie in two- and three-byte units
+};
+
+// a: the byte-level automaton (build_automaton).  Fills u; u.ok = false + u.why when the key set is not eligible or
+// (unless `force`) mostly made of one-byte units.
+void build_unit(const Automaton &a, UnitImage &u, bool force = false);
+
+}  // namespace aha

@@ -110,6 +110,13 @@ typedef struct {
   uint32_t fail_s2_lo;
   uint32_t fail_hdr_lo;
   uint32_t reserved;
+  /* Character-level image (aha_amd/csrc/unit.hpp), built when every key is a sequence of UTF-8-shaped units, at least
+   * 30 % of the key bytes lie in multi-byte characters and the keys' characters fit the symbol table: plain
+   * byte-offset matches then take one step per character instead of one per byte (bit-exact; aha_timing.engine = 4). */
+  uint32_t unit_enabled;
+  uint32_t unit_slots;          /* 8-byte slots of its double array */
+  uint32_t unit_syms;           /* symbols of its dense alphabet (the root's transitions: 4 bytes each, in LDS) */
+  uint32_t unit_multi_permille; /* key bytes in multi-byte units, per 1000 */
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded
@@ -124,7 +131,7 @@ typedef struct {
   float ms_aux;             /* engine 2: hits per chunk + scan (regions) or event sort (slabs); engine 1: char-offset prefix pass */
   uint64_t n_chunks;
   uint64_t n_hits;
-  uint32_t engine;          /* 2 = single-traversal engine, 1 = two-pass engine */
+  uint32_t engine;          /* 4 = character-level traversal, 2 = single-traversal engine, 1 = two-pass engine */
   uint32_t chunk_bytes;     /* bytes per lane chunk */
 } aha_timing;
 
@@ -218,6 +225,10 @@ enum {
   AHA_IMG_KEY_LN = 2,  /* {uint32 len, int32 next}[K] */
   AHA_IMG_KEY_CNT = 3, /* uint32[K] */
   AHA_IMG_KEY_KC = 4,  /* uint32[K] */
+  AHA_IMG_UNIT_SLOTS = 6,     /* uint64[unit_slots]: lo = child base | fail low << 21 | END << 31, hi = symbol | ... (unit.hpp) */
+  AHA_IMG_UNIT_ROOT = 7,      /* uint32[unit_syms]: the root's transitions by symbol */
+  AHA_IMG_UNIT_END_KEY = 8,   /* int32[unit_slots]: key id at the base of an END state, else -1 */
+  AHA_IMG_UNIT_TABLES = 9,    /* uint32[2816]: the decode tables (unit.hpp, SYMBOLS) */
   AHA_IMG_STALE_ENDS = 5     /* {uint32 key id, uint32 prefix length}[]: the states (a prefix of a key each) whose node in
                                  the reference's Cedar keeps a stale END flag (src/aha/cedar.cr:642-648); match_longest
                                  treats them as ends that yield nothing (src/aha/ac.cr:126-128, 249-263) */

@@ -17,13 +17,16 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1", "v2p"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2p", "u"], autouse=True)
 def engine(request, monkeypatch):
-    """Every parity test runs on the single-traversal engine (scan_v2.hip, the default), on the two-pass engine
-    (kernels.hip: the fallback for tiny capacities and very long keys) and on the single-traversal engine with its LDS
+    """Every parity test runs on the single-traversal engine (scan_v2.hip, byte level), on the two-pass engine
+    (kernels.hip: the fallback for tiny capacities and very long keys), on the single-traversal engine with its LDS
     prefix capped at 1024 slots ("v2p": small automata then also take the partial-prefix kernel with the shadow fail
-    links and the HBM probe path).  The variables are read when a handle is compiled."""
-    monkeypatch.setenv("AHA_ENGINE", "v1" if request.param == "v1" else "v2")
+    links and the HBM probe path) and on the character-level engine ("u", scan_unit.hip: AHA_ENGINE=unit builds the
+    unit image for every eligible key set, also the mostly-ASCII ones that would not get one by default; byte-offset
+    calls through the event regions then run it, everything else the single-traversal engine).  Without the variable
+    the library decides per key set (bench.py runs that way).  The variables are read when a handle is compiled."""
+    monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit"}.get(request.param, "v2"))
     if request.param == "v2p":
         monkeypatch.setenv("AHA_LDS_SLOTS", "1024")
     else:
@@ -424,16 +427,29 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
     assert g.match_batch_device(big[1:1 + corpus.size], dd, out) == n  # scratch grows back
 
 
-def test_engine_selected(engine):
+def test_engine_selected(engine, monkeypatch):
     ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine == "u" else (2,))
     ac = AC.compile(["ab", "ba"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"ab ba " * 60))[:3] == [(0, 2, 0), (3, 5, 1), (6, 8, 0)]
-    assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
-    # char offsets and the separator filter run on the same engine
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine == "u" else (2,))
+    if engine == "u":
+        # the library's own choice (no AHA_ENGINE): keys of multi-byte characters get the character-level traversal for
+        # byte-offset batches, ASCII keys and char offsets keep the byte-level one
+        monkeypatch.delenv("AHA_ENGINE", raising=False)
+        cjk = AC.compile(["中国", "国人", "人"])
+        cjk.set_profiling(True)
+        text = "中国人民" * 3000
+        hits, _ = cjk.match_batch(np.frombuffer(text.encode(), dtype=np.uint8), np.array([0, len(text.encode())], dtype=np.uint64))
+        assert cjk.info["unit_enabled"] == 1 and cjk.last_timing()["engine"] == 4 and len(hits) == 9000
+        asc = AC.compile(["abc", "bcd"])
+        asc.set_profiling(True)
+        asc.match_array(b"abcd" * 3000)
+        assert asc.info["unit_enabled"] == 0 and asc.last_timing()["engine"] == 2
+    # char offsets and the separator filter run on the byte-level engines
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
     assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
 
@@ -484,6 +500,36 @@ def test_long_and_nested_keys():
     o = orc.AC.compile(keys)
     text = b"".join(rng.choice([w, v, b"x" + w, keys[16], keys[17], b"ab", b" ", v[2:] + b"#"]) for _ in range(600))
     assert gpu_list(g.match_array(text)) == as_list(o.match(text))
+
+
+def test_malformed_utf8_and_ragged_units(engine):
+    """Text that is NOT valid UTF-8 around keys that are: truncated characters, stray continuation bytes, bytes >= 0xF0,
+    NUL, characters outside the keys' alphabet, documents that start or end inside a character, characters that
+    straddle the 32-byte pieces and the chunk boundaries.  The character-level traversal must see exactly what the
+    byte-level automaton sees (unit.hpp); the other engines run the same batch."""
+    rng = random.Random(31)
+    chars = ["a", "b", "é", "ж", "я", "中", "国", "人", "我", "是", "々", " "]
+    keys = sorted({"".join(rng.choice(chars[:-1]) for _ in range(rng.randint(1, 5))) for _ in range(300)})
+    g = AC.compile(keys)
+    o = orc.AC.compile(keys)
+    junk = [b"\xe4", b"\xe4\xb8", b"\xb8", b"\xad\xad", b"\xf0\x9f\x98\x80", b"\x00", b"\xc3", b"\xff", b"\xe4\xe4\xb8\xad",
+            "€".encode(), "\uffee".encode(), "\u0100".encode()]
+    docs = []
+    for _ in range(60):
+        parts = []
+        for _ in range(rng.choice([0, 1, 3, 40, 400, 3000])):
+            r = rng.random()
+            parts.append(rng.choice(keys).encode() if r < 0.3 else rng.choice(chars).encode() if r < 0.85
+                         else rng.choice(junk))
+        d = b"".join(parts)
+        cut = rng.randint(0, 2)  # some documents lose their first / last bytes: they start or end inside a character
+        docs.append(d[cut:len(d) - rng.randint(0, 2)] if len(d) > 6 else d)
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+    corpus = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    gh, gd = g.match_batch(corpus, offs)
+    oh, od = o.match_batch(corpus, offs, cap=len(gh) + 16)
+    assert np.array_equal(gd, od)
+    assert gh.tobytes() == oh.tobytes()
 
 
 def test_device_resident_entry_point():
@@ -555,8 +601,8 @@ def test_full_size_properties(cfg, engine):
     properties instead of a full oracle run -- ordering, every hit spells its
     key, document independence (any split of the batch gives the same hits),
     engine agreement by checksum -- plus the oracle on a sample of documents."""
-    if engine != "v2":
-        pytest.skip("full-size run: the default engine")
+    if engine not in ("v2", "u"):
+        pytest.skip("full-size run: the byte-level and the character-level traversal")
     import hashlib
 
     import torch
@@ -655,8 +701,8 @@ def test_single_large_document_vs_oracle(engine):
     """SURVEY 8d single-document variant: one 256 MiB document, so every chunk
     but the first starts in the middle of a sequence (warm-up overlap at scale).
     Full comparison with the oracle."""
-    if engine != "v2":
-        pytest.skip("once, on the default engine")
+    if engine not in ("v2", "u"):
+        pytest.skip("the byte-level and the character-level traversal")
     import torch
 
     blob, offs, nf = synth.keys(3)

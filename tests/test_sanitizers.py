@@ -35,7 +35,7 @@ def test_host_side_under_asan_ubsan():
         "AHA_ORACLE_LIB": os.path.join(ROOT, "oracle", "libaha_oracle_asan.so"),
     })
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
-           os.path.join(ROOT, "tests", "test_host_logic.py"),
+           os.path.join(ROOT, "tests", "test_host_logic.py"), os.path.join(ROOT, "tests", "test_unit_twin.py"),
            os.path.join(ROOT, "tests", "test_oracle_kats.py"), os.path.join(ROOT, "tests", "test_oracle_vs_model.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]

@@ -1,0 +1,91 @@
+"""The character-level image (aha_amd/csrc/unit.hpp) against the oracle, on the CPU: the image is built by the
+library (host only), walked by tests/unitsim.py the way scan_unit.hip walks it."""
+import random
+
+import numpy as np
+import pytest
+
+import pyoracle as orc
+from aha_amd import AC
+from test_oracle_vs_model import as_list
+from unitsim import UnitSim
+
+CHARS = ["a", "b", "c", "é", "ж", "я", "中", "国", "人", "我", "是", "々", " "]
+
+
+def rand_word(rng, lo, hi, chars=CHARS[:-1]):
+    return "".join(rng.choice(chars) for _ in range(rng.randint(lo, hi)))
+
+
+def compile_unit(keys, monkeypatch):
+    monkeypatch.setenv("AHA_ENGINE", "unit")  # also below 30 % multi-byte units
+    return AC.compile(keys, host_only=True)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_unit_image_matches_the_oracle(seed, monkeypatch):
+    rng = random.Random(seed)
+    keys = sorted({rand_word(rng, 1, rng.choice([2, 4, 7])) for _ in range(rng.choice([3, 40, 400]))})
+    ac = compile_unit(keys, monkeypatch)
+    assert ac.info["unit_enabled"] == 1
+    sim = UnitSim(ac)
+    o = orc.AC.compile(keys)
+    for _ in range(6):
+        parts = []
+        for _ in range(rng.randint(0, 120)):
+            r = rng.random()
+            if r < 0.35:
+                parts.append(rng.choice(keys).encode())
+            elif r < 0.8:
+                parts.append(rng.choice(CHARS).encode())
+            elif r < 0.9:  # malformed: truncated characters, stray continuation bytes, bytes >= 0xF0, NUL
+                parts.append(rng.choice([b"\xe4", b"\xe4\xb8", b"\xb8", b"\xad\xad", b"\xf0\x9f\x98\x80", b"\x00", b"\xc3",
+                                         b"\xff", b"\xe4\xe4\xb8\xad"]))
+            else:
+                parts.append(bytes([rng.randrange(1, 256)]))
+        text = b"".join(parts)
+        assert sim.match(text) == as_list(o.match(text)), (keys, text)
+
+
+def test_unit_image_reference_kat(monkeypatch):
+    ac = compile_unit(["我", "我是", "是中"], monkeypatch)  # spec/ac_spec.cr:5-12
+    assert [(e, v) for _, e, v in UnitSim(ac).match("我是中国人".encode())] == [(3, 0), (6, 1), (9, 2)]
+
+
+def test_truncated_character_at_the_end_of_a_document(monkeypatch):
+    keys = ["中", "中国", "a"]
+    ac = compile_unit(keys, monkeypatch)
+    o = orc.AC.compile(keys)
+    sim = UnitSim(ac)
+    for text in (b"\xe4\xb8", "中".encode()[:2] + b"a", "a中国".encode()[:-1], "中国".encode() + b"\xe5\x9b", b"\xe4"):
+        assert sim.match(text) == as_list(o.match(text))
+
+
+@pytest.mark.parametrize("keys,why", [
+    ([b"\xe4\xb8"], "ends inside"), ([b"a\xb8"], "stray"), ([b"\xf0\x9f\x98\x80"], "0xF0"), ([b"\xe4a"], "without"),
+])
+def test_ineligible_key_sets_keep_the_byte_level_engines(keys, why, monkeypatch):
+    monkeypatch.setenv("AHA_ENGINE", "unit")
+    ac = AC.compile(keys, host_only=True)
+    assert ac.info["unit_enabled"] == 0
+
+
+def test_when_the_image_is_built(monkeypatch):
+    monkeypatch.delenv("AHA_ENGINE", raising=False)
+    assert AC.compile(["中", "中国"], host_only=True).info["unit_enabled"] == 1       # multi-byte characters: built
+    assert AC.compile(["ab", "abcd", "bcdef", "é"], host_only=True).info["unit_enabled"] == 0    # mostly one-byte units: not
+    monkeypatch.setenv("AHA_ENGINE", "v2")
+    assert AC.compile(["中", "中国"], host_only=True).info["unit_enabled"] == 0       # the byte-level engine by request
+    monkeypatch.setenv("AHA_ENGINE", "unit")
+    # characters from both ends of the Basic Multilingual Plane: more symbols than the root table holds in LDS
+    assert AC.compile(["\u0800a", "\uffeeb"], host_only=True).info["unit_enabled"] == 0
+
+
+def test_fewer_steps_than_bytes(monkeypatch):
+    rng = random.Random(5)
+    keys = sorted({rand_word(rng, 2, 5, CHARS[6:12]) for _ in range(300)})
+    ac = compile_unit(keys, monkeypatch)
+    sim = UnitSim(ac)
+    text = "".join(rng.choice(CHARS[6:12]) for _ in range(3000)).encode()
+    assert sim.match(text) == as_list(orc.AC.compile(keys).match(text))
+    assert sim.trips < len(text) * 0.7  # 3000 characters, a tiny alphabet: many retries from fail states

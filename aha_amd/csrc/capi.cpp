@@ -365,9 +365,11 @@ void v2_setup(aha_ac *ac) {
     const uint64_t *us = nullptr;
     if (unit_prepare(ac->unit.n_syms) == 0 && upload(ac, ac->unit.slots, &us) == AHA_OK &&
         upload(ac, ac->unit.root, &ac->udev.root) == AHA_OK && upload(ac, ac->unit.tables, &ac->udev.tables) == AHA_OK &&
+        upload(ac, ac->unit.fail_tab, &ac->udev.fail_tab) == AHA_OK &&
         upload(ac, info, &ac->d_unit_end_info) == AHA_OK) {
       ac->udev.slots = reinterpret_cast<const uint2 *>(us);
       ac->udev.n_slots = ac->unit.n_slots;
+      ac->udev.n_shared = ac->unit.n_shared;
       ac->udev.n_syms = ac->unit.n_syms;
       ac->udev.max_len = a.max_key_len;
       ac->unit_ok = true;
@@ -673,6 +675,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     // characters (AHA_ENGINE=unit forces it for every eligible key set, AHA_ENGINE=v2 / v1 never build it)
     const char *eng = getenv("AHA_ENGINE");
     if (!eng || strcmp(eng, "unit") == 0) build_unit(ac->aut, ac->unit, eng != nullptr);
+    if (getenv("AHA_DEBUG") && !ac->unit.ok) fprintf(stderr, "aha: no character-level image: %s\n", ac->unit.why);
   }
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     int n = aha_device_count();
@@ -918,6 +921,10 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
     case AHA_IMG_UNIT_END_KEY:
       src = ac->unit.end_key.data();
       bytes = ac->unit.end_key.size() * 4;
+      break;
+    case AHA_IMG_UNIT_FAIL:
+      src = ac->unit.fail_tab.data();
+      bytes = ac->unit.fail_tab.size() * 4;
       break;
     case AHA_IMG_UNIT_TABLES:
       src = ac->unit.tables.data();

@@ -119,8 +119,10 @@ struct V2Args {
 struct UnitDev {
   const uint2 *slots;      // [n_slots] {lo, hi} entries
   const uint32_t *root;    // [n_syms] the root's transitions by symbol
+  const uint32_t *fail_tab;  // [n_slots] the word of the fail state, at the base of a state whose fail link is not the root
   const uint32_t *tables;  // [kUTabWords] decode tables
   uint32_t n_slots;
+  uint32_t n_shared;       // slots of the shared XOR array (states with a region of their own have bases beyond it)
   uint32_t n_syms;
   uint32_t max_len;        // longest key, bytes
 };

@@ -11,8 +11,8 @@
 // table over that alphabet, and an 8-bit filter in the root entry answers most "does the character after this one
 // continue a key" questions without a probe (0.2 probes per byte leave LDS instead of 0.5).
 //
-// LDS: the root's transitions (4 bytes per symbol) + the decode tables (11 KiB) + a wave-private input window (32
-// bytes + the last 4 bytes of the previous piece per lane, rows of 9 dwords: odd stride, no bank conflicts).
+// LDS: the root's transitions (4 bytes per symbol) + the decode tables (11 KiB) + a wave-private input window (three
+// 16-byte pieces + the last 4 bytes before them per lane, rows of 13 dwords: odd stride, no bank conflicts).
 // Everything else is probed in HBM/L2, 8 bytes per probe.
 #include <hip/hip_runtime.h>
 
@@ -25,9 +25,13 @@ namespace aha {
 
 namespace {
 
-constexpr int kUPiece = 32;         // input bytes staged per lane per round (64-byte rounds with a 3-byte root table were
-                                    // measured too: 3 % faster, but the table needs its fourth byte for the filter)
-constexpr int kURow = kUPiece + 4;  // bytes per lane in the LDS input window (9 dwords: odd stride)
+// Input window of a lane: the last 4 bytes before it + three pieces of 16 bytes.  A round appends one piece and ends as
+// soon as EVERY lane of the wave has left the oldest one, so a lane may run up to two pieces ahead of the slowest:
+// characters have different lengths, and with one piece per round (the lanes of a wave in step at every piece) a
+// wave ran 66 % of its lane-trips usefully on the cfg 3 mix; with this window 90 % (simulated, and measured).
+constexpr int kUPiece = 16;
+constexpr int kUWin = 3 * kUPiece;
+constexpr int kURow = kUWin + 4;    // bytes per lane in LDS (13 dwords: odd stride, no bank conflicts)
 constexpr int kUWave = 64 * kURow;
 
 // 16 text bytes at g (any alignment of the corpus end; the corpus itself is 16-byte aligned, g is a multiple of 16)
@@ -78,12 +82,10 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
     const int64_t e = live ? min(a + S, N) : a;
     uint64_t dn = 0;
     int64_t nb = INT64_MAX, doc_start = a, pos = e;
-    uint32_t B = 0, fb = 0, seq = 0;  // state (0 = root), its fail state
-    uint32_t flt = 0xFFu;             // filter of the state's transitions (0xFF: none known, probe)
-    bool ffr = true;                  // the fail state's own fail link is the root
-    uint4 half[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};  // second half of the current input line
-    int64_t half_pb = INT64_MIN;                                       // the piece `half` holds
-    uint32_t tail = 0;  // last four bytes of the piece staged in the previous round
+    uint32_t E = 0, seq = 0;  // the state as one word (unit.hpp): base | filter << 22 | F1 | NFR | END; 0 = the root
+    uint32_t pc = 0;          // the symbol that led to it
+    uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1, q3 = q1;  // the rest of the input line whose first piece was staged last
+    uint32_t w[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // the window's bytes (the LDS row is rewritten from them)
     if (live) {
       dn = first_boundary(M.doc_off, D, (uint64_t)a);
       nb = (int64_t)M.doc_off[dn];
@@ -94,51 +96,51 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
       }
     }
 
-    // one round beyond the chunk: a unit that starts in the last bytes of the chunk and continues in the next one
-    for (int r = -R; r <= rounds; r++) {
+    // Round r: the window holds the pieces r, r + 1, r + 2 of the lane's chunk (piece r + 2 is loaded now; the walk
+    // starts in piece -R, which the first round loads).  One round beyond the chunk: a unit that starts in the last
+    // bytes of the chunk continues in the next one.
+    // (the first piece loaded starts a 64-byte line, so that the line queue below is filled: R is rounded up to whole lines)
+    for (int r = -((R + 3) / 4) * 4 - 2; r <= rounds; r++) {
       const int64_t pb = a + (int64_t)r * kUPiece;
-      const int64_t pend = min(pb + kUPiece, e);
+      const int64_t pl = pb + 2 * kUPiece;  // the piece loaded in this round
+      const int64_t pend = min(pb + kUWin, e);
+      {
+        // a 64-byte line is four pieces: the round that starts a line loads all of it (three pieces wait in registers),
+        // so every input line is requested once while it is in flight.  Chunk starts are multiples of 64: uniform.
+        uint4 v;
+        if ((pl & 63) == 0) {
+          v = load16(M.text, pl, N);
+          q1 = load16(M.text, pl + 16, N);
+          q2 = load16(M.text, pl + 32, N);
+          q3 = load16(M.text, pl + 48, N);
+        } else {
+          v = q1;
+          q1 = q2;
+          q2 = q3;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) w[i] = w[i + 4];
+        w[9] = v.x;
+        w[10] = v.y;
+        w[11] = v.z;
+        w[12] = v.w;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(inl);
+#pragma unroll
+        for (int i = 0; i < 13; i++) dst[i] = w[i];
+      }
       const bool need = live && pos < pend;
       if (!__any(need)) continue;
-      // Row = the last 4 bytes of the previous piece + this piece: a unit whose bytes are not all here yet is left for
-      // the next round (the lane parks), so no byte is requested ahead of its round.
-      uint32_t rel = kURow, lim = 0;  // row coordinates: text position = pb - 4 + rel; inactive: rel >= lim
+      // row coordinates: text position = pb - 4 + rel; inactive: rel >= lim; a unit whose bytes are not all in the
+      // window yet is left for a later round (the lane parks)
+      uint32_t rel = kURow, lim = 0;
       if (need) {
-        // a piece is half a 64-byte line: the round that starts a line also loads its second half into registers,
-        // so both halves are requested while the line is in flight and every input line is fetched once
-        const bool line_start = (pb & 63) == 0;
-        uint4 v0, v1;
-        if (!line_start && half_pb == pb) {
-          v0 = half[0];
-          v1 = half[1];
-        } else {
-          v0 = load16(M.text, pb, N);
-          v1 = load16(M.text, pb + 16, N);
-        }
-        half_pb = INT64_MIN;
-        if (line_start && pb >= 0 && pb + 2 * kUPiece <= N && pb + kUPiece < e) {
-          half[0] = *reinterpret_cast<const uint4 *>(M.text + pb + kUPiece);
-          half[1] = *reinterpret_cast<const uint4 *>(M.text + pb + kUPiece + 16);
-          half_pb = pb + kUPiece;
-        }
-        uint32_t *dst = reinterpret_cast<uint32_t *>(inl);
-        dst[0] = tail;
-        dst[1] = v0.x;
-        dst[2] = v0.y;
-        dst[3] = v0.z;
-        dst[4] = v0.w;
-        dst[5] = v1.x;
-        dst[6] = v1.y;
-        dst[7] = v1.z;
-        dst[8] = v1.w;
-        tail = v1.w;
         rel = (uint32_t)(pos - pb + 4);
         lim = (uint32_t)(pend - pb + 4);  // units that START before pend
       }
       // limits in row coordinates: the next document boundary (when the row shows it), the end of the text, the
       // range of end positions this lane reports ([a, e): a unit that ends in the next chunk is that chunk's)
-      uint32_t nb_rel = (nb >= pb - 4 && nb <= pb + kUPiece) ? (uint32_t)(nb - pb + 4) : ~0u;
-      const uint32_t n_rel = (N - pb) <= (int64_t)kUPiece ? (uint32_t)max<int64_t>(N - pb + 4, 0) : ~0u;
+      uint32_t nb_rel = (nb >= pb - 4 && nb <= pb + kUWin) ? (uint32_t)(nb - pb + 4) : ~0u;
+      const uint32_t n_rel = (N - pb) <= (int64_t)kUWin ? (uint32_t)max<int64_t>(N - pb + 4, 0) : ~0u;
       const int32_t a_rel = (int32_t)max<int64_t>(a - pb + 4, -128);
       const int32_t e_rel = (int32_t)min<int64_t>(e - pb + 4, 128);
       int32_t docrel = (int32_t)(pb - 4 - doc_start);  // end offset in the document = docrel + rel (after the unit)
@@ -154,92 +156,111 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
               nb = dn <= D ? (int64_t)M.doc_off[dn] : INT64_MAX;
             } while (nb == here);
             asm volatile("" : "+v"(nb));  // retire the load inside this block
-            nb_rel = (nb <= pb + kUPiece) ? (uint32_t)(nb - pb + 4) : ~0u;
-            B = 0;
-            fb = 0;
-            ffr = true;
-            flt = 0xFFu;
+            nb_rel = (nb <= pb + kUWin) ? (uint32_t)(nb - pb + 4) : ~0u;
+            E = 0;
+            pc = 0;
             doc_start = here;
             docrel = -(int32_t)rel;
           }
         }
         uint32_t lim2 = min(lim, nb_rel);          // lanes park at the next boundary
         const uint32_t dend = min(nb_rel, n_rel);  // first byte that is not this document's
+        // The unit at row position `at` (unit.hpp): table-driven decode -- the first byte tells the length the unit
+        // would have, where its second and third byte are looked up (a poison value unless they are continuation
+        // bytes) and the window of its class; the sum is the symbol when it falls into that window.  Three dependent
+        // LDS reads: the hot loop decodes the NEXT unit while the current one is probed, so they are off its chain.
+        auto decode = [&](uint32_t at, uint32_t &o_code, uint32_t &o_L, bool &o_good, bool &o_later) {
+          const uint32_t lo = row[at >> 2], hi = row[(at >> 2) + 1];
+          const uint32_t w4 = __builtin_amdgcn_alignbyte(hi, lo, at & 3u);
+          const uint32_t b0 = w4 & 0xFFu;
+          const uint4 q0 = t0a[b0];
+          const uint2 q1 = t0b[b0];
+          const uint32_t s1 = *reinterpret_cast<const uint32_t *>(tabb + q0.x + ((w4 >> 6) & 0x3FCu));
+          const uint32_t s2 = *reinterpret_cast<const uint32_t *>(tabb + q0.y + ((w4 >> 14) & 0x3FCu));
+          const uint32_t sum = q0.z + s1 + s2;
+          const uint32_t want = q1.y;                 // bytes the first byte announces
+          const bool in_doc = at + want <= dend;      // else: a lead byte without its continuation bytes (bad)
+          o_later = in_doc & at + want > (uint32_t)kURow;  // its bytes are not all staged yet: next round
+          const bool whole = in_doc & sum < kUPoison;  // a well-formed unit
+          o_good = whole & (sum - q0.w) < q1.x;        // ... of the keys' alphabet
+          o_L = whole ? want : 1u;
+          o_code = o_good ? sum - kUBias : 0u;         // symbol 0 has no transition anywhere
+        };
+        uint32_t code, L;
+        bool good, later;
+        decode(min(rel, (uint32_t)kURow), code, L, good, later);
+        bool all_left = false;  // every lane has left the oldest piece (or has nothing more to do): next round
         for (;;) {
           const bool act = rel < lim2;
-          if (!__any(act)) break;
+          all_left = __all(rel >= (uint32_t)(4 + kUPiece) || rel >= lim);
+          if (all_left || !__any(act)) break;
           bool ev = false;
           if (act) {
-            // ---- the unit at rel (unit.hpp).  Every select below picks between values that are already computed
-            // (plain locals): that keeps them v_cndmask instead of nested divergent branches, which cost more than
-            // the work they skip.
-            const uint32_t lo = row[rel >> 2], hi = row[(rel >> 2) + 1];
-            const uint32_t w4 = __builtin_amdgcn_alignbyte(hi, lo, rel & 3u);
-            // table-driven decode (unit.hpp, SYMBOLS): the first byte tells the length the unit would have, where its
-            // second and third byte are looked up (a poison value unless they are continuation bytes) and the window
-            // of its class; the sum is the symbol when it falls into that window
-            const uint32_t b0 = w4 & 0xFFu;
-            const uint4 q0 = t0a[b0];
-            const uint2 q1 = t0b[b0];
-            const uint32_t s1 = *reinterpret_cast<const uint32_t *>(tabb + q0.x + ((w4 >> 6) & 0x3FCu));
-            const uint32_t s2 = *reinterpret_cast<const uint32_t *>(tabb + q0.y + ((w4 >> 14) & 0x3FCu));
-            const uint32_t sum = q0.z + s1 + s2;
-            const uint32_t want = q1.y;                  // bytes the first byte announces
-            const bool in_doc = rel + want <= dend;      // else: a lead byte without its continuation bytes (bad)
-            const bool later = in_doc & rel + want > (uint32_t)kURow;  // its bytes are not all staged yet: next round
-            const bool whole = in_doc & sum < kUPoison;  // a well-formed unit
-            const bool good = whole & (sum - q0.w) < q1.x;  // ... of the keys' alphabet
-            const uint32_t L = whole ? want : 1u;
-            const uint32_t code = good ? sum - kUBias : 0u;  // symbol 0 has no transition anywhere
-            // ---- the root's transition on it (LDS)
+            uint32_t n_code, n_L;
+            bool n_good, n_later;
+            decode(rel + L, n_code, n_L, n_good, n_later);  // rows are padded: rel + 3 + 8 bytes stay inside LDS
+            // Every select below picks between values that are already computed (plain locals): that keeps them
+            // v_cndmask instead of nested divergent branches, which cost more than the work they skip.
+            // ---- the root's transitions (LDS) on the unit (symbol 0 -- a bad unit or one outside the alphabet -- has
+            // none) and on the symbol that led to the current state: the one-character state a two-character state
+            // fails to
             const uint32_t rt = rl[code];
-            // ---- the state's own transition: one 8-byte probe
-            // a depth-1 state brought a filter over the codes it continues on: a clear bit is a miss without the probe
-            const bool probe = B != 0u & good & !later & ((flt >> (code & 7u)) & 1u) != 0u;
-            const uint32_t pidx = B ^ code;
-            const uint2 en = slots[probe ? pidx : 0u];
+            const uint32_t rf = rl[pc];
+            // ---- the state's own transition: at most one 8-byte probe.  The state word carries a filter over the
+            // symbols the state continues on: a clear bit is a miss without the probe (the root's word is 0)
+            const uint32_t Bq = u_child(E);
+#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 2  // timing only: states with a region of their own are never probed
+            const bool probe = good & !later & ((u_filter(E) >> (code & 7u)) & 1u) != 0u & Bq != 0u & Bq < U.n_shared;
+#elif defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 4  // timing only: no probe at all
+            const bool probe = false;
+#else
+            const bool probe = good & !later & ((u_filter(E) >> (code & 7u)) & 1u) != 0u & Bq != 0u;
+#endif
+            const uint2 en = slots[probe ? (Bq ^ code) : 0u];
             const bool hit = probe & u_sym(en.y) == code;
-            // the fail link is the root (or the unit takes the state to the root): the root's table answers
-            const bool viaroot = !hit & !later & (!good | B == 0u | fb == 0u);
-            const bool fall = !hit & !viaroot & !later;  // continue in the fail state, the unit is tried again there
-            const bool needh = fall & !ffr;
-            uint2 hd = make_uint2(0, 0);
-            if (__any(needh)) hd = slots[needh ? fb : 0u];  // rare: the fail state's header says where IT fails to
-            const bool keep0 = viaroot | ffr;  // (on a miss) the new fail state is the root
-            const uint32_t en_child = u_child(en.x), en_fail = u_fail(en.x, en.y);
-            const uint32_t hd_fail = u_fail(hd.x, hd.y);
-            const uint32_t rt_child = good ? u_child(rt) : 0u;
-            const bool en_ffr = u_ffr(en.y), hd_ffr = u_ffr(hd.y), en_end = u_end(en.x), rt_end = good & u_end(rt);
-            const uint32_t missB = viaroot ? rt_child : fb;
-            const uint32_t missF = keep0 ? 0u : hd_fail;
-            const bool missR = keep0 | hd_ffr;
-            const bool missE = viaroot & rt_end;
-            const uint32_t newB = hit ? en_child : missB;
-            const uint32_t newF = hit ? en_fail : missF;
-            const bool newR = hit ? en_ffr : missR;
-            const uint32_t rt_flt = u_filter(rt);
-            const uint32_t missT = viaroot ? rt_flt : 0xFFu;
-            const uint32_t newT = hit ? 0xFFu : missT;
-            flt = later ? flt : newT;
-            B = later ? B : newB;
-            fb = later ? fb : newF;
-            ffr = later ? ffr : newR;
-            const bool end = hit ? en_end : missE;
+            // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip;
+            // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or -- rare -- the
+            // side array in HBM
+#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 1  // timing only: every miss is answered by the root (no fall path)
+            const bool viaroot = !hit & !later;
+#else
+            const bool viaroot = !hit & !later & (!u_nfr(E) | !good);
+#endif
+            const bool fall = !hit & !viaroot & !later;
+            const bool fall_far = fall & !u_f1(E);
+            uint32_t ft = rf & 0x7FFFFFFFu;  // (falling into a state reports nothing: END is not carried)
+            if (__any(fall_far)) {
+              const uint32_t fx = U.fail_tab[fall_far ? Bq : 0u];
+              ft = fall_far ? fx : ft;
+            }
+            const uint32_t missE = viaroot ? rt : ft;
+            const uint32_t newE = hit ? en.x : missE;
+            E = later ? E : newE;
             const bool consumed = hit | viaroot;
+            const bool end = consumed & u_end(newE);
+            pc = consumed ? code : pc;
             const uint32_t adv = consumed ? L : 0u;
             rel += adv;
             lim2 = later ? rel : lim2;  // parked until the next round brings the rest of the unit
             lim = later ? rel : lim;
+            code = consumed ? n_code : code;  // (a trip that falls to the fail state tries the same unit again)
+            L = consumed ? n_L : L;
+            good = consumed ? n_good : good;
+            later = consumed ? n_later : later;
             const int32_t last = (int32_t)rel - 1;  // row index of the unit's last byte
             // is_end? -> fetch later (ac.cr:183-185); this lane reports the end positions in [a, e)
-            ev = consumed & end & last >= a_rel & last < e_rel;
+            ev = end & last >= a_rel & last < e_rel;
           }
           if (__any(ev)) {
             if (ev) {
               if (seq < ev_stride) {
                 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-                const v2u rec = {B, (uint32_t)(docrel + (int32_t)rel)};
+                const v2u rec = {u_child(E), (uint32_t)(docrel + (int32_t)rel)};
+#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 3  // timing only: events are counted, not stored
+                asm volatile("" ::"v"(rec.x), "v"(rec.y));
+#else
                 *reinterpret_cast<v2u *>(evreg + seq) = rec;
+#endif
               } else {
                 M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
               }
@@ -247,7 +268,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             }
           }
         }
-        if (!__any(rel < lim)) break;
+        if (all_left || !__any(rel < lim)) break;
       }
       if (need) pos = pb - 4 + rel;
     }

@@ -2,6 +2,8 @@
 #include "unit.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace aha {
@@ -166,46 +168,68 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     u.tables[kUA2 + 256 + b] = cont ? (b & 0x3Fu) : kUPoison;
   }
 
-  // ---- placement: unique bases, the root at base 0 without slots; a header only for a fail target that does not
-  // itself fail to the root
-  std::vector<uint8_t> hdr(S, 0);
-  for (uint32_t s : ustates)
-    if (s != 0 && a.fail[s] != 0 && a.fail[a.fail[s]] != 0) hdr[a.fail[s]] = 1;
+  // ---- placement: unique bases, the root at base 0 without slots; states with kUBigDegree transitions or more get a
+  // region of 2^15 slots each behind the shared array (unit.hpp)
   uint64_t want = 0;
-  for (uint32_t s : ustates)
-    if (s != 0) want += (first[s + 1] - first[s]) + hdr[s];
-  uint32_t n_slots = (uint32_t)(((want * 4 / 3 + 4096) + (1u << 16) - 1) >> 16) << 16;  // load <= 3/4
-  if (n_slots > kUMaxSlots || u.n_states >= kUMaxSlots / 2) {
-    u.why = "more transitions than the 21-bit bases address";
+  uint32_t n_big = 0;
+  for (uint32_t s : ustates) {
+    if (s == 0) continue;
+    const uint32_t deg = first[s + 1] - first[s];
+    if (deg >= kUBigDegree)
+      n_big++;
+    else
+      want += deg;
+  }
+  const uint32_t n_shared = (uint32_t)(((want * 4 / 3 + 4096) + (1u << 16) - 1) >> 16) << 16;  // load <= 3/4
+  const uint64_t n_total = (((uint64_t)n_shared + (uint64_t)n_big * 32768u) + 65535u) & ~65535ull;
+  if (n_total > kUMaxSlots || u.n_states >= n_shared) {
+    u.why = "more transitions than the 22-bit bases address";
     return;
   }
+  const uint32_t n_slots = (uint32_t)n_total;
   std::vector<uint8_t> used(n_slots, 0), is_base(n_slots, 0);
   std::vector<uint32_t> base(S, 0);
   used[0] = 1;  // index 0 stays empty: base 0 is the root
   is_base[0] = 1;
   uint32_t cursor = 1;  // lowest slot that may be free
   uint32_t idc = 1;     // lowest identity that may be unused
+  uint32_t big_next = 0;
   for (uint32_t s : ustates) {
     if (s == 0) continue;
     const uint32_t lo = first[s], hi = first[s + 1];
     uint32_t b = 0;
-    if (lo == hi && !hdr[s]) {  // owns no slot: any unused identity
+    if (hi - lo >= kUBigDegree) {  // a region of its own: base + symbol
+      b = n_shared + big_next * 32768u;
+      big_next++;
+    } else if (lo == hi) {  // owns no slot: any unused identity
       while (is_base[idc]) idc++;  // (fewer states than slots: never runs off the end)
       b = idc;
     } else {
-      // candidates: put the first symbol (or, without children, the header) on the free slots in turn
-      const uint32_t c0 = lo < hi ? tr[lo].sym : 0u;
-      while (used[cursor]) cursor = cursor + 1 < n_slots ? cursor + 1 : 1;
+      // candidates: put the first symbol on the free slots in turn
+      const uint32_t c0 = tr[lo].sym;
+      while (used[cursor]) cursor = cursor + 1 < n_shared ? cursor + 1 : 1;
       uint32_t f = cursor;
-      for (uint32_t tries = 0;; tries++, f = f + 1 < n_slots ? f + 1 : 1) {
-        if (tries > n_slots) {
+      for (uint32_t tries = 0;; tries++, f = f + 1 < n_shared ? f + 1 : 1) {
+        if (tries > n_shared) {
+          if (getenv("AHA_DEBUG")) {
+            fprintf(stderr, "unit placement: state %u depth %u with %u children, cursor %u of %u\n", s, a.depth[s], hi - lo,
+                    cursor, n_slots);
+            for (uint32_t blk = 0; blk < n_slots >> 16; blk++) {
+              uint32_t nu = 0, nbs = 0;
+              for (uint32_t i = 0; i < 65536; i++) nu += used[(blk << 16) + i], nbs += is_base[(blk << 16) + i];
+              fprintf(stderr, "  block %u: %u used, %u bases\n", blk, nu, nbs);
+            }
+            uint32_t mx = 0;
+            for (uint32_t t = lo; t < hi; t++) mx = std::max(mx, tr[t].sym);
+            fprintf(stderr, "  first sym %u max sym %u\n", tr[lo].sym, mx);
+          }
           u.why = "placement failed";
           return;
         }
         if (used[f]) continue;
         const uint32_t cand = f ^ c0;  // same block of 2^16 slots as f
         if (cand == 0 || is_base[cand]) continue;
-        bool okc = !hdr[s] || !used[cand];
+        bool okc = true;
         for (uint32_t t = lo; okc && t < hi; t++) okc = !used[cand ^ tr[t].sym];
         if (okc) {
           b = cand;
@@ -215,39 +239,39 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     }
     base[s] = b;
     is_base[b] = 1;
-    if (hdr[s]) used[b] = 1;
     for (uint32_t t = lo; t < hi; t++) used[b ^ tr[t].sym] = 1;
   }
 
   // ---- the image
-  auto entry = [&](uint32_t sym, uint32_t child_base, bool end, uint32_t st) -> uint64_t {
-    // st: the state whose fail link the entry carries
-    const uint32_t fb = base[a.fail[st]];
-    const bool ffr = a.fail[a.fail[st]] == 0;
-    const uint32_t lo = child_base | ((fb & 0x3FFu) << 21) | (end ? 0x80000000u : 0u);
-    const uint32_t hi = sym | ((fb >> 10) << 16) | (ffr ? (1u << 27) : 0u);
-    return ((uint64_t)hi << 32) | lo;
+  std::vector<uint8_t> udepth(S, 0);  // characters from the root, saturating
+  for (uint32_t s : ustates)           // BFS order: a state comes before the states its transitions lead to
+    for (uint32_t t = first[s]; t < first[s + 1]; t++) udepth[tr[t].child] = (uint8_t)std::min<uint32_t>(udepth[s] + 1u, 255u);
+  auto word = [&](uint32_t st) -> uint32_t {  // the state as one word (unit.hpp)
+    uint32_t flt = 0;
+    for (uint32_t q = first[st]; q < first[st + 1]; q++) flt |= 1u << (tr[q].sym & 7u);
+    const bool nfr = a.fail[st] != 0, f1 = nfr && udepth[a.fail[st]] == 1;
+    return base[st] | ((flt & 0x7Fu) << 22) | (f1 ? (1u << 29) : 0u) | (nfr ? (1u << 30) : 0u) |
+           (a.key_of[st] >= 0 ? 0x80000000u : 0u);
   };
   u.n_slots = n_slots;
+  u.n_shared = n_shared;
   u.slots.assign(n_slots, 0ull);
+  u.fail_tab.assign(n_slots, 0u);
   u.end_key.assign(n_slots, -1);
   u.root.assign(u.n_syms, 0u);
   for (uint32_t s : ustates) {
     const uint32_t b = base[s];
-    if (hdr[s]) {
-      u.slots[b] = entry(0, 0, false, s);
-      u.n_headers++;
+    if (s != 0 && a.fail[s] != 0 && udepth[a.fail[s]] != 1) {
+      u.fail_tab[b] = word(a.fail[s]) & 0x7FFFFFFFu;  // (falling into a state reports nothing: END is not carried)
+      u.n_nfr++;
     }
     if (a.key_of[s] >= 0) u.end_key[b] = a.key_of[s];
     for (uint32_t t = first[s]; t < first[s + 1]; t++) {
       const uint32_t c = tr[t].child;
-      if (s == 0) {
-        uint32_t flt = 0;
-        for (uint32_t q = first[c]; q < first[c + 1]; q++) flt |= 1u << (tr[q].sym & 7u);
-        u.root[tr[t].sym] = base[c] | (flt << 21) | (a.key_of[c] >= 0 ? 0x80000000u : 0u);
-      } else {
-        u.slots[b ^ tr[t].sym] = entry(tr[t].sym, base[c], a.key_of[c] >= 0, c);
-      }
+      if (s == 0)
+        u.root[tr[t].sym] = word(c);
+      else
+        u.slots[b ^ tr[t].sym] = ((uint64_t)tr[t].sym << 32) | word(c);
     }
   }
   u.ok = true;

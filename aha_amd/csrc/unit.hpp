@@ -37,18 +37,22 @@
 // to look up its second and third byte (A1, A2: the payload contribution of a valid continuation byte, a poison
 // value otherwise) and the class's first symbol and window width.
 //
-// Image: an XOR double array with unique bases over the symbols, 8-byte slots, at most 2^21 of them.  The entry that
-// leads to a state also carries where that state fails to, so a miss needs no header load:
-//   transition  lo = child base (21 bits) | low 10 bits of the child's fail base << 21 | END << 31
-//               hi = symbol (16 bits) | high 11 bits of the fail base << 16 | FFR << 27   (FFR: the fail state's own
-//                                                                                          fail link is the root)
-//   header      (same fields, symbol 0, no child)  only for a state that is some state's fail target and does not fail
-//               to the root itself: falling INTO it by a fail link is the one way to be in a state without having read
-//               the entry that leads to it
-// A fail base of 0 is the root (base 0, owns no slot).  The root's transitions: root[symbol] = child base |
-// filter << 21 | END << 31 (a depth-1 state fails to the root).  `filter` is an 8-bit Bloom filter over the symbols the
-// depth-1 state has transitions on (bit symbol & 7): most characters that follow a character do not continue a key,
-// and a clear bit answers that without the probe.
+// Image: an XOR double array with unique bases over the symbols, 8-byte slots, at most 2^22 of them.  A state is
+// carried around as ONE word -- the low word of the entry that led to it:
+//   transition  lo = child base (22 bits) | filter of the child (7 bits) << 22 | F1 << 29 | NFR << 30 | END << 31
+//               hi = symbol (16 bits)
+//   root[symbol]     the same word for the root's transitions (in LDS); 0 = the root itself (base 0, owns no slot)
+// `filter` is a 7-bit Bloom filter over the symbols the child has transitions on (bit symbol & 7; symbols with
+// symbol & 7 = 7 always probe): most characters that follow a character do not continue a key, and a clear bit
+// answers that without the probe.  NFR: the child's fail link is NOT the root.  A miss in a state without NFR (the
+// root, every one-character state, most others) is answered by the root's table in the same trip.  A miss in an NFR
+// state tries the unit again in the fail state: with F1 -- the fail state is a one-character state, the case of every
+// two-character key -- that is root[the symbol that led here], an LDS read; else (rare: a partial match of three
+// characters or more whose suffix is one of two or more) it comes from a side array in HBM, fail_tab[state base].
+// States with many transitions (an ASCII letter that starts a thousand keys) cannot be fitted into a shared XOR
+// array over a dense alphabet -- all their slots would have to be free at once.  Each of them gets a region of 2^15
+// slots of its own behind the shared part, at a base aligned to 2^15: base ^ symbol = base + symbol there, so the
+// kernel does not know the difference.
 #pragma once
 
 #include <cstdint>
@@ -58,34 +62,37 @@
 
 namespace aha {
 
-constexpr uint32_t kUMaxSlots = 1u << 21;
-constexpr uint32_t kUMaxSyms = 29000;    // root table (4 bytes per symbol) + input rows + decode tables fit 160 KiB of LDS
+constexpr uint32_t kUMaxSlots = 1u << 22;
+constexpr uint32_t kUBigDegree = 48;     // transitions from which on a state gets a region of its own
+constexpr uint32_t kUMaxSyms = 29000;    // (< 2^15: a big state's region holds every symbol)    // root table (4 bytes per symbol) + input rows + decode tables fit 160 KiB of LDS
 constexpr uint32_t kUBias = 1u << 17;    // decode sums are kept non-negative
 constexpr uint32_t kUPoison = 1u << 24;  // contribution of a byte that is not a continuation byte where one must be
 // decode tables, in 32-bit words: T0a[256] {a1 byte offset, a2 byte offset, biased base, biased first symbol},
 // T0b[256] {symbols in the class window, length}, A1[768], A2[512]
 constexpr uint32_t kUT0a = 0, kUT0b = 1024, kUA1 = 1536, kUA2 = 2304, kUTabWords = 2816;
 
-// decoding of an entry (device code and the CPU twin in tests/ use the same arithmetic)
-AHA_HD inline uint32_t u_child(uint32_t lo) { return lo & 0x1FFFFFu; }
+// decoding of a state word / an entry (device code and the CPU twin in tests/ use the same arithmetic)
+AHA_HD inline uint32_t u_child(uint32_t lo) { return lo & 0x3FFFFFu; }
+AHA_HD inline uint32_t u_filter(uint32_t lo) { return ((lo >> 22) & 0x7Fu) | 0x80u; }
+AHA_HD inline bool u_f1(uint32_t lo) { return ((lo >> 29) & 1u) != 0; }
+AHA_HD inline bool u_nfr(uint32_t lo) { return ((lo >> 30) & 1u) != 0; }
 AHA_HD inline bool u_end(uint32_t lo) { return (lo >> 31) != 0; }
 AHA_HD inline uint32_t u_sym(uint32_t hi) { return hi & 0xFFFFu; }
-AHA_HD inline uint32_t u_fail(uint32_t lo, uint32_t hi) { return ((lo >> 21) & 0x3FFu) | (((hi >> 16) & 0x7FFu) << 10); }
-AHA_HD inline bool u_ffr(uint32_t hi) { return ((hi >> 27) & 1u) != 0; }
-AHA_HD inline uint32_t u_filter(uint32_t root_entry) { return (root_entry >> 21) & 0xFFu; }
 
 struct UnitImage {
   bool ok = false;
   const char *why = "";
   uint32_t n_slots = 0;             // a multiple of 2^16 (a base and base ^ symbol share a block of 2^16 slots)
+  uint32_t n_shared = 0;            // the shared XOR array; behind it the regions of the states with many transitions
   std::vector<uint64_t> slots;      // [n_slots]
+  std::vector<uint32_t> fail_tab;   // [n_slots] at the base of an NFR state without F1: the word of its fail state
   std::vector<int32_t> end_key;     // [n_slots] key id at the base of an END state, else -1
   std::vector<uint32_t> root;       // [n_syms]
   std::vector<uint32_t> tables;     // [kUTabWords] decode tables
   uint32_t n_syms = 0;              // A
   uint32_t n1 = 128, n2 = 0;        // "other" symbols of the two- and three-byte classes (0 is the bad unit)
   uint32_t c2lo = 0, w2 = 0, c3lo = 0, w3 = 0;
-  uint32_t n_states = 0, n_trans = 0, n_headers = 0;
+  uint32_t n_states = 0, n_trans = 0, n_nfr = 0;
   uint32_t multi_permille = 0;      // share of the key bytes that lie in two- and three-byte units
 };
 

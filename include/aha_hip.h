@@ -225,7 +225,8 @@ enum {
   AHA_IMG_KEY_LN = 2,  /* {uint32 len, int32 next}[K] */
   AHA_IMG_KEY_CNT = 3, /* uint32[K] */
   AHA_IMG_KEY_KC = 4,  /* uint32[K] */
-  AHA_IMG_UNIT_SLOTS = 6,     /* uint64[unit_slots]: lo = child base | fail low << 21 | END << 31, hi = symbol | ... (unit.hpp) */
+  AHA_IMG_UNIT_SLOTS = 6,     /* uint64[unit_slots]: lo = child base | filter << 21 | NFR << 29 | END << 31, hi = symbol (unit.hpp) */
+  AHA_IMG_UNIT_FAIL = 10,     /* uint32[unit_slots]: the word of the fail state at the base of a state that does not fail to the root */
   AHA_IMG_UNIT_ROOT = 7,      /* uint32[unit_syms]: the root's transitions by symbol */
   AHA_IMG_UNIT_END_KEY = 8,   /* int32[unit_slots]: key id at the base of an END state, else -1 */
   AHA_IMG_UNIT_TABLES = 9,    /* uint32[2816]: the decode tables (unit.hpp, SYMBOLS) */

@@ -443,7 +443,8 @@ def test_engine_selected(engine, monkeypatch):
         cjk = AC.compile(["中国", "国人", "人"])
         cjk.set_profiling(True)
         text = "中国人民" * 3000
-        hits, _ = cjk.match_batch(np.frombuffer(text.encode(), dtype=np.uint8), np.array([0, len(text.encode())], dtype=np.uint64))
+        hits, _ = cjk.match_batch(np.frombuffer(text.encode(), dtype=np.uint8),
+                                  np.array([0, len(text.encode())], dtype=np.uint64), cap=40000)  # room for the event regions
         assert cjk.info["unit_enabled"] == 1 and cjk.last_timing()["engine"] == 4 and len(hits) == 9000
         asc = AC.compile(["abc", "bcd"])
         asc.set_profiling(True)

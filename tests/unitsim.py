@@ -19,6 +19,7 @@ class UnitSim:
         self.root = ac.export(N.AHA_IMG_UNIT_ROOT, np.uint32)
         self.end_key = ac.export(N.AHA_IMG_UNIT_END_KEY, np.int32)
         self.tab = ac.export(N.AHA_IMG_UNIT_TABLES, np.uint32)
+        self.fail_tab = ac.export(N.AHA_IMG_UNIT_FAIL, np.uint32)
         self.key_ln = ac.export(N.AHA_IMG_KEY_LN, np.uint32).reshape(-1, 2)
         self.n_slots = info["unit_slots"]
         assert self.slots.size == self.n_slots and self.n_slots % (1 << 16) == 0
@@ -42,8 +43,8 @@ class UnitSim:
         t = bytes(text)
         n = len(t)
         out = []
-        B, fb, ffr = 0, 0, True
-        flt = 0xFF  # filter of the current state (depth-1 states carry one, others pass everything)
+        E = 0  # the state as one word: base | filter (7 bits) << 22 | F1 << 29 | NFR << 30 | END << 31; 0 = the root
+        pc = 0  # the symbol that led to it
         p = 0
         trips = 0
         self.probes = 0
@@ -52,39 +53,28 @@ class UnitSim:
             good = code != 0
             while True:  # the trips of this unit
                 trips += 1
-                lo = hi = 0
                 hit = False
-                if B != 0 and good and (flt >> (code & 7)) & 1:
+                B = E & 0x3FFFFF
+                if good and B != 0 and ((((E >> 22) & 0x7F) | 0x80) >> (code & 7)) & 1:
                     self.probes += 1
                     e = int(self.slots[B ^ code])
                     lo, hi = e & 0xFFFFFFFF, e >> 32
                     hit = (hi & 0xFFFF) == code
                 if hit:
-                    B = lo & 0x1FFFFF
-                    fb = ((lo >> 21) & 0x3FF) | (((hi >> 16) & 0x7FF) << 10)
-                    ffr = bool((hi >> 27) & 1)
-                    end = bool(lo >> 31)
-                    flt = 0xFF
+                    E = lo
                     break
-                if not good or B == 0 or fb == 0:  # the fail link is the root (or nothing matches): its table
-                    r = int(self.root[code])
-                    B, fb, ffr = r & 0x1FFFFF, 0, True
-                    flt = (r >> 21) & 0xFF
-                    end = good and bool(r >> 31)
+                if not good or not (E >> 30) & 1:  # the fail link is the root (or nothing matches): its table
+                    E = int(self.root[code])
                     break
-                flt = 0xFF
-                if ffr:  # fall to the fail state, whose own fail link is the root
-                    B, fb, ffr = fb, 0, True
-                    continue
-                e = int(self.slots[fb])  # header of the fail state
-                lo, hi = e & 0xFFFFFFFF, e >> 32
-                assert (hi & 0xFFFF) == 0 and e != 0, "missing header"
-                B = fb
-                fb = ((lo >> 21) & 0x3FF) | (((hi >> 16) & 0x7FF) << 10)
-                ffr = bool((hi >> 27) & 1)
+                if (E >> 29) & 1:  # F1: the fail state is the one-character state of the symbol that led here
+                    E = int(self.root[pc]) & 0x7FFFFFFF
+                else:
+                    E = int(self.fail_tab[B])  # fall to the fail state, try the unit again there
+                assert E & 0x3FFFFF, "missing fail link"
+            pc = code
             p += L
-            if end:
-                k = int(self.end_key[B])
+            if E >> 31:
+                k = int(self.end_key[E & 0x3FFFFF])
                 assert k >= 0
                 while k >= 0:
                     ln, nxt = int(self.key_ln[k][0]), int(np.int32(self.key_ln[k][1]))

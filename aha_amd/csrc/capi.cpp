@@ -444,19 +444,21 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   const uint64_t n_slabs = M.ev_cap / kV2Slab + 2;
   const uint64_t n_blk = std::max<uint64_t>((M.n_chunks + 255) / 256, (M.ev_cap + 255) / 256) + 2;
   const uint64_t n_reg = direct ? M.n_chunks * M.ev_stride : 0;
+  // byte offsets through the event regions: the character-level traversal where the key set has a unit image
+  const bool unit = ac->unit_ok && direct && !M.chars;
   int32_t rc;
   size_t sizes[24] = {M.ev_cap * 16,      M.ev_cap * 16,      M.ev_cap * 4,     direct ? 0 : n_slabs * 4,
                       M.n_chunks * 4,     (M.n_docs + 1) * 4, M.n_chunks * 8,   n_blk * 8,
                       n_blk * 8,          16 * 8,             M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
                       M.chars ? M.n_chunks * 4 : 0, M.chars ? M.n_chunks * 4 : 0, M.chars ? (M.n_docs + 1) * 4 : 0,
                       M.chars ? M.n_chunks * 8 : 0,
-                      n_reg * 8,          0,                  direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
+                      n_reg * 8,          unit ? n_reg * 8 : 0, direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
                       0, 0, 0, 0};
   for (int i = 0; i < 24; i++) {
     if (!sizes[i]) continue;
     if ((rc = v2_reserve(ac, sc, i, sizes[i]))) {
       // no room for the event regions (someone else holds the HBM): the slab pipeline needs far less temp
-      if (i == 16 && mode != kSlabs) {
+      if ((i == 16 || i == 17) && mode != kSlabs) {
         (void)hipGetLastError();
         return match_v2(ac, sc, M1, s, n_hits, kSlabs);
       }
@@ -481,6 +483,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.doc_lead_rank = (uint32_t *)sc->v2buf[14].p;
   M.lead_base = (uint64_t *)sc->v2buf[15].p;
   M.evd = (uint2 *)sc->v2buf[16].p;
+  M.evg = (uint2 *)sc->v2buf[17].p;
   M.chunk_hits = (uint32_t *)sc->v2buf[18].p;
   M.hit_base = (uint64_t *)sc->v2buf[19].p;
   if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -489,8 +492,6 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[0], s));
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
-  // byte offsets through the event regions: the character-level traversal where the key set has a unit image
-  const bool unit = ac->unit_ok && direct && !M.chars;
   DevAut post = ac->dev;
   if (unit) {
     post.end_info = ac->d_unit_end_info;  // events carry bases of the unit image
@@ -518,7 +519,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
 #endif
   if (direct) {
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
-    v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr);
+    if (unit) unit_launch_regroup(post, M, s);  // the wave-ordered events back into the chunks' regions, counted
+    v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr, unit);
   } else {
     v2_launch_chunk_scan(M, s);
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));

@@ -108,6 +108,8 @@ struct V2Args {
   int32_t dense_hits;        // THIS call's capacity allows for more than one hit per 4 input bytes (capi.cpp match_v2)
   uint32_t ev_stride;        // events a chunk may store (S / 4); more -> overflow flag, slab pipeline instead
   uint2 *evd;                // [n_chunks * ev_stride] {state base (compact) or key id, end offset in the document}
+  uint2 *evg;                // [n_chunks * ev_stride] character-level traversal: the events of 64 chunks (a wave) together,
+                             // in the order of the wave's trips, lane << 22 in the first word; ku_regroup sorts them into evd
   uint32_t *chunk_hits;      // [n_chunks]
   uint64_t *hit_base;        // [n_chunks] exclusive scan of chunk_hits
   aha_hit *out;
@@ -129,6 +131,7 @@ struct UnitDev {
 size_t unit_lds_bytes(uint32_t n_syms);
 int unit_prepare(uint32_t n_syms);  // raises the dynamic-LDS limit; hipError_t as int
 void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream);
+void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream);  // evg -> evd + chunk_hits (replaces k2d_count)
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
@@ -138,7 +141,7 @@ void v2_launch_chunk_scan(const V2Args &M, void *stream);
 void v2_launch_sort(const DevAut &A, const V2Args &M, uint64_t n_records, void *stream);
 void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events, void *stream);
 // direct pipeline (plain mode): per-chunk hit counts, their scan, expansion and document offsets
-void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid);
+void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid, bool counted = false);
 
 // exchange format of the multi-GPU all-gatherv (kernels.hip): {end, value} pairs <-> Hit triples
 void launch_hits_pack(const int32_t *hits, uint64_t n, int32_t *pairs, void *stream);

@@ -47,6 +47,13 @@ __device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t g, int64_t 
   return v;
 }
 
+__host__ __device__ inline size_t u_lds_rows(uint32_t n_syms) {  // decode tables, root table, input rows
+  return (size_t)(kUTabWords + ((n_syms + 3u) & ~3u)) * 4 + (size_t)(kV2Threads / 64) * kUWave + 16;
+}
+__host__ __device__ inline size_t u_lds(uint32_t n_syms) {
+  return u_lds_rows(n_syms) + (size_t)(kV2Threads / 64) * 64 * 8;  // + the waves' event buffers
+}
+
 __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // LDS: decode tables (16-byte aligned), the root's transitions (child base | filter << 21 | END << 31), input rows
@@ -64,6 +71,8 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t *inl = in_base + wave * kUWave + lane * kURow;
   const uint32_t *row = reinterpret_cast<const uint32_t *>(inl);
+  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  v2u *wb = reinterpret_cast<v2u *>(smem + u_lds_rows(U.n_syms)) + wave * 64;  // the wave's event buffer
   const uint2 *slots = U.slots;
   const int64_t N = (int64_t)M.n_bytes;
   const uint64_t D = M.n_docs;
@@ -75,13 +84,21 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t chunk = tile * kV2Threads + threadIdx.x;
-    uint2 *evreg = M.evd + chunk * M.ev_stride;
     const uint32_t ev_stride = M.ev_stride;
     const bool live = chunk < M.n_chunks;
     const int64_t a = (int64_t)chunk * S;
     const int64_t e = live ? min(a + S, N) : a;
     uint64_t dn = 0;
     int64_t nb = INT64_MAX, doc_start = a, pos = e;
+    // Events leave through a buffer of 64 records per wave in LDS and go out 512 bytes at a time into the wave's part
+    // of the event space (the regions of its 64 chunks, taken together), tagged with the lane: a store per lane and event
+    // into the lane's own region put a scattered 8-byte store -- and its acknowledgement, which the next probe waits for
+    // through the shared vmcnt -- into almost every trip (-0.28 ms per GiB on cfg 3, profiles/r03_unit_lab.txt).
+    // ku_regroup sorts them back into the regions, chunk by chunk in order.
+    uint32_t wfill = 0, wout = 0;  // records in the buffer / already written (wave-uniform)
+    const uint64_t wchunk0 = tile * kV2Threads + (uint64_t)wave * 64;
+    uint2 *wreg = M.evg + wchunk0 * M.ev_stride;
+    const uint32_t wcap = (uint32_t)min<uint64_t>(64, M.n_chunks > wchunk0 ? M.n_chunks - wchunk0 : 0) * M.ev_stride;
     uint32_t E = 0, seq = 0;  // the state as one word (unit.hpp): base | filter << 22 | F1 | NFR | END; 0 = the root
     uint32_t pc = 0;          // the symbol that led to it
     uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1, q3 = q1;  // the rest of the input line whose first piece was staged last
@@ -216,7 +233,13 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
 #else
             const bool probe = good & !later & ((u_filter(E) >> (code & 7u)) & 1u) != 0u & Bq != 0u;
 #endif
+#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 5  // timing only: a big state's probes fall into 8 KiB of its region
+            const uint2 en = slots[probe ? (Bq >= U.n_shared ? Bq + (code & 1023u) : (Bq ^ code)) : 0u];
+#elif defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 6  // timing only: ... into half of its region
+            const uint2 en = slots[probe ? (Bq >= U.n_shared ? Bq + (code >> 1) : (Bq ^ code)) : 0u];
+#else
             const uint2 en = slots[probe ? (Bq ^ code) : 0u];
+#endif
             const bool hit = probe & u_sym(en.y) == code;
             // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip;
             // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or -- rare -- the
@@ -227,7 +250,11 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const bool viaroot = !hit & !later & (!u_nfr(E) | !good);
 #endif
             const bool fall = !hit & !viaroot & !later;
+#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 7  // timing only: no fail link comes from the side array
+            const bool fall_far = false;
+#else
             const bool fall_far = fall & !u_f1(E);
+#endif
             uint32_t ft = rf & 0x7FFFFFFFu;  // (falling into a state reports nothing: END is not carried)
             if (__any(fall_far)) {
               const uint32_t fx = U.fail_tab[fall_far ? Bq : 0u];
@@ -250,27 +277,37 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const int32_t last = (int32_t)rel - 1;  // row index of the unit's last byte
             // is_end? -> fetch later (ac.cr:183-185); this lane reports the end positions in [a, e)
             ev = end & last >= a_rel & last < e_rel;
-          }
-          if (__any(ev)) {
-            if (ev) {
-              if (seq < ev_stride) {
-                typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-                const v2u rec = {u_child(E), (uint32_t)(docrel + (int32_t)rel)};
-#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 3  // timing only: events are counted, not stored
-                asm volatile("" ::"v"(rec.x), "v"(rec.y));
-#else
-                *reinterpret_cast<v2u *>(evreg + seq) = rec;
+#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 8  // timing only: nothing is reported
+            ev = false;
 #endif
-              } else {
-                M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
-              }
-              seq++;
+          }
+          const uint64_t evm = __ballot(ev);
+          if (evm) {
+            const bool room = seq < ev_stride;  // a lane never sends more than its region holds: the wave's part cannot overflow
+            if (ev & !room) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
+            const uint64_t pm = __ballot(ev & room);
+            const uint32_t my = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+            const v2u rec = {u_child(E) | (uint32_t)lane << 22, (uint32_t)(docrel + (int32_t)rel)};
+            const bool push = ev & room;
+            if (push && my < 64u) wb[my] = rec;
+            const uint32_t kp = __popcll(pm);
+            if (wfill + kp >= 64u) {
+              const v2u r = wb[lane];
+              if (wout + 64u <= wcap) *reinterpret_cast<v2u *>(wreg + wout + lane) = r;
+              wout += 64u;
+              if (push && my >= 64u) wb[my - 64u] = rec;
             }
+            wfill = (wfill + kp) & 63u;
+            seq += ev ? 1u : 0u;
           }
         }
         if (all_left || !__any(rel < lim)) break;
       }
       if (need) pos = pb - 4 + rel;
+    }
+    {  // the rest of the wave's buffer
+      const v2u r = wb[lane];
+      if ((uint32_t)lane < wfill && wout + (uint32_t)lane < wcap) *reinterpret_cast<v2u *>(wreg + wout + lane) = r;
     }
     if (live) {
       M.ev_cnt[chunk] = seq;
@@ -284,11 +321,128 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   }
 }
 
+// The events of a group of 64 chunks, as the traversal's wave wrote them (in the order of its trips, lane tagged in
+// bits 22..27 of the first word), go back into the chunks' own regions, each chunk's in order -- and get what
+// k2d_count gives an event on the way: the key (or the offset of its flattened output chain) and the chain length
+// instead of the END state's base; the hits of every chunk are summed up.
+// One workgroup per group.  A block of 1024 records (four per thread, read coalesced) is sorted by chunk in LDS -- a
+// stable counting sort: sixteen sub-batches of 64 records in source order; six ballots over the lane tag give every
+// record its rank among the sub-batch's records of the same chunk and every lane the sub-batch's count for "its"
+// chunk; exclusive sums over the sub-batches and the chunks give the place -- and leaves LDS as 64 runs, each
+// appended to its chunk's region: consecutive threads store consecutive records (a store per record into 64 different
+// regions costs a memory request per record, here as in the traversal).
+constexpr int kRgThreads = 256, kRgPer = 4, kRgBlock = kRgThreads * kRgPer, kRgSubs = kRgBlock / 64;
+__global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
+  __shared__ uint2 s_sorted[kRgBlock];
+  __shared__ uint8_t s_lane[kRgBlock];
+  __shared__ uint32_t s_cnt[kRgSubs][64], s_part[kRgThreads / 64][64];
+  __shared__ uint32_t s_start[64], s_tot[64], s_run[64], s_hits[64];
+  if (M.cursor[1]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t n_groups = (M.n_chunks + 63) / 64;
+  const uint32_t stride = M.ev_stride;
+  for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    __syncthreads();
+    if (wv == 0) {
+      s_run[lane] = 0;
+      s_hits[lane] = 0;
+    }
+    const uint64_t c = g * 64 + lane;
+    uint32_t total = c < M.n_chunks ? min(M.ev_cnt[c], stride) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
+    const uint2 *src = M.evg + g * 64 * stride;
+    uint2 *dst = M.evd + g * 64 * stride;
+    uint2 nxt[kRgPer];
+#pragma unroll
+    for (int q = 0; q < kRgPer; q++) {
+      const uint32_t i = q * kRgThreads + threadIdx.x;
+      nxt[q] = i < total ? src[i] : make_uint2(0, 0);
+    }
+    for (uint32_t i0 = 0; i0 < total; i0 += kRgBlock) {
+      uint2 rec[kRgPer];
+      uint32_t x[kRgPer], rank[kRgPer], l[kRgPer];
+      bool live[kRgPer];
+#pragma unroll
+      for (int q = 0; q < kRgPer; q++) {
+        const uint32_t i = i0 + q * kRgThreads + threadIdx.x;
+        live[q] = i < total;
+        rec[q] = nxt[q];
+        nxt[q] = i + kRgBlock < total ? src[i + kRgBlock] : make_uint2(0, 0);
+        // key id, or (flattened chains) the offset of its chain, | min(chain length, 255) << 24
+        x[q] = live[q] ? A.end_info[rec[q].x & 0x3FFFFFu] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < kRgPer; q++) {
+        l[q] = (rec[q].x >> 22) & 63u;
+        uint64_t same = __ballot(live[q]), mine = same;  // records of the sub-batch with this record's tag / with tag == lane
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+          const uint64_t bal = __ballot(live[q] & ((l[q] >> b) & 1u) != 0u);
+          same &= ((l[q] >> b) & 1u) ? bal : ~bal;
+          mine &= ((lane >> b) & 1) ? bal : ~bal;
+        }
+        rank[q] = __popcll(same & ((1ull << lane) - 1ull));
+        s_cnt[q * (kRgThreads / 64) + wv][lane] = __popcll(mine);  // sub-batch q * 4 + wv holds the records i0 + sb * 64 ..
+      }
+      __syncthreads();
+      {  // exclusive sums down the sub-batches: four rows per thread, then across the four quarters
+        uint32_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < kRgSubs / (kRgThreads / 64); r++) {
+          const uint32_t v = s_cnt[wv * (kRgSubs / (kRgThreads / 64)) + r][lane];
+          s_cnt[wv * (kRgSubs / (kRgThreads / 64)) + r][lane] = acc;
+          acc += v;
+        }
+        s_part[wv][lane] = acc;
+      }
+      __syncthreads();
+      if (wv == 0) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kRgThreads / 64; w2++) {
+          const uint32_t v = s_part[w2][lane];
+          s_part[w2][lane] = acc;
+          acc += v;
+        }
+        s_tot[lane] = acc;
+        s_start[lane] = wave_incl_scan(acc) - acc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kRgPer; q++) {
+        if (live[q]) {
+          const uint32_t sb = q * (kRgThreads / 64) + wv;
+          const uint32_t p = s_start[l[q]] + s_part[sb / (kRgSubs / (kRgThreads / 64))][l[q]] + s_cnt[sb][l[q]] + rank[q];
+          uint32_t cnt = x[q] >> 24;
+          if (cnt == 255u) cnt = A.key_cnt[A.chain ? A.chain[x[q] & 0xFFFFFFu].y : (x[q] & 0xFFFFFFu)];
+          s_sorted[p] = make_uint2(x[q], rec[q].y);
+          s_lane[p] = (uint8_t)l[q];
+          if (cnt) atomicAdd(&s_hits[l[q]], cnt);
+        }
+      }
+      __syncthreads();
+      const uint32_t nb = min(total - i0, (uint32_t)kRgBlock);
+#pragma unroll
+      for (int q = 0; q < kRgPer; q++) {
+        const uint32_t p = q * kRgThreads + threadIdx.x;
+        if (p < nb) {
+          const uint32_t lp = s_lane[p];
+          const uint32_t at = s_run[lp] + (p - s_start[lp]);
+          if (at < stride) dst[(uint64_t)lp * stride + at] = s_sorted[p];
+        }
+      }
+      __syncthreads();
+      if (wv == 0) s_run[lane] += s_tot[lane];
+    }
+    __syncthreads();
+    if (wv == 0 && c < M.n_chunks) M.chunk_hits[c] = s_hits[lane];
+  }
+}
+
 }  // namespace
 
-size_t unit_lds_bytes(uint32_t n_syms) {
-  return (size_t)(kUTabWords + ((n_syms + 3u) & ~3u)) * 4 + (size_t)(kV2Threads / 64) * kUWave + 16;
-}
+size_t unit_lds_bytes(uint32_t n_syms) { return u_lds(n_syms); }
 
 int unit_prepare(uint32_t n_syms) {
   return (int)hipFuncSetAttribute((const void *)ku_traverse, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -297,6 +451,12 @@ int unit_prepare(uint32_t n_syms) {
 
 void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream) {
   hipLaunchKernelGGL(ku_traverse, dim3(grid), dim3(kV2Threads), unit_lds_bytes(U.n_syms), (hipStream_t)stream, U, M);
+}
+
+void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream) {
+  const uint64_t n_groups = (M.n_chunks + 63) / 64;
+  hipLaunchKernelGGL(ku_regroup, dim3((uint32_t)std::min<uint64_t>(n_groups, 1u << 16)), dim3(kRgThreads), 0,
+                     (hipStream_t)stream, A, M);
 }
 
 }  // namespace aha

@@ -1191,13 +1191,16 @@ void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events_hint, 
   }
 }
 
-void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid) {
+void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid, bool counted) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t gw = grid_for(M.n_chunks, 4, 8192);  // 4 waves (chunks) per 256-thread block
-  if (A.compact)
+  if (counted) {
+    // (the character-level traversal's regroup pass has done it: unit_launch_regroup)
+  } else if (A.compact) {
     hipLaunchKernelGGL(k2d_count<true>, dim3(gw), dim3(256), 0, s, A, M);
-  else
+  } else {
     hipLaunchKernelGGL(k2d_count<false>, dim3(gw), dim3(256), 0, s, A, M);
+  }
   const uint32_t g = grid_for(M.n_chunks, 256, 4096);
   const unsigned long long *abortf = (const unsigned long long *)(M.cursor + 1);
   hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.chunk_hits, (const uint64_t *)nullptr, M.n_chunks,

@@ -79,9 +79,12 @@ struct aha_ac {
   bool unit_ok = false;  // uploaded and usable on the device
   UnitDev udev{};
   const uint32_t *d_unit_end_info = nullptr;
+  const uint2 *d_unit_end = nullptr;  // fused expansion (scan_unit.hip ku_expand_groups): key, key length, chain offset per END base
+  bool unit_fused = false;            // ... usable: flattened chains of at most 15 keys, key lengths below 2^16
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
   // match_longest only (cedar_replay.cpp): the states that carry one of Cedar's stale END flags, derived on the first
   // match_longest call (it replays every insert: as long again as the rest of compile); dev_longest = dev + the bitmap
+  std::vector<uint2> chain_host;     // the flattened output chains {key length, key}
   std::vector<uint32_t> key_info;    // [K] flattened-chain offset | min(chain length, 255) << 24 (empty: no flat chains)
   std::vector<uint32_t> state_base;  // [n_states] base of every state in the image
   std::once_flag stale_once;
@@ -212,7 +215,8 @@ int32_t upload_image(aha_ac *ac, const Image &img) {
   std::vector<uint32_t> kinfo;
   if (a.n_keys && total < (1ull << 24)) {
     std::vector<uint32_t> kc;
-    std::vector<uint2> ch;
+    std::vector<uint2> &ch = ac->chain_host;
+    ch.clear();
     kinfo.resize(a.n_keys);
     ch.reserve((size_t)total);
     kc.reserve((size_t)total);
@@ -362,7 +366,24 @@ void v2_setup(aha_ac *ac) {
       const int32_t k = ac->unit.end_key[i];
       if (k >= 0) info[i] = ac->key_info.empty() ? ((uint32_t)k | (std::min<uint32_t>(a.key_cnt[k], 255u) << 24)) : ac->key_info[k];
     }
+    // the fused expansion's table: one gather gives an event's first hit and where the rest of its chain is
+    uint32_t max_cnt = 0;
+    for (uint32_t k = 0; k < a.n_keys; k++) max_cnt = std::max(max_cnt, a.key_cnt[k]);
+    const char *upost = getenv("AHA_UNIT_POST");  // "regroup": the general post passes (tests)
+    const bool fused = !ac->key_info.empty() && max_cnt <= 15 && a.max_key_len < 65536 &&
+                       !(upost && strcmp(upost, "regroup") == 0);
+    std::vector<uint2> uend;
+    if (fused) {
+      uend.assign(ac->unit.end_key.size(), uint2{0, 0});
+      for (size_t i = 0; i < uend.size(); i++) {
+        const int32_t k = ac->unit.end_key[i];
+        if (k < 0) continue;
+        const uint32_t co = ac->key_info[k] & 0xFFFFFFu, len = a.key_len[k];
+        uend[i] = uint2{(uint32_t)k | (len & 0xFFu) << 24, co | (len >> 8) << 24};
+      }
+    }
     const uint64_t *us = nullptr;
+    if (fused && upload(ac, uend, &ac->d_unit_end) == AHA_OK) ac->unit_fused = true;
     if (unit_prepare(ac->unit.n_syms) == 0 && upload(ac, ac->unit.slots, &us) == AHA_OK &&
         upload(ac, ac->unit.root, &ac->udev.root) == AHA_OK && upload(ac, ac->unit.tables, &ac->udev.tables) == AHA_OK &&
         upload(ac, ac->unit.fail_tab, &ac->udev.fail_tab) == AHA_OK &&
@@ -452,8 +473,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
                       n_blk * 8,          16 * 8,             M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
                       M.chars ? M.n_chunks * 4 : 0, M.chars ? M.n_chunks * 4 : 0, M.chars ? (M.n_docs + 1) * 4 : 0,
                       M.chars ? M.n_chunks * 8 : 0,
-                      n_reg * 8,          unit ? n_reg * 8 : 0, direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
-                      0, 0, 0, 0};
+                      (unit && ac->unit_fused) ? 0 : n_reg * 8, unit ? n_reg * 8 : 0, direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
+                      unit ? (M.n_docs + 1) * 4 : 0, 0, 0, 0};
   for (int i = 0; i < 24; i++) {
     if (!sizes[i]) continue;
     if ((rc = v2_reserve(ac, sc, i, sizes[i]))) {
@@ -484,6 +505,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.lead_base = (uint64_t *)sc->v2buf[15].p;
   M.evd = (uint2 *)sc->v2buf[16].p;
   M.evg = (uint2 *)sc->v2buf[17].p;
+  M.doc_hit_rank = (uint32_t *)sc->v2buf[20].p;
   M.chunk_hits = (uint32_t *)sc->v2buf[18].p;
   M.hit_base = (uint64_t *)sc->v2buf[19].p;
   if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -519,8 +541,14 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
 #endif
   if (direct) {
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
-    if (unit) unit_launch_regroup(post, M, s);  // the wave-ordered events back into the chunks' regions, counted
-    v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr, unit);
+    if (unit && ac->unit_fused) {  // the traversal counted the hits: bases, then the expansion straight from the wave-ordered events
+      v2_launch_hit_scan(M, s);
+      if (prof) HIPCHK(ac, hipEventRecord(sc->ev[3], s));
+      unit_launch_expand(ac->d_unit_end, post, M, s);
+    } else {
+      if (unit) unit_launch_regroup(post, M, s);  // the wave-ordered events back into the chunks' regions, counted
+      v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr, unit);
+    }
   } else {
     v2_launch_chunk_scan(M, s);
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));

@@ -110,6 +110,8 @@ struct V2Args {
   uint2 *evd;                // [n_chunks * ev_stride] {state base (compact) or key id, end offset in the document}
   uint2 *evg;                // [n_chunks * ev_stride] character-level traversal: the events of 64 chunks (a wave) together,
                              // in the order of the wave's trips, lane << 22 in the first word; ku_regroup sorts them into evd
+  uint32_t *doc_hit_rank;    // [D+1] character-level traversal: hits of the chunk before the document start (exact when no
+                             // event stands for more than 15 hits: the record carries the count in bits 28..31 then)
   uint32_t *chunk_hits;      // [n_chunks]
   uint64_t *hit_base;        // [n_chunks] exclusive scan of chunk_hits
   aha_hit *out;
@@ -132,6 +134,10 @@ size_t unit_lds_bytes(uint32_t n_syms);
 int unit_prepare(uint32_t n_syms);  // raises the dynamic-LDS limit; hipError_t as int
 void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream);
 void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream);  // evg -> evd + chunk_hits (replaces k2d_count)
+// evg + hit_base -> out, doc_hit_off: the whole expansion in one pass over the wave-ordered events.  uend[base] of an END
+// state = {key | (key length & 255) << 24, offset of its flattened output chain | (key length >> 8) << 24}
+void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, void *stream);
+void v2_launch_hit_scan(const V2Args &M, void *stream);  // chunk_hits -> hit_base, totals[0]
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int

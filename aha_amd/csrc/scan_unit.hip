@@ -99,6 +99,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
     const uint64_t wchunk0 = tile * kV2Threads + (uint64_t)wave * 64;
     uint2 *wreg = M.evg + wchunk0 * M.ev_stride;
     const uint32_t wcap = (uint32_t)min<uint64_t>(64, M.n_chunks > wchunk0 ? M.n_chunks - wchunk0 : 0) * M.ev_stride;
+    uint32_t hits = 0;        // hits the lane's events stand for (exact while no event stands for more than 15)
     uint32_t E = 0, seq = 0;  // the state as one word (unit.hpp): base | filter << 22 | F1 | NFR | END; 0 = the root
     uint32_t pc = 0;          // the symbol that led to it
     uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1, q3 = q1;  // the rest of the input line whose first piece was staged last
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const int64_t here = pb - 4 + rel;
             do {
               M.doc_ev_rank[dn] = seq;
+              M.doc_hit_rank[dn] = hits;
               dn++;
               nb = dn <= D ? (int64_t)M.doc_off[dn] : INT64_MAX;
             } while (nb == here);
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
           all_left = __all(rel >= (uint32_t)(4 + kUPiece) || rel >= lim);
           if (all_left || !__any(act)) break;
           bool ev = false;
+          uint32_t c4 = 0;  // hits the event stands for (a one-character state: its own key and no more)
           if (act) {
             uint32_t n_code, n_L;
             bool n_good, n_later;
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             E = later ? E : newE;
             const bool consumed = hit | viaroot;
             const bool end = consumed & u_end(newE);
+            c4 = hit ? u_c4(en.y) : 1u;
             pc = consumed ? code : pc;
             const uint32_t adv = consumed ? L : 0u;
             rel += adv;
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             if (ev & !room) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
             const uint64_t pm = __ballot(ev & room);
             const uint32_t my = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-            const v2u rec = {u_child(E) | (uint32_t)lane << 22, (uint32_t)(docrel + (int32_t)rel)};
+            const v2u rec = {u_child(E) | (uint32_t)lane << 22 | c4 << 28, (uint32_t)(docrel + (int32_t)rel)};
             const bool push = ev & room;
             if (push && my < 64u) wb[my] = rec;
             const uint32_t kp = __popcll(pm);
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             }
             wfill = (wfill + kp) & 63u;
             seq += ev ? 1u : 0u;
+            hits += ev ? c4 : 0u;
           }
         }
         if (all_left || !__any(rel < lim)) break;
@@ -311,9 +316,11 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
     }
     if (live) {
       M.ev_cnt[chunk] = seq;
+      M.chunk_hits[chunk] = hits;  // (ku_regroup counts again where chains are longer than the record's field)
       if (e == N) {  // documents that start at N (empty tail documents, and d = D)
         while (dn <= D) {
           M.doc_ev_rank[dn] = seq;
+          M.doc_hit_rank[dn] = hits;
           dn++;
         }
       }
@@ -440,6 +447,167 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
   }
 }
 
+// The expansion in one pass over the wave-ordered events (key sets whose output chains hold at most 15 keys: the
+// traversal then knows the hits of every chunk, the bases are scanned before this kernel and nothing has to be put
+// back into per-chunk order in HBM).  A block of 1024 records is sorted by chunk in LDS as in ku_regroup; in sorted
+// order the hits of the block are 64 runs -- one per chunk, each the continuation of the chunk's part of the output
+// -- so an exclusive sum of the records' hit counts places every hit, and consecutive threads write consecutive hits.
+// One gather per event: uend[base of the END state] = its key, the key's length and the offset of its flattened
+// output chain (the second and later hits of an event -- rare -- read the chain).
+constexpr int kXgThreads = 256, kXgPer = 4, kXgBlock = kXgThreads * kXgPer, kXgSubs = kXgBlock / 64;
+__global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend, DevAut A, V2Args M) {
+  __shared__ __attribute__((aligned(16))) uint4 s_rec[kXgBlock];  // sorted: {uend.x, uend.y, end offset, hits}
+  __shared__ uint8_t s_lane[kXgBlock];
+  __shared__ uint32_t s_cnt[kXgSubs][64], s_part[kXgThreads / 64][64];
+  __shared__ uint32_t s_start[64], s_tot[64], s_h[kXgBlock + 1], s_wsum[kXgThreads / 64];
+  __shared__ uint64_t s_base[64];  // where the chunk's next hit goes
+  if (M.cursor[1]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t n_groups = (M.n_chunks + 63) / 64;
+  const uint32_t stride = M.ev_stride;
+  constexpr int kQ = kXgSubs / (kXgThreads / 64);  // sub-batches per quarter
+  for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    __syncthreads();
+    const uint64_t c = g * 64 + lane;
+    if (wv == 0) s_base[lane] = c < M.n_chunks ? M.hit_base[c] : 0ull;
+    uint32_t total = c < M.n_chunks ? min(M.ev_cnt[c], stride) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
+    const uint2 *src = M.evg + g * 64 * stride;
+    uint2 nxt[kXgPer];
+#pragma unroll
+    for (int q = 0; q < kXgPer; q++) {
+      const uint32_t i = q * kXgThreads + threadIdx.x;
+      nxt[q] = i < total ? src[i] : make_uint2(0, 0);
+    }
+    for (uint32_t i0 = 0; i0 < total; i0 += kXgBlock) {
+      uint2 rec[kXgPer], ue[kXgPer];
+      uint32_t rank[kXgPer], l[kXgPer];
+      bool live[kXgPer];
+#pragma unroll
+      for (int q = 0; q < kXgPer; q++) {
+        const uint32_t i = i0 + q * kXgThreads + threadIdx.x;
+        live[q] = i < total;
+        rec[q] = nxt[q];
+        nxt[q] = i + kXgBlock < total ? src[i + kXgBlock] : make_uint2(0, 0);
+        ue[q] = live[q] ? uend[rec[q].x & 0x3FFFFFu] : make_uint2(0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < kXgPer; q++) {
+        l[q] = (rec[q].x >> 22) & 63u;
+        uint64_t same = __ballot(live[q]), mine = same;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+          const uint64_t bal = __ballot(live[q] & ((l[q] >> b) & 1u) != 0u);
+          same &= ((l[q] >> b) & 1u) ? bal : ~bal;
+          mine &= ((lane >> b) & 1) ? bal : ~bal;
+        }
+        rank[q] = __popcll(same & ((1ull << lane) - 1ull));
+        s_cnt[q * (kXgThreads / 64) + wv][lane] = __popcll(mine);
+      }
+      __syncthreads();
+      {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < kQ; r++) {
+          const uint32_t v = s_cnt[wv * kQ + r][lane];
+          s_cnt[wv * kQ + r][lane] = acc;
+          acc += v;
+        }
+        s_part[wv][lane] = acc;
+      }
+      __syncthreads();
+      if (wv == 0) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kXgThreads / 64; w2++) {
+          const uint32_t v = s_part[w2][lane];
+          s_part[w2][lane] = acc;
+          acc += v;
+        }
+        s_tot[lane] = acc;
+        s_start[lane] = wave_incl_scan(acc) - acc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kXgPer; q++) {
+        if (live[q]) {
+          const uint32_t sb = q * (kXgThreads / 64) + wv;
+          const uint32_t p = s_start[l[q]] + s_part[sb / kQ][l[q]] + s_cnt[sb][l[q]] + rank[q];
+          s_rec[p] = make_uint4(ue[q].x, ue[q].y, rec[q].y, rec[q].x >> 28);
+          s_lane[p] = (uint8_t)l[q];
+        }
+      }
+      __syncthreads();
+      // hits before every record of the sorted block: a thread owns four consecutive records
+      const uint32_t nb = min(total - i0, (uint32_t)kXgBlock);
+      const uint32_t p0 = threadIdx.x * kXgPer;
+      uint4 r4[kXgPer];
+      uint32_t own = 0;
+#pragma unroll
+      for (int q = 0; q < kXgPer; q++) {
+        r4[q] = p0 + q < nb ? s_rec[p0 + q] : make_uint4(0, 0, 0, 0);
+        own += r4[q].w;
+      }
+      const uint32_t incl = wave_incl_scan(own);
+      if (lane == 63) s_wsum[wv] = incl;
+      __syncthreads();
+      uint32_t h = incl - own;
+#pragma unroll
+      for (int w2 = 0; w2 < kXgThreads / 64; w2++) h += w2 < wv ? s_wsum[w2] : 0u;
+      {
+        uint32_t hh = h;
+#pragma unroll
+        for (int q = 0; q < kXgPer; q++) {
+          s_h[p0 + q] = hh;
+          hh += r4[q].w;
+        }
+        if (threadIdx.x == kXgThreads - 1) s_h[kXgBlock] = hh;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kXgPer; q++) {
+        const uint32_t n = r4[q].w;
+        if (n) {
+          const uint32_t lp = s_lane[p0 + q];
+          uint64_t idx = s_base[lp] + (h - s_h[s_start[lp]]);
+          const uint32_t end = r4[q].z;
+          const uint32_t co = r4[q].y & 0xFFFFFFu;
+          // Hit(idx - len + 1, idx + 1, value) ac.cr:271-273: the state's own key, then its output chain (ac.cr:265-278)
+          uint32_t len = (r4[q].x >> 24) | (r4[q].y >> 24) << 8, key = r4[q].x & 0xFFFFFFu;
+          for (uint32_t k = 0;;) {
+            if (idx < M.cap) {
+              aha_hit hit;
+              hit.start = (int32_t)(end - len);
+              hit.end = (int32_t)end;
+              hit.value = (int32_t)key;
+              M.out[idx] = hit;
+            }
+            if (++k >= n) break;
+            const uint2 ce = A.chain[co + k];
+            len = ce.x;
+            key = ce.y;
+            idx++;
+          }
+          h += n;
+        }
+      }
+      __syncthreads();
+      if (wv == 0) s_base[lane] += s_h[s_start[lane] + s_tot[lane]] - s_h[s_start[lane]];
+    }
+  }
+}
+
+// doc_hit_off[d] = hits before the document's first event: the chunk's hit base + the hits of the chunk before the
+// document start, which the traversal noted at the boundary
+__global__ __launch_bounds__(256) void ku_doc_offsets(V2Args M) {
+  if (M.cursor[1] || !M.doc_hit_off) return;
+  const uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (d > M.n_docs) return;
+  const uint64_t q = M.doc_off[d];
+  M.doc_hit_off[d] = q < M.n_bytes ? M.hit_base[q / M.S] + M.doc_hit_rank[d] : M.totals[0];
+}
+
 }  // namespace
 
 size_t unit_lds_bytes(uint32_t n_syms) { return u_lds(n_syms); }
@@ -457,6 +625,14 @@ void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream) {
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
   hipLaunchKernelGGL(ku_regroup, dim3((uint32_t)std::min<uint64_t>(n_groups, 1u << 16)), dim3(kRgThreads), 0,
                      (hipStream_t)stream, A, M);
+}
+
+void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, void *stream) {
+  const uint64_t n_groups = (M.n_chunks + 63) / 64;
+  hipLaunchKernelGGL(ku_expand_groups, dim3((uint32_t)std::min<uint64_t>(n_groups, 1u << 16)), dim3(kXgThreads), 0,
+                     (hipStream_t)stream, uend, A, M);
+  if (M.doc_hit_off)
+    hipLaunchKernelGGL(ku_doc_offsets, dim3((uint32_t)((M.n_docs + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M);
 }
 
 }  // namespace aha

@@ -1191,6 +1191,17 @@ void v2_launch_expand(const DevAut &A, const V2Args &M, uint64_t n_events_hint, 
   }
 }
 
+void v2_launch_hit_scan(const V2Args &M, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t g = grid_for(M.n_chunks, 256, 4096);
+  const unsigned long long *abortf = (const unsigned long long *)(M.cursor + 1);
+  hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.chunk_hits, (const uint64_t *)nullptr, M.n_chunks,
+                     M.blk_a, abortf);
+  hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_a, (const uint64_t *)nullptr, M.n_chunks,
+                     M.totals + 0, abortf);
+  hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.chunk_hits, M.n_chunks, M.blk_a, M.hit_base);
+}
+
 void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid, bool counted) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t gw = grid_for(M.n_chunks, 4, 8192);  // 4 waves (chunks) per 256-thread block

@@ -253,6 +253,9 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     return base[st] | ((flt & 0x7Fu) << 22) | (f1 ? (1u << 29) : 0u) | (nfr ? (1u << 30) : 0u) |
            (a.key_of[st] >= 0 ? 0x80000000u : 0u);
   };
+  auto u_c4_of = [](const Automaton &au, uint32_t st) -> uint32_t {  // hits an event in this state stands for, at most 15
+    return au.key_of[st] >= 0 ? std::min<uint32_t>(au.key_cnt[au.key_of[st]], 15u) : 0u;
+  };
   u.n_slots = n_slots;
   u.n_shared = n_shared;
   u.slots.assign(n_slots, 0ull);
@@ -271,7 +274,7 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
       if (s == 0)
         u.root[tr[t].sym] = word(c);
       else
-        u.slots[b ^ tr[t].sym] = ((uint64_t)tr[t].sym << 32) | word(c);
+        u.slots[b ^ tr[t].sym] = ((uint64_t)(tr[t].sym | u_c4_of(a, c) << 16) << 32) | word(c);
     }
   }
   u.ok = true;

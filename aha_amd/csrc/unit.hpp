@@ -40,7 +40,7 @@
 // Image: an XOR double array with unique bases over the symbols, 8-byte slots, at most 2^22 of them.  A state is
 // carried around as ONE word -- the low word of the entry that led to it:
 //   transition  lo = child base (22 bits) | filter of the child (7 bits) << 22 | F1 << 29 | NFR << 30 | END << 31
-//               hi = symbol (16 bits)
+//               hi = symbol (16 bits) | min(hits an event in the child stands for, 15) << 16  (0 unless the child is END)
 //   root[symbol]     the same word for the root's transitions (in LDS); 0 = the root itself (base 0, owns no slot)
 // `filter` is a 7-bit Bloom filter over the symbols the child has transitions on (bit symbol & 7; symbols with
 // symbol & 7 = 7 always probe): most characters that follow a character do not continue a key, and a clear bit
@@ -78,6 +78,7 @@ AHA_HD inline bool u_f1(uint32_t lo) { return ((lo >> 29) & 1u) != 0; }
 AHA_HD inline bool u_nfr(uint32_t lo) { return ((lo >> 30) & 1u) != 0; }
 AHA_HD inline bool u_end(uint32_t lo) { return (lo >> 31) != 0; }
 AHA_HD inline uint32_t u_sym(uint32_t hi) { return hi & 0xFFFFu; }
+AHA_HD inline uint32_t u_c4(uint32_t hi) { return (hi >> 16) & 15u; }
 
 struct UnitImage {
   bool ok = false;

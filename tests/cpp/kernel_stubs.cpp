@@ -24,6 +24,8 @@ void v2_launch_sort(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("
 void v2_launch_expand(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("v2_launch_expand"); }
 void v2_launch_direct_post(const DevAut &, const V2Args &, void *, void *, bool) { no_gpu("v2_launch_direct_post"); }
 void unit_launch_regroup(const DevAut &, const V2Args &, void *) { no_gpu("unit_launch_regroup"); }
+void unit_launch_expand(const uint2 *, const DevAut &, const V2Args &, void *) { no_gpu("unit_launch_expand"); }
+void v2_launch_hit_scan(const V2Args &, void *) { no_gpu("v2_launch_hit_scan"); }
 void launch_hits_pack(const int32_t *, uint64_t, int32_t *, void *) { no_gpu("launch_hits_pack"); }
 void launch_hits_unpack(const DevAut &, const int32_t *, uint64_t, int, int32_t *, void *) { no_gpu("launch_hits_unpack"); }
 void launch_hits_pack4(const int32_t *, uint64_t, uint32_t *, unsigned long long *, void *) { no_gpu("launch_hits_pack4"); }

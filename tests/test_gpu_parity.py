@@ -17,16 +17,22 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1", "v2p", "u"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur"], autouse=True)
 def engine(request, monkeypatch):
     """Every parity test runs on the single-traversal engine (scan_v2.hip, byte level), on the two-pass engine
     (kernels.hip: the fallback for tiny capacities and very long keys), on the single-traversal engine with its LDS
     prefix capped at 1024 slots ("v2p": small automata then also take the partial-prefix kernel with the shadow fail
     links and the HBM probe path) and on the character-level engine ("u", scan_unit.hip: AHA_ENGINE=unit builds the
     unit image for every eligible key set, also the mostly-ASCII ones that would not get one by default; byte-offset
-    calls through the event regions then run it, everything else the single-traversal engine).  Without the variable
+    calls through the event regions then run it, everything else the single-traversal engine; its post pass is the fused
+    expansion wherever the output chains are short enough, "ur" -- AHA_UNIT_POST=regroup -- keeps it to the general
+    regroup + count + expand passes).  Without the variable
     the library decides per key set (bench.py runs that way).  The variables are read when a handle is compiled."""
-    monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit"}.get(request.param, "v2"))
+    monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit"}.get(request.param, "v2"))
+    if request.param == "ur":
+        monkeypatch.setenv("AHA_UNIT_POST", "regroup")
+    else:
+        monkeypatch.delenv("AHA_UNIT_POST", raising=False)
     if request.param == "v2p":
         monkeypatch.setenv("AHA_LDS_SLOTS", "1024")
     else:
@@ -431,12 +437,12 @@ def test_engine_selected(engine, monkeypatch):
     ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine == "u" else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur") else (2,))
     ac = AC.compile(["ab", "ba"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"ab ba " * 60))[:3] == [(0, 2, 0), (3, 5, 1), (6, 8, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine == "u" else (2,))
-    if engine == "u":
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur") else (2,))
+    if engine in ("u", "ur"):
         # the library's own choice (no AHA_ENGINE): keys of multi-byte characters get the character-level traversal for
         # byte-offset batches, ASCII keys and char offsets keep the byte-level one
         monkeypatch.delenv("AHA_ENGINE", raising=False)

@@ -473,7 +473,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
                       n_blk * 8,          16 * 8,             M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
                       M.chars ? M.n_chunks * 4 : 0, M.chars ? M.n_chunks * 4 : 0, M.chars ? (M.n_docs + 1) * 4 : 0,
                       M.chars ? M.n_chunks * 8 : 0,
-                      (unit && ac->unit_fused) ? 0 : n_reg * 8, unit ? n_reg * 8 : 0, direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
+                      (unit && ac->unit_fused) ? 0 : n_reg * 8, unit ? n_reg * 12 : 0, direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
                       unit ? (M.n_docs + 1) * 4 : 0, 0, 0, 0};
   for (int i = 0; i < 24; i++) {
     if (!sizes[i]) continue;
@@ -504,7 +504,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.doc_lead_rank = (uint32_t *)sc->v2buf[14].p;
   M.lead_base = (uint64_t *)sc->v2buf[15].p;
   M.evd = (uint2 *)sc->v2buf[16].p;
-  M.evg = (uint2 *)sc->v2buf[17].p;
+  M.evg = (uint32_t *)sc->v2buf[17].p;
   M.doc_hit_rank = (uint32_t *)sc->v2buf[20].p;
   M.chunk_hits = (uint32_t *)sc->v2buf[18].p;
   M.hit_base = (uint64_t *)sc->v2buf[19].p;

@@ -51,7 +51,7 @@ __host__ __device__ inline size_t u_lds_rows(uint32_t n_syms) {  // decode table
   return (size_t)(kUTabWords + ((n_syms + 3u) & ~3u)) * 4 + (size_t)(kV2Threads / 64) * kUWave + 16;
 }
 __host__ __device__ inline size_t u_lds(uint32_t n_syms) {
-  return u_lds_rows(n_syms) + (size_t)(kV2Threads / 64) * 64 * 8;  // + the waves' event buffers
+  return u_lds_rows(n_syms) + (size_t)(kV2Threads / 64) * 64 * 12;  // + the waves' event buffers
 }
 
 __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t *inl = in_base + wave * kUWave + lane * kURow;
   const uint32_t *row = reinterpret_cast<const uint32_t *>(inl);
-  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-  v2u *wb = reinterpret_cast<v2u *>(smem + u_lds_rows(U.n_syms)) + wave * 64;  // the wave's event buffer
+  typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+  uint32_t *wb = reinterpret_cast<uint32_t *>(smem + u_lds_rows(U.n_syms)) + wave * 64 * 3;  // the wave's event buffer
   const uint2 *slots = U.slots;
   const int64_t N = (int64_t)M.n_bytes;
   const uint64_t D = M.n_docs;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
     // ku_regroup sorts them back into the regions, chunk by chunk in order.
     uint32_t wfill = 0, wout = 0;  // records in the buffer / already written (wave-uniform)
     const uint64_t wchunk0 = tile * kV2Threads + (uint64_t)wave * 64;
-    uint2 *wreg = M.evg + wchunk0 * M.ev_stride;
+    uint32_t *wreg = M.evg + wchunk0 * M.ev_stride * 3;
     const uint32_t wcap = (uint32_t)min<uint64_t>(64, M.n_chunks > wchunk0 ? M.n_chunks - wchunk0 : 0) * M.ev_stride;
     uint32_t hits = 0;        // hits the lane's events stand for (exact while no event stands for more than 15)
     uint32_t E = 0, seq = 0;  // the state as one word (unit.hpp): base | filter << 22 | F1 | NFR | END; 0 = the root
@@ -291,15 +291,24 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             if (ev & !room) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
             const uint64_t pm = __ballot(ev & room);
             const uint32_t my = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-            const v2u rec = {u_child(E) | (uint32_t)lane << 22 | c4 << 28, (uint32_t)(docrel + (int32_t)rel)};
+            // {END state | lane | hits it stands for, end offset in the document, hits of the chunk before it}
+            const uint32_t rx = u_child(E) | (uint32_t)lane << 22 | c4 << 28, ry = (uint32_t)(docrel + (int32_t)rel);
             const bool push = ev & room;
-            if (push && my < 64u) wb[my] = rec;
+            if (push && my < 64u) {
+              wb[my * 3] = rx;
+              wb[my * 3 + 1] = ry;
+              wb[my * 3 + 2] = hits;
+            }
             const uint32_t kp = __popcll(pm);
             if (wfill + kp >= 64u) {
-              const v2u r = wb[lane];
-              if (wout + 64u <= wcap) *reinterpret_cast<v2u *>(wreg + wout + lane) = r;
+              const v3u r = {wb[lane * 3], wb[lane * 3 + 1], wb[lane * 3 + 2]};
+              if (wout + 64u <= wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
               wout += 64u;
-              if (push && my >= 64u) wb[my - 64u] = rec;
+              if (push && my >= 64u) {
+                wb[(my - 64u) * 3] = rx;
+                wb[(my - 64u) * 3 + 1] = ry;
+                wb[(my - 64u) * 3 + 2] = hits;
+              }
             }
             wfill = (wfill + kp) & 63u;
             seq += ev ? 1u : 0u;
@@ -311,8 +320,8 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
       if (need) pos = pb - 4 + rel;
     }
     {  // the rest of the wave's buffer
-      const v2u r = wb[lane];
-      if ((uint32_t)lane < wfill && wout + (uint32_t)lane < wcap) *reinterpret_cast<v2u *>(wreg + wout + lane) = r;
+      const v3u r = {wb[lane * 3], wb[lane * 3 + 1], wb[lane * 3 + 2]};
+      if ((uint32_t)lane < wfill && wout + (uint32_t)lane < wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
     }
     if (live) {
       M.ev_cnt[chunk] = seq;
@@ -358,13 +367,13 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
     uint32_t total = c < M.n_chunks ? min(M.ev_cnt[c], stride) : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
-    const uint2 *src = M.evg + g * 64 * stride;
+    const uint32_t *src = M.evg + g * 64 * stride * 3;
     uint2 *dst = M.evd + g * 64 * stride;
     uint2 nxt[kRgPer];
 #pragma unroll
     for (int q = 0; q < kRgPer; q++) {
       const uint32_t i = q * kRgThreads + threadIdx.x;
-      nxt[q] = i < total ? src[i] : make_uint2(0, 0);
+      nxt[q] = i < total ? make_uint2(src[(size_t)i * 3], src[(size_t)i * 3 + 1]) : make_uint2(0, 0);
     }
     for (uint32_t i0 = 0; i0 < total; i0 += kRgBlock) {
       uint2 rec[kRgPer];
@@ -375,7 +384,8 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
         const uint32_t i = i0 + q * kRgThreads + threadIdx.x;
         live[q] = i < total;
         rec[q] = nxt[q];
-        nxt[q] = i + kRgBlock < total ? src[i + kRgBlock] : make_uint2(0, 0);
+        nxt[q] = i + kRgBlock < total ? make_uint2(src[(size_t)(i + kRgBlock) * 3], src[(size_t)(i + kRgBlock) * 3 + 1])
+                                      : make_uint2(0, 0);
         // key id, or (flattened chains) the offset of its chain, | min(chain length, 255) << 24
         x[q] = live[q] ? A.end_info[rec[q].x & 0x3FFFFFu] : 0u;
       }
@@ -448,152 +458,116 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
 }
 
 // The expansion in one pass over the wave-ordered events (key sets whose output chains hold at most 15 keys: the
-// traversal then knows the hits of every chunk, the bases are scanned before this kernel and nothing has to be put
-// back into per-chunk order in HBM).  A block of 1024 records is sorted by chunk in LDS as in ku_regroup; in sorted
-// order the hits of the block are 64 runs -- one per chunk, each the continuation of the chunk's part of the output
-// -- so an exclusive sum of the records' hit counts places every hit, and consecutive threads write consecutive hits.
+// traversal then knows the hits of every chunk and of every event's predecessors in its chunk -- the record's third
+// word -- so the bases are scanned before this kernel and every record knows where its hits go: nothing has to be put
+// back into order).  Only the stores want order: a wave's 64 records belong to 64 chunks, and a 12-byte store per
+// record is a memory request per record.  So a block of 1024 records stages its hits in LDS chunk by chunk -- the
+// place is the chunk's start in the block (an exclusive sum over the chunks' hit counts, LDS atomics) + the hits of
+// the chunk before the event - the hits of the chunk before the block -- and consecutive threads write consecutive hits.
 // One gather per event: uend[base of the END state] = its key, the key's length and the offset of its flattened
 // output chain (the second and later hits of an event -- rare -- read the chain).
-constexpr int kXgThreads = 256, kXgPer = 4, kXgBlock = kXgThreads * kXgPer, kXgSubs = kXgBlock / 64;
+constexpr int kXgThreads = 256, kXgPer = 4, kXgBlock = kXgThreads * kXgPer, kXgStage = 1536;
 __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend, DevAut A, V2Args M) {
-  __shared__ __attribute__((aligned(16))) uint4 s_rec[kXgBlock];  // sorted: {uend.x, uend.y, end offset, hits}
-  __shared__ uint8_t s_lane[kXgBlock];
-  __shared__ uint32_t s_cnt[kXgSubs][64], s_part[kXgThreads / 64][64];
-  __shared__ uint32_t s_start[64], s_tot[64], s_h[kXgBlock + 1], s_wsum[kXgThreads / 64];
-  __shared__ uint64_t s_base[64];  // where the chunk's next hit goes
+  __shared__ uint32_t s_hs[kXgStage], s_he[kXgStage], s_hk[kXgStage];  // staged hits: start, end, key
+  __shared__ uint8_t s_hl[kXgStage];                                    // ... and the chunk (lane tag) of each
+  __shared__ uint32_t s_tot[2][64], s_start[64], s_run[64], s_all;
+  __shared__ uint64_t s_base[64];  // the chunk's place in the output
   if (M.cursor[1]) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
   const uint32_t stride = M.ev_stride;
-  constexpr int kQ = kXgSubs / (kXgThreads / 64);  // sub-batches per quarter
   for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     __syncthreads();
     const uint64_t c = g * 64 + lane;
-    if (wv == 0) s_base[lane] = c < M.n_chunks ? M.hit_base[c] : 0ull;
+    if (wv == 0) {
+      s_base[lane] = c < M.n_chunks ? M.hit_base[c] : 0ull;
+      s_run[lane] = 0;
+      s_tot[0][lane] = 0;
+    }
     uint32_t total = c < M.n_chunks ? min(M.ev_cnt[c], stride) : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
-    const uint2 *src = M.evg + g * 64 * stride;
-    uint2 nxt[kXgPer];
+    const uint32_t *src = M.evg + g * 64 * stride * 3;
+    typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+    v3u nxt[kXgPer];
 #pragma unroll
     for (int q = 0; q < kXgPer; q++) {
       const uint32_t i = q * kXgThreads + threadIdx.x;
-      nxt[q] = i < total ? src[i] : make_uint2(0, 0);
+      nxt[q] = i < total ? *reinterpret_cast<const v3u *>(src + (size_t)i * 3) : v3u{0, 0, 0};
     }
-    for (uint32_t i0 = 0; i0 < total; i0 += kXgBlock) {
-      uint2 rec[kXgPer], ue[kXgPer];
-      uint32_t rank[kXgPer], l[kXgPer];
+    __syncthreads();
+    uint32_t par = 0;
+    for (uint32_t i0 = 0; i0 < total; i0 += kXgBlock, par ^= 1u) {
+      v3u rec[kXgPer];
+      uint2 ue[kXgPer];
       bool live[kXgPer];
 #pragma unroll
       for (int q = 0; q < kXgPer; q++) {
         const uint32_t i = i0 + q * kXgThreads + threadIdx.x;
         live[q] = i < total;
         rec[q] = nxt[q];
-        nxt[q] = i + kXgBlock < total ? src[i + kXgBlock] : make_uint2(0, 0);
+        nxt[q] = i + kXgBlock < total ? *reinterpret_cast<const v3u *>(src + (size_t)(i + kXgBlock) * 3) : v3u{0, 0, 0};
+#if defined(AHA_XG_LAB) && (AHA_XG_LAB & 2)  // timing only: no gather
+        ue[q] = make_uint2(rec[q].x & 0xFFFFu | 3u << 24, 0);
+#else
         ue[q] = live[q] ? uend[rec[q].x & 0x3FFFFFu] : make_uint2(0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < kXgPer; q++) {
-        l[q] = (rec[q].x >> 22) & 63u;
-        uint64_t same = __ballot(live[q]), mine = same;
-#pragma unroll
-        for (int b = 0; b < 6; b++) {
-          const uint64_t bal = __ballot(live[q] & ((l[q] >> b) & 1u) != 0u);
-          same &= ((l[q] >> b) & 1u) ? bal : ~bal;
-          mine &= ((lane >> b) & 1) ? bal : ~bal;
-        }
-        rank[q] = __popcll(same & ((1ull << lane) - 1ull));
-        s_cnt[q * (kXgThreads / 64) + wv][lane] = __popcll(mine);
-      }
-      __syncthreads();
-      {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int r = 0; r < kQ; r++) {
-          const uint32_t v = s_cnt[wv * kQ + r][lane];
-          s_cnt[wv * kQ + r][lane] = acc;
-          acc += v;
-        }
-        s_part[wv][lane] = acc;
+#endif
+        if (live[q]) atomicAdd(&s_tot[par][(rec[q].x >> 22) & 63u], rec[q].x >> 28);
       }
       __syncthreads();
       if (wv == 0) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < kXgThreads / 64; w2++) {
-          const uint32_t v = s_part[w2][lane];
-          s_part[w2][lane] = acc;
-          acc += v;
-        }
-        s_tot[lane] = acc;
-        s_start[lane] = wave_incl_scan(acc) - acc;
+        const uint32_t t = s_tot[par][lane];
+        const uint32_t incl = wave_incl_scan(t);
+        s_start[lane] = incl - t;
+        if (lane == 63) s_all = incl;
+        s_tot[par ^ 1u][lane] = 0;  // the next block's
       }
       __syncthreads();
-#pragma unroll
-      for (int q = 0; q < kXgPer; q++) {
-        if (live[q]) {
-          const uint32_t sb = q * (kXgThreads / 64) + wv;
-          const uint32_t p = s_start[l[q]] + s_part[sb / kQ][l[q]] + s_cnt[sb][l[q]] + rank[q];
-          s_rec[p] = make_uint4(ue[q].x, ue[q].y, rec[q].y, rec[q].x >> 28);
-          s_lane[p] = (uint8_t)l[q];
-        }
-      }
-      __syncthreads();
-      // hits before every record of the sorted block: a thread owns four consecutive records
-      const uint32_t nb = min(total - i0, (uint32_t)kXgBlock);
-      const uint32_t p0 = threadIdx.x * kXgPer;
-      uint4 r4[kXgPer];
-      uint32_t own = 0;
-#pragma unroll
-      for (int q = 0; q < kXgPer; q++) {
-        r4[q] = p0 + q < nb ? s_rec[p0 + q] : make_uint4(0, 0, 0, 0);
-        own += r4[q].w;
-      }
-      const uint32_t incl = wave_incl_scan(own);
-      if (lane == 63) s_wsum[wv] = incl;
-      __syncthreads();
-      uint32_t h = incl - own;
-#pragma unroll
-      for (int w2 = 0; w2 < kXgThreads / 64; w2++) h += w2 < wv ? s_wsum[w2] : 0u;
-      {
-        uint32_t hh = h;
+      const uint32_t T = s_all;
+      for (uint32_t w0 = 0; w0 < T; w0 += kXgStage) {  // one window unless events stand for many hits
 #pragma unroll
         for (int q = 0; q < kXgPer; q++) {
-          s_h[p0 + q] = hh;
-          hh += r4[q].w;
-        }
-        if (threadIdx.x == kXgThreads - 1) s_h[kXgBlock] = hh;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < kXgPer; q++) {
-        const uint32_t n = r4[q].w;
-        if (n) {
-          const uint32_t lp = s_lane[p0 + q];
-          uint64_t idx = s_base[lp] + (h - s_h[s_start[lp]]);
-          const uint32_t end = r4[q].z;
-          const uint32_t co = r4[q].y & 0xFFFFFFu;
-          // Hit(idx - len + 1, idx + 1, value) ac.cr:271-273: the state's own key, then its output chain (ac.cr:265-278)
-          uint32_t len = (r4[q].x >> 24) | (r4[q].y >> 24) << 8, key = r4[q].x & 0xFFFFFFu;
-          for (uint32_t k = 0;;) {
-            if (idx < M.cap) {
-              aha_hit hit;
-              hit.start = (int32_t)(end - len);
-              hit.end = (int32_t)end;
-              hit.value = (int32_t)key;
-              M.out[idx] = hit;
+          if (live[q]) {
+            const uint32_t l = (rec[q].x >> 22) & 63u, n = rec[q].x >> 28;
+            const uint32_t pos = s_start[l] + (rec[q].z - s_run[l]);
+            const uint32_t end = rec[q].y, co = ue[q].y & 0xFFFFFFu;
+            // Hit(idx - len + 1, idx + 1, value) ac.cr:271-273: the state's own key, then its output chain (ac.cr:265-278)
+            uint32_t len = (ue[q].x >> 24) | (ue[q].y >> 24) << 8, key = ue[q].x & 0xFFFFFFu;
+            for (uint32_t k = 0;;) {
+              const uint32_t j = pos + k - w0;
+              if (j < (uint32_t)kXgStage) {
+                s_hs[j] = end - len;
+                s_he[j] = end;
+                s_hk[j] = key;
+                s_hl[j] = (uint8_t)l;
+              }
+              if (++k >= n) break;
+              const uint2 ce = A.chain[co + k];
+              len = ce.x;
+              key = ce.y;
             }
-            if (++k >= n) break;
-            const uint2 ce = A.chain[co + k];
-            len = ce.x;
-            key = ce.y;
-            idx++;
           }
-          h += n;
         }
+        __syncthreads();
+        const uint32_t nh = min(T - w0, (uint32_t)kXgStage);
+        for (uint32_t j = threadIdx.x; j < nh; j += kXgThreads) {
+          const uint32_t l = s_hl[j];
+          const uint64_t idx = s_base[l] + s_run[l] + (w0 + j - s_start[l]);
+#if defined(AHA_XG_LAB) && (AHA_XG_LAB & 1)  // timing only: no hit stores
+          asm volatile("" ::"v"(s_hs[j]), "v"(s_hk[j]), "v"(idx));
+#else
+          if (idx < M.cap) {
+            aha_hit hit;
+            hit.start = (int32_t)s_hs[j];
+            hit.end = (int32_t)s_he[j];
+            hit.value = (int32_t)s_hk[j];
+            M.out[idx] = hit;
+          }
+#endif
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      if (wv == 0) s_base[lane] += s_h[s_start[lane] + s_tot[lane]] - s_h[s_start[lane]];
+      if (wv == 0) s_run[lane] += s_tot[par][lane];
     }
   }
 }

@@ -29,5 +29,5 @@ for name, corpus in (("three-byte characters only", uni), ("cfg 3 mix", mix)):
     for _ in range(3):
         h = ac.match_batch_device(dc, dd, out, None)
     tm = ac.last_timing()
-    print(f"{os.environ.get('AHA_ENGINE')}: {name}: engine {tm['engine']} traverse {tm['ms_count']:.3f} ms total {tm['ms_total']:.3f} ms hits {h}", flush=True)
+    print(f"{os.environ.get('AHA_ENGINE')}: {name}: engine {tm['engine']} traverse {tm['ms_count']:.3f} ms total {tm['ms_total']:.3f} ms (aux {tm['ms_aux']:.3f}, write {tm['ms_write']:.3f}) hits {h}", flush=True)
     del dc, out

@@ -47,6 +47,11 @@ __device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t g, int64_t 
   return v;
 }
 
+// wave votes straight from the compare's mask (hipcc's __any/__all go through a 0/1 VGPR and a second compare)
+__device__ __forceinline__ uint64_t wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wany(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool wall(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
 __host__ __device__ inline size_t u_lds_rows(uint32_t n_syms) {  // decode tables, root table, input rows
   return (size_t)(kUTabWords + ((n_syms + 3u) & ~3u)) * 4 + (size_t)(kV2Threads / 64) * kUWave + 16;
 }
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   uint8_t *inl = in_base + wave * kUWave + lane * kURow;
   const uint32_t *row = reinterpret_cast<const uint32_t *>(inl);
   typedef uint32_t v3u __attribute__((ext_vector_type(3)));
-  uint32_t *wb = reinterpret_cast<uint32_t *>(smem + u_lds_rows(U.n_syms)) + wave * 64 * 3;  // the wave's event buffer
+  uint32_t *wb = reinterpret_cast<uint32_t *>(smem + (uint32_t)u_lds_rows(U.n_syms) + (uint32_t)wave * (64u * 12u));  // the wave's event buffer
   const uint2 *slots = U.slots;
   const int64_t N = (int64_t)M.n_bytes;
   const uint64_t D = M.n_docs;
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
         for (int i = 0; i < 13; i++) dst[i] = w[i];
       }
       const bool need = live && pos < pend;
-      if (!__any(need)) continue;
+      if (!wany(need)) continue;
       // row coordinates: text position = pb - 4 + rel; inactive: rel >= lim; a unit whose bytes are not all in the
       // window yet is left for a later round (the lane parks)
       uint32_t rel = kURow, lim = 0;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
 
       for (;;) {  // outer: resolve document boundaries, then run the trips up to the next one
         const bool bnd = rel < lim && rel == nb_rel;
-        if (__any(bnd)) {  // rare: a document starts here (ac.cr:177: the state is per sequence)
+        if (wany(bnd)) {  // rare: a document starts here (ac.cr:177: the state is per sequence)
           if (bnd) {
             const int64_t here = pb - 4 + rel;
             do {
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
         // would have, where its second and third byte are looked up (a poison value unless they are continuation
         // bytes) and the window of its class; the sum is the symbol when it falls into that window.  Three dependent
         // LDS reads: the hot loop decodes the NEXT unit while the current one is probed, so they are off its chain.
-        auto decode = [&](uint32_t at, uint32_t &o_code, uint32_t &o_L, bool &o_good, bool &o_later) {
+        auto decode = [&](uint32_t at, uint32_t &o_code, uint32_t &o_L, bool &o_later) {
           const uint32_t lo = row[at >> 2], hi = row[(at >> 2) + 1];
           const uint32_t w4 = __builtin_amdgcn_alignbyte(hi, lo, at & 3u);
           const uint32_t b0 = w4 & 0xFFu;
@@ -201,24 +206,25 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
           const bool in_doc = at + want <= dend;      // else: a lead byte without its continuation bytes (bad)
           o_later = in_doc & at + want > (uint32_t)kURow;  // its bytes are not all staged yet: next round
           const bool whole = in_doc & sum < kUPoison;  // a well-formed unit
-          o_good = whole & (sum - q0.w) < q1.x;        // ... of the keys' alphabet
+          const bool o_good = whole & (sum - q0.w) < q1.x;  // ... of the keys' alphabet
           o_L = whole ? want : 1u;
           o_code = o_good ? sum - kUBias : 0u;         // symbol 0 has no transition anywhere
         };
         uint32_t code, L;
-        bool good, later;
-        decode(min(rel, (uint32_t)kURow), code, L, good, later);
+        bool later;
+        decode(min(rel, (uint32_t)kURow), code, L, later);
         bool all_left = false;  // every lane has left the oldest piece (or has nothing more to do): next round
         for (;;) {
           const bool act = rel < lim2;
-          all_left = __all(rel >= (uint32_t)(4 + kUPiece) || rel >= lim);
-          if (all_left || !__any(act)) break;
+          all_left = wall(rel >= (uint32_t)(4 + kUPiece) || rel >= lim);
+          if (all_left || !wany(act)) break;
           bool ev = false;
           uint32_t c4 = 0;  // hits the event stands for (a one-character state: its own key and no more)
           if (act) {
             uint32_t n_code, n_L;
-            bool n_good, n_later;
-            decode(rel + L, n_code, n_L, n_good, n_later);  // rows are padded: rel + 3 + 8 bytes stay inside LDS
+            bool n_later;
+            const bool good = code != 0u;
+            decode(rel + L, n_code, n_L, n_later);  // rows are padded: rel + 3 + 8 bytes stay inside LDS
             // Every select below picks between values that are already computed (plain locals): that keeps them
             // v_cndmask instead of nested divergent branches, which cost more than the work they skip.
             // ---- the root's transitions (LDS) on the unit (symbol 0 -- a bad unit or one outside the alphabet -- has
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const bool fall_far = fall & !u_f1(E);
 #endif
             uint32_t ft = rf & 0x7FFFFFFFu;  // (falling into a state reports nothing: END is not carried)
-            if (__any(fall_far)) {
+            if (wany(fall_far)) {
               const uint32_t fx = U.fail_tab[fall_far ? Bq : 0u];
               ft = fall_far ? fx : ft;
             }
@@ -276,7 +282,6 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             lim = later ? rel : lim;
             code = consumed ? n_code : code;  // (a trip that falls to the fail state tries the same unit again)
             L = consumed ? n_L : L;
-            good = consumed ? n_good : good;
             later = consumed ? n_later : later;
             const int32_t last = (int32_t)rel - 1;  // row index of the unit's last byte
             // is_end? -> fetch later (ac.cr:183-185); this lane reports the end positions in [a, e)
@@ -285,11 +290,10 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             ev = false;
 #endif
           }
-          const uint64_t evm = __ballot(ev);
+          const uint64_t evm = wballot(ev);
           if (evm) {
             const bool room = seq < ev_stride;  // a lane never sends more than its region holds: the wave's part cannot overflow
-            if (ev & !room) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
-            const uint64_t pm = __ballot(ev & room);
+            const uint64_t pm = wballot(ev & room);
             const uint32_t my = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
             // {END state | lane | hits it stands for, end offset in the document, hits of the chunk before it}
             const uint32_t rx = u_child(E) | (uint32_t)lane << 22 | c4 << 28, ry = (uint32_t)(docrel + (int32_t)rel);
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             hits += ev ? c4 : 0u;
           }
         }
-        if (all_left || !__any(rel < lim)) break;
+        if (all_left || !wany(rel < lim)) break;
       }
       if (need) pos = pb - 4 + rel;
     }
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
     }
     if (live) {
       M.ev_cnt[chunk] = seq;
+      if (seq > ev_stride) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
       M.chunk_hits[chunk] = hits;  // (ku_regroup counts again where chains are longer than the record's field)
       if (e == N) {  // documents that start at N (empty tail documents, and d = D)
         while (dn <= D) {

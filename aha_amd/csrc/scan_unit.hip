@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   uint8_t *inl = in_base + wave * kUWave + lane * kURow;
   const uint32_t *row = reinterpret_cast<const uint32_t *>(inl);
   typedef uint32_t v3u __attribute__((ext_vector_type(3)));
-  uint32_t *wb = reinterpret_cast<uint32_t *>(smem + (uint32_t)u_lds_rows(U.n_syms) + (uint32_t)wave * (64u * 12u));  // the wave's event buffer
+  const uint32_t wbo = (uint32_t)u_lds_rows(U.n_syms) + (uint32_t)wave * (64u * 12u);  // the wave's event buffer (byte offset)
   const uint2 *slots = U.slots;
   const int64_t N = (int64_t)M.n_bytes;
   const uint64_t D = M.n_docs;
@@ -211,15 +211,18 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
           o_code = o_good ? sum - kUBias : 0u;         // symbol 0 has no transition anywhere
         };
         uint32_t code, L;
-        bool later;
-        decode(min(rel, (uint32_t)kURow), code, L, later);
+        {
+          bool later;  // the unit's bytes are not all staged yet: the lane parks until the next round brings the rest
+          decode(min(rel, (uint32_t)kURow), code, L, later);
+          lim2 = later ? min(lim2, rel) : lim2;
+          lim = later ? min(lim, rel) : lim;
+        }
         bool all_left = false;  // every lane has left the oldest piece (or has nothing more to do): next round
         for (;;) {
           const bool act = rel < lim2;
           all_left = wall(rel >= (uint32_t)(4 + kUPiece) || rel >= lim);
           if (all_left || !wany(act)) break;
-          bool ev = false;
-          uint32_t c4 = 0;  // hits the event stands for (a one-character state: its own key and no more)
+          uint32_t evc = 0;  // the lane reports: the hits the event stands for (a one-character state: its own key and no more)
           if (act) {
             uint32_t n_code, n_L;
             bool n_later;
@@ -235,88 +238,67 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             // ---- the state's own transition: at most one 8-byte probe.  The state word carries a filter over the
             // symbols the state continues on: a clear bit is a miss without the probe (the root's word is 0)
             const uint32_t Bq = u_child(E);
-#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 2  // timing only: states with a region of their own are never probed
-            const bool probe = good & !later & ((u_filter(E) >> (code & 7u)) & 1u) != 0u & Bq != 0u & Bq < U.n_shared;
-#elif defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 4  // timing only: no probe at all
-            const bool probe = false;
-#else
-            const bool probe = good & !later & ((u_filter(E) >> (code & 7u)) & 1u) != 0u & Bq != 0u;
-#endif
-#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 5  // timing only: a big state's probes fall into 8 KiB of its region
-            const uint2 en = slots[probe ? (Bq >= U.n_shared ? Bq + (code & 1023u) : (Bq ^ code)) : 0u];
-#elif defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 6  // timing only: ... into half of its region
-            const uint2 en = slots[probe ? (Bq >= U.n_shared ? Bq + (code >> 1) : (Bq ^ code)) : 0u];
-#else
+            const bool probe = good & ((u_filter(E) >> (code & 7u)) & 1u) != 0u & Bq != 0u;
             const uint2 en = slots[probe ? (Bq ^ code) : 0u];
-#endif
             const bool hit = probe & u_sym(en.y) == code;
             // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip;
             // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or -- rare -- the
             // side array in HBM
-#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 1  // timing only: every miss is answered by the root (no fall path)
-            const bool viaroot = !hit & !later;
-#else
-            const bool viaroot = !hit & !later & (!u_nfr(E) | !good);
-#endif
-            const bool fall = !hit & !viaroot & !later;
-#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 7  // timing only: no fail link comes from the side array
-            const bool fall_far = false;
-#else
-            const bool fall_far = fall & !u_f1(E);
-#endif
+            const bool viaroot = !hit & (!u_nfr(E) | !good);
+            const bool fall = !hit & !viaroot;
+            const uint32_t ffb = (fall & !u_f1(E)) ? Bq : 0u;  // (a state with a fail link is not the root: its base is not 0)
             uint32_t ft = rf & 0x7FFFFFFFu;  // (falling into a state reports nothing: END is not carried)
-            if (wany(fall_far)) {
-              const uint32_t fx = U.fail_tab[fall_far ? Bq : 0u];
-              ft = fall_far ? fx : ft;
+            if (wany(ffb != 0u)) {
+              const uint32_t fx = U.fail_tab[ffb];
+              ft = ffb != 0u ? fx : ft;
             }
             const uint32_t missE = viaroot ? rt : ft;
-            const uint32_t newE = hit ? en.x : missE;
-            E = later ? E : newE;
+            E = hit ? en.x : missE;
             const bool consumed = hit | viaroot;
-            const bool end = consumed & u_end(newE);
-            c4 = hit ? u_c4(en.y) : 1u;
+            const bool end = consumed & u_end(E);
+            const uint32_t c4 = hit ? u_c4(en.y) : 1u;
             pc = consumed ? code : pc;
             const uint32_t adv = consumed ? L : 0u;
             rel += adv;
-            lim2 = later ? rel : lim2;  // parked until the next round brings the rest of the unit
-            lim = later ? rel : lim;
+            const bool park = consumed & n_later;  // the next unit waits for the next round
+            lim2 = park ? rel : lim2;
+            lim = park ? rel : lim;
             code = consumed ? n_code : code;  // (a trip that falls to the fail state tries the same unit again)
             L = consumed ? n_L : L;
-            later = consumed ? n_later : later;
             const int32_t last = (int32_t)rel - 1;  // row index of the unit's last byte
             // is_end? -> fetch later (ac.cr:183-185); this lane reports the end positions in [a, e)
-            ev = end & last >= a_rel & last < e_rel;
-#if defined(AHA_UNIT_LAB) && AHA_UNIT_LAB == 8  // timing only: nothing is reported
-            ev = false;
-#endif
+            evc = (end & last >= a_rel & last < e_rel) ? c4 : 0u;
           }
-          const uint64_t evm = wballot(ev);
+          const uint64_t evm = wballot(evc != 0u);
           if (evm) {
-            const bool room = seq < ev_stride;  // a lane never sends more than its region holds: the wave's part cannot overflow
-            const uint64_t pm = wballot(ev & room);
-            const uint32_t my = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+            // (a lane may send more than its region holds -- the call is repeated with larger regions then, see below --
+            // but a wave never writes beyond its part: blocks past it are dropped)
+            const bool ev = evc != 0u;
+            const uint32_t my = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(evm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)evm, 0u));
             // {END state | lane | hits it stands for, end offset in the document, hits of the chunk before it}
-            const uint32_t rx = u_child(E) | (uint32_t)lane << 22 | c4 << 28, ry = (uint32_t)(docrel + (int32_t)rel);
-            const bool push = ev & room;
-            if (push && my < 64u) {
-              wb[my * 3] = rx;
-              wb[my * 3 + 1] = ry;
-              wb[my * 3 + 2] = hits;
+            const uint32_t rx = u_child(E) | (uint32_t)lane << 22 | evc << 28, ry = (uint32_t)(docrel + (int32_t)rel);
+            if (ev && my < 64u) {
+              uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + my * 12u));
+              d[0] = rx;
+              d[1] = ry;
+              d[2] = hits;
             }
-            const uint32_t kp = __popcll(pm);
+            const uint32_t kp = __popcll(evm);
             if (wfill + kp >= 64u) {
-              const v3u r = {wb[lane * 3], wb[lane * 3 + 1], wb[lane * 3 + 2]};
+              const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (wbo + (uint32_t)lane * 12u));
+              const v3u r = {q[0], q[1], q[2]};
               if (wout + 64u <= wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
               wout += 64u;
-              if (push && my >= 64u) {
-                wb[(my - 64u) * 3] = rx;
-                wb[(my - 64u) * 3 + 1] = ry;
-                wb[(my - 64u) * 3 + 2] = hits;
+              if (ev && my >= 64u) {
+                uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + (my - 64u) * 12u));
+                d[0] = rx;
+                d[1] = ry;
+                d[2] = hits;
               }
             }
             wfill = (wfill + kp) & 63u;
             seq += ev ? 1u : 0u;
-            hits += ev ? c4 : 0u;
+            hits += evc;
           }
         }
         if (all_left || !wany(rel < lim)) break;
@@ -324,7 +306,8 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
       if (need) pos = pb - 4 + rel;
     }
     {  // the rest of the wave's buffer
-      const v3u r = {wb[lane * 3], wb[lane * 3 + 1], wb[lane * 3 + 2]};
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (wbo + (uint32_t)lane * 12u));
+      const v3u r = {q[0], q[1], q[2]};
       if ((uint32_t)lane < wfill && wout + (uint32_t)lane < wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
     }
     if (live) {

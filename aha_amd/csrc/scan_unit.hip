@@ -238,20 +238,21 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             // ---- the state's own transition: at most one 8-byte probe.  The state word carries a filter over the
             // symbols the state continues on: a clear bit is a miss without the probe (the root's word is 0)
             const uint32_t Bq = u_child(E);
-            const bool probe = good & ((u_filter(E) >> (code & 7u)) & 1u) != 0u & Bq != 0u;
+            // (bit 29 -- F1 -- stands in for the filter's eighth bit, which is always set)
+            const bool probe = good & (((E | 0x20000000u) >> (22u + (code & 7u))) & 1u) != 0u & Bq != 0u;
             const uint2 en = slots[probe ? (Bq ^ code) : 0u];
+            // the fail link of a state that fails neither to the root nor to a one-character state comes from a side
+            // array in HBM: rare per lane, but some lane of a wave needs it in every other trip -- so it is requested
+            // beside the probe, not after it, by every lane in such a state (a state with a fail link is not the
+            // root: its base is not 0)
+            const uint32_t ffb = ((E >> 29) & 3u) == 2u ? Bq : 0u;  // NFR and not F1
+            uint32_t fx = 0;
+            if (wany(ffb != 0u)) fx = U.fail_tab[ffb];
             const bool hit = probe & u_sym(en.y) == code;
             // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip;
-            // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or -- rare -- the
-            // side array in HBM
+            // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or the side array's word
             const bool viaroot = !hit & (!u_nfr(E) | !good);
-            const bool fall = !hit & !viaroot;
-            const uint32_t ffb = (fall & !u_f1(E)) ? Bq : 0u;  // (a state with a fail link is not the root: its base is not 0)
-            uint32_t ft = rf & 0x7FFFFFFFu;  // (falling into a state reports nothing: END is not carried)
-            if (wany(ffb != 0u)) {
-              const uint32_t fx = U.fail_tab[ffb];
-              ft = ffb != 0u ? fx : ft;
-            }
+            const uint32_t ft = ffb != 0u ? fx : (rf & 0x7FFFFFFFu);  // (falling into a state reports nothing: END is not carried)
             const uint32_t missE = viaroot ? rt : ft;
             E = hit ? en.x : missE;
             const bool consumed = hit | viaroot;
@@ -278,19 +279,19 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             // {END state | lane | hits it stands for, end offset in the document, hits of the chunk before it}
             const uint32_t rx = u_child(E) | (uint32_t)lane << 22 | evc << 28, ry = (uint32_t)(docrel + (int32_t)rel);
             if (ev && my < 64u) {
-              uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + my * 12u));
+              uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + __umul24(my, 12u)));
               d[0] = rx;
               d[1] = ry;
               d[2] = hits;
             }
             const uint32_t kp = __popcll(evm);
             if (wfill + kp >= 64u) {
-              const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (wbo + (uint32_t)lane * 12u));
+              const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (wbo + __umul24((uint32_t)lane, 12u)));
               const v3u r = {q[0], q[1], q[2]};
               if (wout + 64u <= wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
               wout += 64u;
               if (ev && my >= 64u) {
-                uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + (my - 64u) * 12u));
+                uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + __umul24(my - 64u, 12u)));
                 d[0] = rx;
                 d[1] = ry;
                 d[2] = hits;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
       if (need) pos = pb - 4 + rel;
     }
     {  // the rest of the wave's buffer
-      const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (wbo + (uint32_t)lane * 12u));
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (wbo + __umul24((uint32_t)lane, 12u)));
       const v3u r = {q[0], q[1], q[2]};
       if ((uint32_t)lane < wfill && wout + (uint32_t)lane < wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
     }

@@ -386,7 +386,13 @@ def main():
     avg = {k: float(np.mean(v)) for k, v in kern.items()}
     engine = ac.last_timing()["engine"]
     A = info["image_bytes"]
-    if engine == 2:
+    if engine == 4:
+        # ku_traverse (character-level image): corpus + doc offsets + the unit image in (8-byte slots, the side array of
+        # fail words, the root table and the decode tables); its event records are scratch
+        dom, dom_ms = "ku_traverse", avg["ms_count"]
+        A = info["unit_slots"] * 12 + info["unit_syms"] * 4 + 11264
+        alg_bytes = n_bytes + 8 * (D + 1) + A
+    elif engine == 2:
         # k2_traverse: corpus + doc offsets + automaton image in; its event records are scratch
         dom, dom_ms = "k2_traverse", avg["ms_count"]
         alg_bytes = n_bytes + 8 * (D + 1) + A

@@ -20,7 +20,7 @@ out = {"_note": note, "config": 3, "bytes_per_gpu": 1 << 30, "git_head": head + 
 
 
 def short(k):
-    m = re.search(r"(k2?d?_[a-z_]+)", k)
+    m = re.search(r"(k[2u]?d?_[a-z_0-9]+)", k)
     return m.group(1) if m else None
 
 
@@ -41,11 +41,11 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
 # the traversal's FETCH_SIZE is corrected by that factor; the rest (random 4-byte table loads = 64-byte requests,
 # 8-byte event stores) is quoted as counted.
 INPUT_REPORTED_FRACTION = 0.8953e9 / (1 << 30)
-out["_note"] += (" k2_traverse: hbm_bytes_per_launch = FETCH_SIZE*1024 + corpus*(1-%.3f) [calibration of the staging "
+out["_note"] += (" k2_traverse / ku_traverse (the same 16-byte staging loads): hbm_bytes_per_launch = FETCH_SIZE*1024 + corpus*(1-%.3f) [calibration of the staging "
                  "loads, tools/calib_fetch.py] + WRITE_SIZE*1024." % INPUT_REPORTED_FRACTION)
 for k, d in out["kernels"].items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        corr = out["bytes_per_gpu"] * (1 - INPUT_REPORTED_FRACTION) if k == "k2_traverse" else 0
+        corr = out["bytes_per_gpu"] * (1 - INPUT_REPORTED_FRACTION) if k in ("k2_traverse", "ku_traverse") else 0
         d["hbm_bytes_per_launch"] = int((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024 + corr)
 json.dump(out, open(f"profiles/{rnd}_pmc.json", "w"), indent=1)
 json.dump(out, open("profiles/pmc_traffic_latest.json", "w"), indent=1)
@@ -55,4 +55,4 @@ st = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(st[0], f"profiles/{rnd}_rocprofv3_kernel_stats.csv")
 b = json.load(open(os.path.join(src, "bench.json")))
 print(b["value"], b["m_hits_per_s"], b["roofline"], b["cpu_baseline"])
-print(out["kernels"].get("k2_traverse"))
+print(out["kernels"].get("ku_traverse") or out["kernels"].get("k2_traverse"))

@@ -496,11 +496,7 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
         live[q] = i < total;
         rec[q] = nxt[q];
         nxt[q] = i + kXgBlock < total ? *reinterpret_cast<const v3u *>(src + (size_t)(i + kXgBlock) * 3) : v3u{0, 0, 0};
-#if defined(AHA_XG_LAB) && (AHA_XG_LAB & 2)  // timing only: no gather
-        ue[q] = make_uint2(rec[q].x & 0xFFFFu | 3u << 24, 0);
-#else
         ue[q] = live[q] ? uend[rec[q].x & 0x3FFFFFu] : make_uint2(0, 0);
-#endif
         if (live[q]) atomicAdd(&s_tot[par][(rec[q].x >> 22) & 63u], rec[q].x >> 28);
       }
       __syncthreads();
@@ -542,9 +538,6 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
         for (uint32_t j = threadIdx.x; j < nh; j += kXgThreads) {
           const uint32_t l = s_hl[j];
           const uint64_t idx = s_base[l] + s_run[l] + (w0 + j - s_start[l]);
-#if defined(AHA_XG_LAB) && (AHA_XG_LAB & 1)  // timing only: no hit stores
-          asm volatile("" ::"v"(s_hs[j]), "v"(s_hk[j]), "v"(idx));
-#else
           if (idx < M.cap) {
             aha_hit hit;
             hit.start = (int32_t)s_hs[j];
@@ -552,7 +545,6 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
             hit.value = (int32_t)s_hk[j];
             M.out[idx] = hit;
           }
-#endif
         }
         __syncthreads();
       }

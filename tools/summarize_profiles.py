@@ -53,6 +53,24 @@ shutil.copy(os.path.join(src, "bench.json"), f"profiles/{rnd}_bench_cfg3.json")
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), f"profiles/{rnd}_bench_under_rocprof.json")
 st = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(st[0], f"profiles/{rnd}_rocprofv3_kernel_stats.csv")
+# the stats CSV averages over every launch of the process (small parity subsets and capacity probes included): the
+# full-size launches -- the timed steps and their warm-ups -- are picked out of the kernel trace by their duration
+tr = glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv"))
+if tr:
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr[0])):
+        k = short(r["Kernel_Name"]) if "aha::" in r["Kernel_Name"] else None
+        if k:
+            per[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    u = json.load(open(os.path.join(src, "bench_under_rocprof.json")))
+    with open(f"profiles/{rnd}_kernel_trace_full_size.txt", "w") as fo:
+        fo.write("# rocprofv3 --kernel-trace of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`: launches longer than half\n"
+                 "# the kernel's longest one (= the full-size launches of the timed steps, warm-ups and parity pass), ms\n"
+                 f"# bench.py's own HIP-event average in the same process: {u['roofline']['kernel']} {u['roofline']['avg_ms']} ms\n")
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            big = [x for x in v if x > 0.5 * max(v)]
+            fo.write(f"{k:20s} launches {len(v):4d}  full-size {len(big):3d}  mean {sum(big) / len(big):8.4f}  "
+                     f"min {min(big):8.4f}  max {max(big):8.4f}\n")
 b = json.load(open(os.path.join(src, "bench.json")))
 print(b["value"], b["m_hits_per_s"], b["roofline"], b["cpu_baseline"])
 print(out["kernels"].get("ku_traverse") or out["kernels"].get("k2_traverse"))

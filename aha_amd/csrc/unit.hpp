@@ -64,7 +64,8 @@ namespace aha {
 
 constexpr uint32_t kUMaxSlots = 1u << 22;
 constexpr uint32_t kUBigDegree = 48;     // transitions from which on a state gets a region of its own
-constexpr uint32_t kUMaxSyms = 29000;    // (< 2^15: a big state's region holds every symbol)    // root table (4 bytes per symbol) + input rows + decode tables fit 160 KiB of LDS
+constexpr uint32_t kUMaxSyms = 21756;    // root table (4 bytes per symbol) + decode tables + input rows + the waves' event buffers fit 160 KiB of
+                                         // LDS (scan_unit.hip u_lds); < 2^15: a big state's region holds every symbol
 constexpr uint32_t kUBias = 1u << 17;    // decode sums are kept non-negative
 constexpr uint32_t kUPoison = 1u << 24;  // contribution of a byte that is not a continuation byte where one must be
 // decode tables, in 32-bit words: T0a[256] {a1 byte offset, a2 byte offset, biased base, biased first symbol},

@@ -68,6 +68,23 @@ lib LibAhaHip
                          params : MatchParams*, out : Hit*, cap : UInt64,
                          doc_hit_offsets : UInt64*, n_hits : UInt64*) : Int32
 
+  # device-resident batches: upload a corpus once, match it many times, keep the hits in HBM until they are wanted
+  fun aha_ac_match_batch_device(ac : Ac, d_corpus : UInt8*, d_doc_offsets : UInt64*, n_docs : UInt64, n_bytes : UInt64,
+                                params : MatchParams*, d_out : Hit*, cap : UInt64, d_doc_hit_offsets : UInt64*,
+                                n_hits : UInt64*, stream : Void*) : Int32
+  fun aha_buffer_alloc(device : Int32, bytes : UInt64, d_ptr : Void**) : Int32
+  fun aha_buffer_free(device : Int32, d_ptr : Void*) : Int32
+  fun aha_buffer_upload(device : Int32, d_dst : Void*, src : Void*, bytes : UInt64) : Int32
+  fun aha_buffer_download(device : Int32, dst : Void*, d_src : Void*, bytes : UInt64) : Int32
+  type Corpus = Void*
+  fun aha_corpus_upload(device : Int32, corpus : UInt8*, doc_offsets : UInt64*, n_docs : UInt64, out : Corpus*) : Int32
+  fun aha_corpus_free(c : Corpus) : Void
+  fun aha_corpus_bytes(c : Corpus) : UInt8*
+  fun aha_corpus_doc_offsets(c : Corpus) : UInt64*
+  fun aha_corpus_n_docs(c : Corpus) : UInt64
+  fun aha_corpus_n_bytes(c : Corpus) : UInt64
+  fun aha_corpus_device(c : Corpus) : Int32
+
   type Group = Void*
   fun aha_group_compile(key_bytes : UInt8*, key_offsets : UInt64*, n_keys : UInt32,
                         devices : Int32*, n_devices : Int32, flags : UInt32,

@@ -473,13 +473,14 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
                       n_blk * 8,          16 * 8,             M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
                       M.chars ? M.n_chunks * 4 : 0, M.chars ? M.n_chunks * 4 : 0, M.chars ? (M.n_docs + 1) * 4 : 0,
                       M.chars ? M.n_chunks * 8 : 0,
-                      (unit && ac->unit_fused) ? 0 : n_reg * 8, unit ? n_reg * 12 : 0, direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
-                      unit ? (M.n_docs + 1) * 4 : 0, 0, 0, 0};
+                      (unit && ac->unit_fused) ? 0 : n_reg * 8, 0 /* [17]: aligned copy of an unaligned corpus */,
+                      direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
+                      unit ? (M.n_docs + 1) * 4 : 0, unit ? n_reg * 12 : 0, 0, 0};
   for (int i = 0; i < 24; i++) {
     if (!sizes[i]) continue;
     if ((rc = v2_reserve(ac, sc, i, sizes[i]))) {
       // no room for the event regions (someone else holds the HBM): the slab pipeline needs far less temp
-      if ((i == 16 || i == 17) && mode != kSlabs) {
+      if ((i == 16 || i == 21) && mode != kSlabs) {
         (void)hipGetLastError();
         return match_v2(ac, sc, M1, s, n_hits, kSlabs);
       }
@@ -504,7 +505,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.doc_lead_rank = (uint32_t *)sc->v2buf[14].p;
   M.lead_base = (uint64_t *)sc->v2buf[15].p;
   M.evd = (uint2 *)sc->v2buf[16].p;
-  M.evg = (uint32_t *)sc->v2buf[17].p;
+  M.evg = (uint32_t *)sc->v2buf[21].p;
   M.doc_hit_rank = (uint32_t *)sc->v2buf[20].p;
   M.chunk_hits = (uint32_t *)sc->v2buf[18].p;
   M.hit_base = (uint64_t *)sc->v2buf[19].p;
@@ -604,10 +605,23 @@ int32_t ensure_stale(aha_ac *ac) {
     cedar_stale_ends(ac->aut, ac->stale_states);
     ac->dev_longest = ac->dev;
     ac->dev_longest.stale_bits = nullptr;
-    if (ac->device < 0 || ac->stale_states.empty()) return;
+    ac->dev_longest.term_bits = nullptr;
+    if (ac->device < 0) return;
+    DeviceGuard g(ac->device);
+    // states whose Cedar node keeps its value in a label-0 child (they end a key and have children): what a NUL byte
+    // of the text reaches there (kernels.hip, kValueNode)
+    const Automaton &a = ac->aut;
+    std::vector<uint32_t> term(((size_t)ac->n_slots + 31) / 32, 0u);
+    bool any_term = false;
+    for (uint32_t s = 1; s < a.n_states; s++)
+      if (a.key_of[s] >= 0 && a.n_child[s] > 0) {
+        term[ac->state_base[s] >> 5] |= 1u << (ac->state_base[s] & 31);
+        any_term = true;
+      }
+    if (any_term && (ac->stale_rc = upload(ac, term, &ac->dev_longest.term_bits))) return;
+    if (ac->stale_states.empty()) return;
     std::vector<uint32_t> bits(((size_t)ac->n_slots + 31) / 32, 0u);
     for (uint32_t s : ac->stale_states) bits[ac->state_base[s] >> 5] |= 1u << (ac->state_base[s] & 31);
-    DeviceGuard g(ac->device);
     ac->stale_rc = upload(ac, bits, &ac->dev_longest.stale_bits);
   });
   return ac->stale_rc;
@@ -1118,7 +1132,16 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
   M.doc_hit_off = d_doc_hit_offsets;
   if (longest) {
     // match_longest: count -> scan -> write, like the two-pass engine (kernels.hip)
-    const int mode = longest == 1 ? 1 : (M.chars ? 3 : 2);
+    int mode = longest == 1 ? 1 : (M.chars ? 3 : 2);
+    if ((rc = ensure_scratch(ac, sc, 1, 1, n_docs))) return rc;
+    if (mode == 2) {
+      // the chunked form is exact only for text without NUL bytes (kernels.hip, k_has_nul): look first
+      HIPCHK(ac, hipMemsetAsync(sc->d_totals, 0, 2 * sizeof(uint64_t), s));
+      launch_has_nul(d_corpus, n_bytes, sc->d_totals + 1, s);
+      HIPCHK(ac, hipMemcpyAsync(sc->h_totals, sc->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+      HIPCHK(ac, hipStreamSynchronize(s));
+      if (sc->h_totals[1]) mode = 3;
+    }
     M.chunk = 1024;
     while (M.chunk < 16ull * ac->aut.max_key_len && M.chunk < (1u << 20)) M.chunk *= 2;  // the warm-up is 2 * Lmax
     M.n_chunks = (n_bytes + M.chunk - 1) / M.chunk;

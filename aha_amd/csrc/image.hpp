@@ -35,6 +35,8 @@ struct DevAut {
   // match_longest only: bit B set <=> the state with base B carries one of Cedar's stale END flags (cedar_replay.cpp);
   // null when there is none
   const uint32_t *stale_bits;
+  const uint32_t *term_bits;   // match_longest: one bit per slot, set at the base of a state that ends a key AND has children
+                               // (its Cedar node keeps the value in a label-0 child, which a NUL byte reaches; kernels.hip)
 };
 
 struct MatchArgs {
@@ -171,6 +173,7 @@ void launch_docg(const MatchArgs &M, void *stream);
 void launch_write(const DevAut &A, const MatchArgs &M, void *stream);
 // match_longest (ac.cr:118-143): mode 1 = intersectable false (a thread per document), 2 = true (a thread per chunk,
 // byte offsets), 3 = true with a thread per document (char offsets)
+void launch_has_nul(const uint8_t *text, uint64_t n, uint64_t *flag, void *stream);  // *flag = 1 when the text holds a NUL byte
 void launch_longest(const DevAut &A, const MatchArgs &M, int mode, bool write, void *stream);
 
 }  // namespace aha

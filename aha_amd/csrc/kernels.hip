@@ -226,7 +226,15 @@ __global__ __launch_bounds__(kBlock) void k_write(DevAut A, MatchArgs M) {
 // an evicted node (a slot reused inside resolve, cedar.cr:642-648): such a stale end replaces the pending end by one
 // for which fetch_one yields nothing, and still resets the state when it is "yielded".  Which states are stale follows
 // from Cedar's slot history, replayed on the host (cedar_replay.cpp): A.stale_bits, one bit per slot at the state's base.
+// A NUL byte (keys hold none, cedar.cr:235) is not simply a miss here: a Cedar node that holds a value AND has children
+// keeps the value in a child with label 0, which `child` finds like any other (cedar.cr:441-447).  That node has no
+// children of its own, so is_end? holds for it (cedar.cr:657-660) -- it REPLACES the pending end by one that yields
+// nothing (fetch_one finds no output) -- and compile's BFS skips it (cedar.cr:450-463), so its fail link is unset: the
+// byte after it is consumed at the root without a goto (defined for intersectable = false; for true the reference
+// reads array[-1] there and the oracle pins the same).  A.term_bits marks the states with such a child (they end a
+// key and have children), kValueNode is the state "in it".
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;  // a pending end that yields nothing
+constexpr uint32_t kValueNode = 0xFFFFFFFEu;
 struct Pending {
   int64_t p = -1;      // absolute position of the pending end (-1: none)
   uint32_t key = 0;
@@ -239,9 +247,22 @@ __device__ __forceinline__ bool longest_step(const DevAut &A, uint32_t &B, const
                                              bool intersectable, Pending &pend, Pending *out) {
   const uint32_t b = *tp;
   bool yielded = false;
+  if (B == kValueNode) {  // no goto from it, no fail link: the pending (empty) end is yielded, the byte is gone
+    *out = pend;
+    pend.p = -1;
+    B = A.root;
+    return true;
+  }
   for (;;) {
     uint32_t key = 0;
-    const int r = b ? Probe<COMPACT>::go(A, B, b, key) : 0;  // a NUL byte has no goto anywhere (keys hold none)
+    if (b == 0 && A.term_bits && ((A.term_bits[B >> 5] >> (B & 31)) & 1u)) {
+      B = kValueNode;
+      pend.p = p;
+      pend.key = kNoKey;
+      pend.endc = lc;
+      break;
+    }
+    const int r = b ? Probe<COMPACT>::go(A, B, b, key) : 0;  // a NUL byte has no other goto (keys hold none)
     if (r) {
       if (r == 2) {
         pend.p = p;
@@ -385,6 +406,27 @@ __global__ __launch_bounds__(kBlock) void k_longest_chunks(DevAut A, MatchArgs M
     block_excl_scan<uint64_t>(hits, sm, &tot);
     if (threadIdx.x == 0) M.blk_hits[blockIdx.x] = tot;
   }
+}
+
+// Is there a NUL byte in the text?  The chunked form of match_longest (a thread per chunk with a warm-up) relies on the
+// state being a function of the last Lmax bytes; a NUL makes the byte after it vanish or not depending on the state it
+// met (kValueNode), which a warm-up cannot know -- such a batch takes the per-document kernel.
+__global__ __launch_bounds__(256) void k_has_nul(const uint8_t *text, uint64_t n, uint64_t *flag) {
+  bool z = false;
+  const uint64_t n16 = n / 16;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {
+    const uint4 v = reinterpret_cast<const uint4 *>(text)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) z |= ((w[k] - 0x01010101u) & ~w[k] & 0x80808080u) != 0u;  // some byte of the word is 0
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 15u)) z |= text[n16 * 16 + threadIdx.x] == 0;
+  if (__any(z) && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
+void launch_has_nul(const uint8_t *text, uint64_t n, uint64_t *flag, void *stream) {
+  const uint32_t g = (uint32_t)std::min<uint64_t>((n / 16 + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(k_has_nul, dim3(g), dim3(256), 0, (hipStream_t)stream, text, n, flag);
 }
 
 void launch_longest(const DevAut &A, const MatchArgs &M, int mode, bool write, void *stream) {

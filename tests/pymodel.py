@@ -112,7 +112,12 @@ class ModelAC:
         """match_longest_ / fetch_one restated from src/aha/ac.cr:118-143, 249-263.  is_end? = "really ends a key" or
         the state's string is in `stale`: Cedar's stale END flags (cedar.cr:642-648) are a property of its slot
         history, not of the key set, so the model takes them as an input -- the set of byte strings whose node holds
-        one -- and treats such a state as an end for which fetch_one yields nothing."""
+        one -- and treats such a state as an end for which fetch_one yields nothing.
+        A NUL byte: a Cedar node that holds a value AND has children keeps the value in a child with label 0
+        (cedar.cr:441-447 finds it like any child), a node without children of its own, for which is_end? holds
+        (cedar.cr:657-660) and fetch_one yields nothing: it replaces the pending end; the BFS of compile skips it
+        (cedar.cr:450-463), so its fail link is unset and the byte after it is consumed at the root without a goto
+        (defined for intersectable = false; the same is pinned for true, where the reference reads array[-1])."""
         if chars is None:
             chars = isinstance(text, str)
         t = _b(text)
@@ -126,12 +131,21 @@ class ModelAC:
             stale_nodes.add(n)
 
         def fetch_one(i, n):
-            k = self.key_of[n]
+            k = self.key_of[n] if n >= 0 else -1
             if k >= 0:
                 out.append((i - len(self.keys[k]) + 1, i + 1, k))
 
+        VALUE_NODE = -2  # the label-0 child of a state that ends a key and has children
         for i, b in enumerate(t):
             while True:
+                if nid == VALUE_NODE:  # no goto from it, no fail link: the pending (empty) end is yielded, the byte is gone
+                    prev_i = -1
+                    nid = 0
+                    break
+                if b == 0 and self.key_of[nid] >= 0 and self.children[nid]:
+                    nid = VALUE_NODE
+                    prev_i, prev_nid = i, nid
+                    break
                 nxt = self.children[nid].get(b) if b else None
                 if nxt is not None:
                     nid = nxt

@@ -1,7 +1,8 @@
 """Differential fuzzing of the HIP path against the CPU oracle (test tooling, run on the GPU box):
 random automata (small alphabets -> deep fail links, UTF-8-like bytes, nested keys), random batches
 (ragged documents, NUL bytes), random image variants (compact/wide, capped LDS prefix, shadow fail
-links on/off, two-pass, position-parallel and character-level engines), match_longest against the independent model.  python tools/fuzz_gpu.py [seconds] [seed]"""
+links on/off, two-pass and character-level engines, the latter with the fused and with the general post passes),
+match_longest against the oracle (stale END flags included).  python tools/fuzz_gpu.py [seconds] [seed]"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -47,7 +48,8 @@ while time.time() < t_end:
             keys.append(k)
     env = {"AHA_LDS_SLOTS": rng.choice([None, None, "512", "1024", "4096"]),
            "AHA_SHADOW_FAIL": rng.choice([None, None, None, "0"]),
-           "AHA_ENGINE": rng.choice([None, None, None, "v1"]),
+           "AHA_ENGINE": rng.choice([None, None, "unit", "unit", "v2", "v1"]),
+           "AHA_UNIT_POST": rng.choice([None, None, "regroup"]),
            "AHA_DIRECT": rng.choice([None, None, "0"])}
     for k, v in env.items():
         if v is None:
@@ -85,12 +87,15 @@ while time.time() < t_end:
         n_cases += 1
         n_hits += len(gh)
         if text.size <= 20000 and len(keys) <= 2000 and rng.random() < 0.5:
-            # match_longest against the independent restatement (tests/pymodel.py), first document of the batch
+            # match_longest against the oracle (Cedar's stale END flags included) and against the independent restatement
+            # (tests/pymodel.py) given the oracle's stale paths; first document of the batch
             m = ModelAC(keys)
+            stale = o.stale_paths()
             d0 = bytes(text[int(doc[0]):int(doc[1])]) if doc.size > 1 else b""
             for inter in (False, True):
                 got = [(h.start, h.end, h.value) for h in ac.match_longest(d0, inter)]
-                if got != m.match_longest(d0, inter):
+                want = [(int(h["start"]), int(h["end"]), int(h["value"])) for h in o.match_longest(d0, inter)]
+                if got != want or got != m.match_longest(d0, inter, stale=stale):
                     print("LONGEST MISMATCH seed", seed, "keys", len(keys), "env", env, "wide", wide, "n", len(d0),
                           "intersectable", inter, flush=True)
                     sys.exit(1)

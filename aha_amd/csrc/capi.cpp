@@ -79,6 +79,7 @@ struct aha_ac {
   bool unit_ok = false;  // uploaded and usable on the device
   UnitDev udev{};
   const uint32_t *d_unit_end_info = nullptr;
+  const uint2 *d_unit_end_chars = nullptr;  // ... with the key's length in characters (char offsets)
   const uint2 *d_unit_end = nullptr;  // fused expansion (scan_unit.hip ku_expand_groups): key, key length, chain offset per END base
   bool unit_fused = false;            // ... usable: flattened chains of at most 15 keys, key lengths below 2^16
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
@@ -372,18 +373,21 @@ void v2_setup(aha_ac *ac) {
     const char *upost = getenv("AHA_UNIT_POST");  // "regroup": the general post passes (tests)
     const bool fused = !ac->key_info.empty() && max_cnt <= 15 && a.max_key_len < 65536 &&
                        !(upost && strcmp(upost, "regroup") == 0);
-    std::vector<uint2> uend;
+    std::vector<uint2> uend, uendc;
     if (fused) {
       uend.assign(ac->unit.end_key.size(), uint2{0, 0});
+      uendc = uend;
       for (size_t i = 0; i < uend.size(); i++) {
         const int32_t k = ac->unit.end_key[i];
         if (k < 0) continue;
-        const uint32_t co = ac->key_info[k] & 0xFFFFFFu, len = a.key_len[k];
+        const uint32_t co = ac->key_info[k] & 0xFFFFFFu, len = a.key_len[k], kc = a.key_kc[k] + 1u;
         uend[i] = uint2{(uint32_t)k | (len & 0xFFu) << 24, co | (len >> 8) << 24};
+        uendc[i] = uint2{(uint32_t)k | (kc & 0xFFu) << 24, co | (kc >> 8) << 24};
       }
     }
     const uint64_t *us = nullptr;
-    if (fused && upload(ac, uend, &ac->d_unit_end) == AHA_OK) ac->unit_fused = true;
+    if (fused && upload(ac, uend, &ac->d_unit_end) == AHA_OK && upload(ac, uendc, &ac->d_unit_end_chars) == AHA_OK)
+      ac->unit_fused = true;
     if (unit_prepare(ac->unit.n_syms) == 0 && upload(ac, ac->unit.slots, &us) == AHA_OK &&
         upload(ac, ac->unit.root, &ac->udev.root) == AHA_OK && upload(ac, ac->unit.tables, &ac->udev.tables) == AHA_OK &&
         upload(ac, ac->unit.fail_tab, &ac->udev.fail_tab) == AHA_OK &&
@@ -466,7 +470,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   const uint64_t n_blk = std::max<uint64_t>((M.n_chunks + 255) / 256, (M.ev_cap + 255) / 256) + 2;
   const uint64_t n_reg = direct ? M.n_chunks * M.ev_stride : 0;
   // byte offsets through the event regions: the character-level traversal where the key set has a unit image
-  const bool unit = ac->unit_ok && direct && !M.chars;
+  const bool unit = ac->unit_ok && direct;
   int32_t rc;
   size_t sizes[24] = {M.ev_cap * 16,      M.ev_cap * 16,      M.ev_cap * 4,     direct ? 0 : n_slabs * 4,
                       M.n_chunks * 4,     (M.n_docs + 1) * 4, M.n_chunks * 8,   n_blk * 8,
@@ -544,8 +548,9 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
     if (unit && ac->unit_fused) {  // the traversal counted the hits: bases, then the expansion straight from the wave-ordered events
       v2_launch_hit_scan(M, s);
+      if (M.chars) v2_launch_lead_scan(M, s);  // characters before every chunk (the traversal counted them per chunk)
       if (prof) HIPCHK(ac, hipEventRecord(sc->ev[3], s));
-      unit_launch_expand(ac->d_unit_end, post, M, s);
+      unit_launch_expand(M.chars ? ac->d_unit_end_chars : ac->d_unit_end, post, M, s);
     } else {
       if (unit) unit_launch_regroup(post, M, s);  // the wave-ordered events back into the chunks' regions, counted
       v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr, unit);

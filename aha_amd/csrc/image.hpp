@@ -140,7 +140,8 @@ void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream);  // ev
 // evg + hit_base -> out, doc_hit_off: the whole expansion in one pass over the wave-ordered events.  uend[base] of an END
 // state = {key | (key length & 255) << 24, offset of its flattened output chain | (key length >> 8) << 24}
 void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, void *stream);
-void v2_launch_hit_scan(const V2Args &M, void *stream);  // chunk_hits -> hit_base, totals[0]
+void v2_launch_hit_scan(const V2Args &M, void *stream);   // chunk_hits -> hit_base, totals[0]
+void v2_launch_lead_scan(const V2Args &M, void *stream);  // lead_cnt -> lead_base, totals[1] (char offsets)
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int

@@ -59,6 +59,11 @@ __host__ __device__ inline size_t u_lds(uint32_t n_syms) {
   return u_lds_rows(n_syms) + (size_t)(kV2Threads / 64) * 64 * 12;  // + the waves' event buffers
 }
 
+// CHARS (String overload, matcher.cr:34-39): an event's second word is the number of characters -- bytes outside
+// 0x80..0xBF: one per unit that does not start with a stray continuation byte -- of the lane's chunk up to and
+// including the unit, << 1 | "counted from the start of the document" (the format of k2_traverse<.., CHARS>: the
+// expansion adds the characters between the start of the document and the chunk).
+template <bool CHARS>
 __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // LDS: decode tables (16-byte aligned), the root's transitions (child base | filter << 21 | END << 31), input rows
@@ -105,6 +110,8 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
     uint32_t *wreg = M.evg + wchunk0 * M.ev_stride * 3;
     const uint32_t wcap = (uint32_t)min<uint64_t>(64, M.n_chunks > wchunk0 ? M.n_chunks - wchunk0 : 0) * M.ev_stride;
     uint32_t hits = 0;        // hits the lane's events stand for (exact while no event stands for more than 15)
+    uint32_t lead_total = 0;
+    uint32_t lc = 0, lc_exact = 0;  // CHARS: characters of the chunk so far, or (lc_exact) of the document that started in it
     uint32_t E = 0, seq = 0;  // the state as one word (unit.hpp): base | filter << 22 | F1 | NFR | END; 0 = the root
     uint32_t pc = 0;          // the symbol that led to it
     uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1, q3 = q1;  // the rest of the input line whose first piece was staged last
@@ -116,6 +123,9 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
       if (nb != a) {
         doc_start = (int64_t)M.doc_off[dn - 1];
         pos = a - min<int64_t>(a - doc_start, warm);
+        if (CHARS) M.chunk_doc0[chunk] = (uint32_t)(dn - 1);
+      } else if (CHARS) {
+        M.chunk_doc0[chunk] = (uint32_t)dn;
       }
     }
 
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             do {
               M.doc_ev_rank[dn] = seq;
               M.doc_hit_rank[dn] = hits;
+              if (CHARS) M.doc_lead_rank[dn] = lead_total;
               dn++;
               nb = dn <= D ? (int64_t)M.doc_off[dn] : INT64_MAX;
             } while (nb == here);
@@ -183,6 +194,8 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             nb_rel = (nb <= pb + kUWin) ? (uint32_t)(nb - pb + 4) : ~0u;
             E = 0;
             pc = 0;
+            lc = 0;
+            lc_exact = 1;
             doc_start = here;
             docrel = -(int32_t)rel;
           }
@@ -208,6 +221,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
           const bool whole = in_doc & sum < kUPoison;  // a well-formed unit
           const bool o_good = whole & (sum - q0.w) < q1.x;  // ... of the keys' alphabet
           o_L = whole ? want : 1u;
+          if (CHARS) o_L |= (b0 & 0xC0u) != 0x80u ? 0x100u : 0u;  // the unit is a character (it does not start with a stray continuation byte)
           o_code = o_good ? sum - kUBias : 0u;         // symbol 0 has no transition anywhere
         };
         uint32_t code, L;
@@ -227,7 +241,8 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             uint32_t n_code, n_L;
             bool n_later;
             const bool good = code != 0u;
-            decode(rel + L, n_code, n_L, n_later);  // rows are padded: rel + 3 + 8 bytes stay inside LDS
+            const uint32_t Lb = CHARS ? (L & 0xFFu) : L;  // (CHARS: bit 8 = the unit is a character)
+            decode(rel + Lb, n_code, n_L, n_later);  // rows are padded: rel + 3 + 8 bytes stay inside LDS
             // Every select below picks between values that are already computed (plain locals): that keeps them
             // v_cndmask instead of nested divergent branches, which cost more than the work they skip.
             // ---- the root's transitions (LDS) on the unit (symbol 0 -- a bad unit or one outside the alphabet -- has
@@ -259,7 +274,12 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const bool end = consumed & u_end(E);
             const uint32_t c4 = hit ? u_c4(en.y) : 1u;
             pc = consumed ? code : pc;
-            const uint32_t adv = consumed ? L : 0u;
+            const uint32_t adv = consumed ? Lb : 0u;
+            if (CHARS) {  // characters that START in the lane's chunk (the rest of a chunk's bytes are continuation bytes)
+              const uint32_t isl = (consumed & (int32_t)rel >= a_rel) ? (L >> 8) : 0u;
+              lc += isl;
+              lead_total += isl;
+            }
             rel += adv;
             const bool park = consumed & n_later;  // the next unit waits for the next round
             lim2 = park ? rel : lim2;
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const bool ev = evc != 0u;
             const uint32_t my = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(evm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)evm, 0u));
             // {END state | lane | hits it stands for, end offset in the document, hits of the chunk before it}
-            const uint32_t rx = u_child(E) | (uint32_t)lane << 22 | evc << 28, ry = (uint32_t)(docrel + (int32_t)rel);
+            const uint32_t rx = u_child(E) | (uint32_t)lane << 22 | evc << 28, ry = CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel);
             if (ev && my < 64u) {
               uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + __umul24(my, 12u)));
               d[0] = rx;
@@ -314,11 +334,13 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
     if (live) {
       M.ev_cnt[chunk] = seq;
       if (seq > ev_stride) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
+      if (CHARS) M.lead_cnt[chunk] = lead_total;
       M.chunk_hits[chunk] = hits;  // (ku_regroup counts again where chains are longer than the record's field)
       if (e == N) {  // documents that start at N (empty tail documents, and d = D)
         while (dn <= D) {
           M.doc_ev_rank[dn] = seq;
           M.doc_hit_rank[dn] = hits;
+          if (CHARS) M.doc_lead_rank[dn] = lead_total;
           dn++;
         }
       }
@@ -455,12 +477,16 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
 // the chunk before the event - the hits of the chunk before the block -- and consecutive threads write consecutive hits.
 // One gather per event: uend[base of the END state] = its key, the key's length and the offset of its flattened
 // output chain (the second and later hits of an event -- rare -- read the chain).
+// CHARS: uend carries the key's length in characters, the record's second word the character count (see ku_traverse):
+// hits are char offsets, Hit(char_of_byte[start], char_of_byte[end - 1] + 1) (matcher.cr:34-39).
 constexpr int kXgThreads = 256, kXgPer = 4, kXgBlock = kXgThreads * kXgPer, kXgStage = 1536;
+template <bool CHARS>
 __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend, DevAut A, V2Args M) {
   __shared__ uint32_t s_hs[kXgStage], s_he[kXgStage], s_hk[kXgStage];  // staged hits: start, end, key
   __shared__ uint8_t s_hl[kXgStage];                                    // ... and the chunk (lane tag) of each
   __shared__ uint32_t s_tot[2][64], s_start[64], s_run[64], s_all;
   __shared__ uint64_t s_base[64];  // the chunk's place in the output
+  __shared__ uint32_t s_adj[64];   // CHARS: characters between the start of the document that contains the chunk start and it
   if (M.cursor[1]) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
@@ -469,6 +495,11 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
     __syncthreads();
     const uint64_t c = g * 64 + lane;
     if (wv == 0) {
+      if (CHARS && c < M.n_chunks) {
+        const uint32_t d0 = M.chunk_doc0[c];
+        const uint64_t dchunk = M.doc_off[d0] / M.S;
+        s_adj[lane] = (uint32_t)(M.lead_base[c] - (M.lead_base[dchunk] + M.doc_lead_rank[d0]));
+      }
       s_base[lane] = c < M.n_chunks ? M.hit_base[c] : 0ull;
       s_run[lane] = 0;
       s_tot[0][lane] = 0;
@@ -515,7 +546,7 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
           if (live[q]) {
             const uint32_t l = (rec[q].x >> 22) & 63u, n = rec[q].x >> 28;
             const uint32_t pos = s_start[l] + (rec[q].z - s_run[l]);
-            const uint32_t end = rec[q].y, co = ue[q].y & 0xFFFFFFu;
+            const uint32_t end = CHARS ? (rec[q].y >> 1) + ((rec[q].y & 1u) ? 0u : s_adj[l]) : rec[q].y, co = ue[q].y & 0xFFFFFFu;
             // Hit(idx - len + 1, idx + 1, value) ac.cr:271-273: the state's own key, then its output chain (ac.cr:265-278)
             uint32_t len = (ue[q].x >> 24) | (ue[q].y >> 24) << 8, key = ue[q].x & 0xFFFFFFu;
             for (uint32_t k = 0;;) {
@@ -528,7 +559,7 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
               }
               if (++k >= n) break;
               const uint2 ce = A.chain[co + k];
-              len = ce.x;
+              len = CHARS ? A.chain_kc[co + k] : ce.x;
               key = ce.y;
             }
           }
@@ -568,12 +599,18 @@ __global__ __launch_bounds__(256) void ku_doc_offsets(V2Args M) {
 size_t unit_lds_bytes(uint32_t n_syms) { return u_lds(n_syms); }
 
 int unit_prepare(uint32_t n_syms) {
-  return (int)hipFuncSetAttribute((const void *)ku_traverse, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)unit_lds_bytes(n_syms));
+  const int e1 = (int)hipFuncSetAttribute((const void *)ku_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)unit_lds_bytes(n_syms));
+  const int e2 = (int)hipFuncSetAttribute((const void *)ku_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)unit_lds_bytes(n_syms));
+  return e1 ? e1 : e2;
 }
 
 void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream) {
-  hipLaunchKernelGGL(ku_traverse, dim3(grid), dim3(kV2Threads), unit_lds_bytes(U.n_syms), (hipStream_t)stream, U, M);
+  if (M.chars)
+    hipLaunchKernelGGL(ku_traverse<true>, dim3(grid), dim3(kV2Threads), unit_lds_bytes(U.n_syms), (hipStream_t)stream, U, M);
+  else
+    hipLaunchKernelGGL(ku_traverse<false>, dim3(grid), dim3(kV2Threads), unit_lds_bytes(U.n_syms), (hipStream_t)stream, U, M);
 }
 
 void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream) {
@@ -584,8 +621,11 @@ void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream) {
 
 void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, void *stream) {
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
-  hipLaunchKernelGGL(ku_expand_groups, dim3((uint32_t)std::min<uint64_t>(n_groups, 1u << 16)), dim3(kXgThreads), 0,
-                     (hipStream_t)stream, uend, A, M);
+  const dim3 grid((uint32_t)std::min<uint64_t>(n_groups, 1u << 16));
+  if (M.chars)
+    hipLaunchKernelGGL(ku_expand_groups<true>, grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
+  else
+    hipLaunchKernelGGL(ku_expand_groups<false>, grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
   if (M.doc_hit_off)
     hipLaunchKernelGGL(ku_doc_offsets, dim3((uint32_t)((M.n_docs + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M);
 }

@@ -1202,6 +1202,17 @@ void v2_launch_hit_scan(const V2Args &M, void *stream) {
   hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.chunk_hits, M.n_chunks, M.blk_a, M.hit_base);
 }
 
+void v2_launch_lead_scan(const V2Args &M, void *stream) {  // lead_cnt -> lead_base, totals[1] (char offsets)
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t g = grid_for(M.n_chunks, 256, 4096);
+  const unsigned long long *abortf = (const unsigned long long *)(M.cursor + 1);
+  hipLaunchKernelGGL(k2_blocksum, dim3(g), dim3(256), 0, s, M.lead_cnt, (const uint64_t *)nullptr, M.n_chunks,
+                     M.blk_b, abortf);
+  hipLaunchKernelGGL(k2_scan_blocks, dim3(1), dim3(1024), 0, s, M.blk_b, (const uint64_t *)nullptr, M.n_chunks,
+                     M.totals + 1, abortf);
+  hipLaunchKernelGGL(k2_scan_apply, dim3(g), dim3(256), 0, s, M.lead_cnt, M.n_chunks, M.blk_b, M.lead_base);
+}
+
 void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid, bool counted) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t gw = grid_for(M.n_chunks, 4, 8192);  // 4 waves (chunks) per 256-thread block

@@ -27,6 +27,7 @@ void launch_has_nul(const uint8_t *, uint64_t, uint64_t *, void *) { no_gpu("lau
 void unit_launch_regroup(const DevAut &, const V2Args &, void *) { no_gpu("unit_launch_regroup"); }
 void unit_launch_expand(const uint2 *, const DevAut &, const V2Args &, void *) { no_gpu("unit_launch_expand"); }
 void v2_launch_hit_scan(const V2Args &, void *) { no_gpu("v2_launch_hit_scan"); }
+void v2_launch_lead_scan(const V2Args &, void *) { no_gpu("v2_launch_lead_scan"); }
 void launch_hits_pack(const int32_t *, uint64_t, int32_t *, void *) { no_gpu("launch_hits_pack"); }
 void launch_hits_unpack(const DevAut &, const int32_t *, uint64_t, int, int32_t *, void *) { no_gpu("launch_hits_unpack"); }
 void launch_hits_pack4(const int32_t *, uint64_t, uint32_t *, unsigned long long *, void *) { no_gpu("launch_hits_pack4"); }

@@ -447,7 +447,7 @@ def test_engine_selected(engine, monkeypatch):
     assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur") else (2,))
     if engine in ("u", "ur"):
         # the library's own choice (no AHA_ENGINE): keys of multi-byte characters get the character-level traversal for
-        # byte-offset batches, ASCII keys and char offsets keep the byte-level one
+        # byte- and char-offset batches, ASCII keys keep the byte-level one
         monkeypatch.delenv("AHA_ENGINE", raising=False)
         cjk = AC.compile(["中国", "国人", "人"])
         cjk.set_profiling(True)
@@ -459,8 +459,12 @@ def test_engine_selected(engine, monkeypatch):
         asc.set_profiling(True)
         asc.match_array(b"abcd" * 3000)
         assert asc.info["unit_enabled"] == 0 and asc.last_timing()["engine"] == 2
-    # char offsets and the separator filter run on the byte-level engines
+    # char offsets run on the character-level engine too, the separator filter on the byte-level engines only
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur") else (2,))
+    sep = BitArray(256)
+    sep[ord(" ")] = True
+    assert [tuple(h) for h in ac.match("ab ba", sep)] == [(0, 2, 0), (3, 5, 1)]
     assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
 
 

@@ -453,7 +453,9 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   const bool dense = M1.cap / 4 > N / 16;          // more than one hit per 4 input bytes expected
   const bool sparse = M1.cap < 16ull * M.n_chunks;  // fewer than 16 hits per chunk expected
   if (de && strcmp(de, "0") == 0) mode = kSlabs;
-  if (M.sep || (mode == kRegions && sparse)) mode = kSlabs;
+  // (the character-level engine leaves its events wave by wave and expands them group by group: its cost follows the
+  // events too, so a handle that has it keeps the regions for sparse batches)
+  if (M.sep || (mode == kRegions && sparse && !ac->unit_ok)) mode = kSlabs;
   if (mode == kRegions && dense) mode = kFullRegions;
   uint64_t stride = S;
   // twice the average the caller allows for, plus a slack of 1/64 of the chunk (64 events at 4 KiB): 16 bytes per hit of

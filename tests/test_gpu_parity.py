@@ -453,8 +453,14 @@ def test_engine_selected(engine, monkeypatch):
         cjk.set_profiling(True)
         text = "中国人民" * 3000
         hits, _ = cjk.match_batch(np.frombuffer(text.encode(), dtype=np.uint8),
-                                  np.array([0, len(text.encode())], dtype=np.uint64), cap=40000)  # room for the event regions
+                                  np.array([0, len(text.encode())], dtype=np.uint64), cap=40000)
         assert cjk.info["unit_enabled"] == 1 and cjk.last_timing()["engine"] == 4 and len(hits) == 9000
+        # ... also when the caller expects few hits (the byte-level engine would take its slab pipeline then)
+        sparse = "民" * 200000 + "中国人"
+        hits, _ = cjk.match_batch(np.frombuffer(sparse.encode(), dtype=np.uint8),
+                                  np.array([0, len(sparse.encode())], dtype=np.uint64), cap=64)
+        assert cjk.last_timing()["engine"] == 4 and [tuple(h) for h in hits.tolist()] == [
+            (600000, 600006, 0), (600003, 600009, 1), (600006, 600009, 2)]
         asc = AC.compile(["abc", "bcd"])
         asc.set_profiling(True)
         asc.match_array(b"abcd" * 3000)

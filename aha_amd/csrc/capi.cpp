@@ -903,7 +903,8 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->fail_s1_lo = ac->s1_lo;
   info->fail_s2_lo = ac->s2_lo;
   info->fail_hdr_lo = ac->s2_hi;
-  info->unit_enabled = ac->unit.ok ? 1u : 0u;
+  // (a device handle: the image is uploaded and the kernel's LDS fits -- calls will run it; a host-only handle: it is built)
+  info->unit_enabled = (ac->device < 0 ? ac->unit.ok : ac->unit_ok) ? 1u : 0u;
   info->unit_slots = ac->unit.n_slots;
   info->unit_syms = ac->unit.n_syms;
   info->unit_multi_permille = ac->unit.multi_permille;

@@ -111,8 +111,10 @@ typedef struct {
   uint32_t fail_hdr_lo;
   uint32_t reserved;
   /* Character-level image (aha_amd/csrc/unit.hpp), built when every key is a sequence of UTF-8-shaped units, at least
-   * 30 % of the key bytes lie in multi-byte characters and the keys' characters fit the symbol table: plain
-   * byte-offset matches then take one step per character instead of one per byte (bit-exact; aha_timing.engine = 4). */
+   * 30 % of the key bytes lie in multi-byte characters and the keys' characters fit the symbol table (AHA_ENGINE=unit:
+   * for every eligible key set).  1 = this handle's matches without a separator filter -- byte or char offsets -- take
+   * one step per character instead of one per byte (bit-exact; aha_timing.engine = 4); on a host-only handle: the image
+   * was built (aha_ac_export). */
   uint32_t unit_enabled;
   uint32_t unit_slots;          /* 8-byte slots of its double array */
   uint32_t unit_syms;           /* symbols of its dense alphabet (the root's transitions: 4 bytes each, in LDS) */

@@ -461,7 +461,9 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   // twice the average the caller allows for, plus a slack of 1/64 of the chunk (64 events at 4 KiB): 16 bytes per hit of
   // capacity + 1/8 byte per input byte
   if (mode == kRegions) stride = std::min<uint64_t>(S, 2 * (M1.cap / M.n_chunks) + std::max<uint64_t>(16, S / 64));
-  if (mode != kSlabs && M.n_chunks * stride * 8 > kV2MaxRegionBytes) mode = kSlabs;
+  // bytes per event of the regions: 8 (byte-level engine), 12 (character-level, fused expansion), 12 + 8 (general passes)
+  const uint64_t rec_bytes = ac->unit_ok ? (ac->unit_fused ? 12 : 20) : 8;
+  if (mode != kSlabs && M.n_chunks * stride * rec_bytes > kV2MaxRegionBytes) mode = kSlabs;
   const bool direct = mode != kSlabs;
   const uint64_t waves = (uint64_t)ac->v2_grid * (kV2Threads / 64);
   M.direct = direct ? 1 : 0;

@@ -89,6 +89,7 @@ SIGNATURES = {
     "aha_ac_export": (C.c_int64, [_vp, _i32, _vp, _u64]),
     "aha_ac_hits_pack_device": (_i32, [_vp, _vp, _u64, _vp, _vp]),
     "aha_ac_hits_unpack_device": (_i32, [_vp, _vp, _u64, _i32, _vp, _vp]),
+    "aha_ac_stream_format": (_i32, [_vp, _vp, _vp]),
     "aha_ac_hits_pack4_device": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp, _vp]),
     "aha_ac_hits_unpack4_device": (_i32, [_vp, _vp, _u64, _i32, _vp, _vp]),
     "aha_ac_hits_unpack4_segs_device": (_i32, [_vp, _vp, _vp, _u32, _i32, _vp, _vp]),

@@ -348,6 +348,12 @@ class AC:
         self._check(N.lib().aha_ac_hits_unpack_device(self._h, pairs.data_ptr(), n, 1 if chars else 0,
                                                       hits.data_ptr(), C.c_void_p(s)))
 
+    def stream_format(self):
+        """(step_bits, len_bits) of the 4-byte exchange stream's words for this automaton (include/aha_hip.h)."""
+        sb, lb = C.c_uint32(0), C.c_uint32(0)
+        self._check(N.lib().aha_ac_stream_format(self._h, C.byref(sb), C.byref(lb)))
+        return int(sb.value), int(lb.value)
+
     def hits_pack4_device(self, hits, n, words, n_words, stream=None):
         """hits [>=n,3] int32 -> the 4-byte exchange stream in `words` (int32, capacity >= 2n + ceil(n/1024)); the
         stream length lands in n_words[0] (int64 device tensor).  Asynchronous."""

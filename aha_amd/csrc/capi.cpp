@@ -784,10 +784,35 @@ int32_t aha_ac_hits_unpack_device(aha_ac *ac, const int32_t *d_pairs, uint64_t n
   return AHA_OK;
 }
 
+// Field widths of the 4-byte exchange stream for this automaton (include/aha_hip.h): the key id needs vb bits, a key's
+// length lb bits (in bytes; its length in characters is not longer); when at least 6 bits are left for the step of `end`
+// the word carries the length, else only id and a 12-bit step (ids below 2^20) and the receiver looks the length up.
+static StreamFmt stream_fmt(const aha_ac *ac) {
+  auto bits = [](uint32_t x) {
+    uint32_t b = 0;
+    while (x) {
+      b++;
+      x >>= 1;
+    }
+    return b;
+  };
+  const uint32_t vb = std::max(1u, bits(ac->aut.n_keys ? ac->aut.n_keys - 1 : 0)), lb = std::max(1u, bits(ac->aut.max_key_len));
+  if (vb + lb + 6 <= 32) return StreamFmt{std::min(12u, 32 - vb - lb), lb};
+  return StreamFmt{12, 0};
+}
+
+int32_t aha_ac_stream_format(const aha_ac *ac, uint32_t *step_bits, uint32_t *len_bits) {
+  if (!ac || !step_bits || !len_bits) return AHA_E_INVALID;
+  const StreamFmt f = stream_fmt(ac);
+  *step_bits = f.step_bits;
+  *len_bits = f.len_bits;
+  return AHA_OK;
+}
+
 int32_t aha_ac_hits_pack4_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, uint32_t *d_words, uint64_t cap_words,
                                  uint64_t *d_n_words, void *stream) {
   if (!ac || ac->device < 0 || !d_words || !d_n_words || (n && !d_hits)) return AHA_E_INVALID;
-  if (ac->aut.n_keys > (1u << 20)) {
+  if (stream_fmt(ac).len_bits == 0 && ac->aut.n_keys > (1u << 20)) {
     tls_err = "the 4-byte exchange stream holds key ids below 2^20: use the {end, value} pairs";
     return AHA_E_INVALID;
   }
@@ -798,7 +823,7 @@ int32_t aha_ac_hits_pack4_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, 
   }
   DeviceGuard g(ac->device);
   launch_hits_pack4(reinterpret_cast<const int32_t *>(d_hits), n, d_words,
-                    reinterpret_cast<unsigned long long *>(d_n_words), stream);
+                    reinterpret_cast<unsigned long long *>(d_n_words), stream_fmt(ac), stream);
   HIPCHK(ac, hipGetLastError());
   return AHA_OK;
 }
@@ -807,7 +832,7 @@ int32_t aha_ac_hits_unpack4_device(aha_ac *ac, const uint32_t *d_words, uint64_t
                                    aha_hit *d_hits, void *stream) {
   if (!ac || ac->device < 0 || (n && (!d_hits || !d_words))) return AHA_E_INVALID;
   DeviceGuard g(ac->device);
-  launch_hits_unpack4(ac->dev, d_words, n, char_offsets ? 1 : 0, reinterpret_cast<int32_t *>(d_hits), stream);
+  launch_hits_unpack4(ac->dev, d_words, n, char_offsets ? 1 : 0, reinterpret_cast<int32_t *>(d_hits), stream_fmt(ac), stream);
   HIPCHK(ac, hipGetLastError());
   return AHA_OK;
 }
@@ -826,7 +851,7 @@ int32_t aha_ac_hits_unpack4_segs_device(aha_ac *ac, const uint32_t *d_words, con
   if (any && (!d_words || !d_hits)) return AHA_E_INVALID;
   DeviceGuard g(ac->device);
   launch_hits_unpack4_segs(ac->dev, d_words, woff, nh, ooff, n_segs, char_offsets ? 1 : 0,
-                           reinterpret_cast<int32_t *>(d_hits), stream);
+                           reinterpret_cast<int32_t *>(d_hits), stream_fmt(ac), stream);
   HIPCHK(ac, hipGetLastError());
   return AHA_OK;
 }

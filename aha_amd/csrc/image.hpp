@@ -157,12 +157,19 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
 void launch_hits_pack(const int32_t *hits, uint64_t n, int32_t *pairs, void *stream);
 void launch_hits_unpack(const DevAut &A, const int32_t *pairs, uint64_t n, int chars, int32_t *hits, void *stream);
 // 4-byte exchange stream (kernels.hip): stream_words holds n + ceil(n/1024) + exceptions words (capacity 2n + ceil(n/1024))
-void launch_hits_pack4(const int32_t *hits, uint64_t n, uint32_t *stream_words, unsigned long long *n_words, void *stream);
-void launch_hits_unpack4(const DevAut &A, const uint32_t *stream_words, uint64_t n, int chars, int32_t *hits, void *stream);
+// field widths of the 4-byte exchange stream's words (kernels.hip): value << (step_bits + len_bits) | len << step_bits | step
+struct StreamFmt {
+  uint32_t step_bits;  // 6..12; 2^step_bits - 1 = exception
+  uint32_t len_bits;   // 0: the key's length is not carried (looked up on arrival)
+};
+void launch_hits_pack4(const int32_t *hits, uint64_t n, uint32_t *stream_words, unsigned long long *n_words, StreamFmt F,
+                       void *stream);
+void launch_hits_unpack4(const DevAut &A, const uint32_t *stream_words, uint64_t n, int chars, int32_t *hits, StreamFmt F,
+                         void *stream);
 // several streams in one launch: stream k starts at word word_off[k] of `land`, holds n_hits[k] hits, goes to hits[out_off[k]..]
 constexpr uint32_t kMaxSegs = 64;
 void launch_hits_unpack4_segs(const DevAut &A, const uint32_t *land, const uint64_t *word_off, const uint64_t *n_hits,
-                              const uint64_t *out_off, uint32_t n_segs, int chars, int32_t *hits, void *stream);
+                              const uint64_t *out_off, uint32_t n_segs, int chars, int32_t *hits, StreamFmt F, void *stream);
 
 // flag[0] |= 1: not the offsets of n_docs documents over n_bytes; |= 2: a document of 2^31 bytes or more
 void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_bytes, uint32_t *flag, void *stream);

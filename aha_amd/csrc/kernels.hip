@@ -492,31 +492,34 @@ void launch_hits_unpack(const DevAut &A, const int32_t *pairs, uint64_t n, int c
 // -------------------------------------------------- 4-byte exchange stream
 // Hits leave the match in per-document order with ascending `end`, so the stream of `end` values is a sequence of
 // small non-negative steps with a reset per document.  The compressed exchange format of n hits:
-//   words[n]   value << 12 | step, step = end - previous end when that is 0..4094, else 4095 = exception
+//   words[n]   value << (sb + lb) | len << sb | step; step = end - previous end when that is below 2^sb - 1, else
+//              2^sb - 1 = exception; len = end - start (lb bits; lb = 0: not carried)
 //   blk[nb]    nb = ceil(n / 1024): index into exc[] of the block's first exception (every block starts with one)
 //   exc[]      the absolute `end` of every exception, in hit order
-// i.e. 4 bytes per hit + 8 bytes per 1024 hits + 4 bytes per document change or gap of 4095+ bytes.  Needs
-// value < 2^20.  Hit#start is rebuilt from the key length like in the 8-byte form (ac.cr:270-272).
+// i.e. 4 bytes per hit + 8 bytes per 1024 hits + 4 bytes per document change or long gap.  The widths (StreamFmt) follow
+// from the automaton, which every rank holds: with the key's length in the word the receiver needs no table lookup per
+// hit to rebuild Hit#start (ac.cr:270-272) -- its seven rebuilds per step were bound by that gather (1.55 -> 0.75 ms) --;
+// where key ids and lengths leave fewer than 6 bits for the step, the length is looked up as in the 8-byte form.
 constexpr uint32_t kPk4Block = 1024;
-constexpr uint32_t kPk4Exc = 4095;
 
-__device__ __forceinline__ bool pack4_is_exc(const int32_t *hits, uint64_t i, uint32_t t, int32_t &e, uint32_t &step) {
+__device__ __forceinline__ bool pack4_is_exc(const int32_t *hits, uint64_t i, uint32_t t, int32_t &e, uint32_t &step,
+                                             uint32_t exc_code) {
   e = hits[i * 3 + 1];
   if (t == 0) {
-    step = kPk4Exc;
+    step = exc_code;
     return true;
   }
   const int64_t d = (int64_t)e - (int64_t)hits[(i - 1) * 3 + 1];
-  const bool x = d < 0 || d >= (int64_t)kPk4Exc;
-  step = x ? kPk4Exc : (uint32_t)d;
+  const bool x = d < 0 || d >= (int64_t)exc_code;
+  step = x ? exc_code : (uint32_t)d;
   return x;
 }
 
-__global__ __launch_bounds__(kPk4Block) void k_pack4_flags(const int32_t *hits, uint64_t n, uint32_t *blk) {
+__global__ __launch_bounds__(kPk4Block) void k_pack4_flags(const int32_t *hits, uint64_t n, uint32_t *blk, StreamFmt F) {
   const uint64_t i = (uint64_t)blockIdx.x * kPk4Block + threadIdx.x;
   int32_t e;
   uint32_t step;
-  const int x = i < n && pack4_is_exc(hits, i, threadIdx.x, e, step);
+  const int x = i < n && pack4_is_exc(hits, i, threadIdx.x, e, step, (1u << F.step_bits) - 1u);
   const int c = __syncthreads_count(x);
   if (threadIdx.x == 0) blk[blockIdx.x] = (uint32_t)c;
 }
@@ -550,20 +553,21 @@ __global__ __launch_bounds__(1024) void k_pack4_scan(uint32_t *blk, uint64_t nb,
 }
 
 __global__ __launch_bounds__(kPk4Block) void k_pack4_write(const int32_t *hits, uint64_t n, uint32_t *words,
-                                                           const uint32_t *blk, int32_t *exc) {
+                                                           const uint32_t *blk, int32_t *exc, StreamFmt F) {
   __shared__ uint32_t wcnt[16];
   const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint64_t i = (uint64_t)blockIdx.x * kPk4Block + t;
   int32_t e = 0;
   uint32_t step = 0;
-  const bool x = i < n && pack4_is_exc(hits, i, t, e, step);
+  const bool x = i < n && pack4_is_exc(hits, i, t, e, step, (1u << F.step_bits) - 1u);
   const unsigned long long m = __ballot(x);
   if (lane == 0) wcnt[w] = (uint32_t)__popcll(m);
   __syncthreads();
   if (i >= n) return;
   uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   for (uint32_t u = 0; u < w; u++) rank += wcnt[u];
-  words[i] = ((uint32_t)hits[i * 3 + 2] << 12) | step;
+  const uint32_t len = F.len_bits ? (uint32_t)(e - hits[i * 3]) : 0u;  // Hit#end - Hit#start, in the batch's offsets
+  words[i] = ((uint32_t)hits[i * 3 + 2] << (F.step_bits + F.len_bits)) | (len << F.step_bits) | step;
   if (x) exc[(uint64_t)blk[blockIdx.x] + rank] = e;
 }
 
@@ -583,7 +587,9 @@ struct SegTab {
 constexpr uint32_t kUnpThreads = 256;
 
 __global__ __launch_bounds__(kUnpThreads) void k_unpack4(const uint32_t *land, SegTab S, const uint2 *key_ln,
-                                                         const uint32_t *key_kc, int chars, int32_t *hits_all) {
+                                                         const uint32_t *key_kc, int chars, int32_t *hits_all,
+                                                         StreamFmt F) {
+  const uint32_t exc_code = (1u << F.step_bits) - 1u, vshift = F.step_bits + F.len_bits;
   __shared__ uint32_t wcnt[4];
   __shared__ int32_t wagg[4];
   __shared__ uint32_t wflag[4];
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(kUnpThreads) void k_unpack4(const uint32_t *land, S
   uint32_t before = 0, mine = 0;  // exceptions of the wave before this thread; of this thread
 #pragma unroll
   for (uint32_t k = 0; k < 4; k++) {
-    f[k] = k < left && (wd[k] & 0xFFFu) == kPk4Exc;
+    f[k] = k < left && (wd[k] & exc_code) == exc_code;
     const unsigned long long m = __ballot(f[k]);
     before += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     mine += f[k] ? 1u : 0u;
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(kUnpThreads) void k_unpack4(const uint32_t *land, S
   uint32_t taken = 0;
 #pragma unroll
   for (uint32_t k = 0; k < 4; k++) {
-    const int32_t x = f[k] ? exc[e0 + taken] : (int32_t)(wd[k] & 0xFFFu);
+    const int32_t x = f[k] ? exc[e0 + taken] : (int32_t)(wd[k] & exc_code);
     taken += f[k] ? 1u : 0u;
     v = f[k] ? x : v + x;
     any = any || f[k];
@@ -674,10 +680,13 @@ __global__ __launch_bounds__(kUnpThreads) void k_unpack4(const uint32_t *land, S
   int32_t o12[12];
 #pragma unroll
   for (uint32_t k = 0; k < 4; k++) {
-    const uint32_t value = wd[k] >> 12;
+    const uint32_t value = wd[k] >> vshift;
     const int32_t end = seen[k] ? pre[k] : pre[k] + cx;
     int32_t len = 0;
-    if (k < left) len = chars ? (int32_t)key_kc[value] + 1 : (int32_t)key_ln[value].x;
+    if (F.len_bits)
+      len = (int32_t)((wd[k] >> F.step_bits) & ((1u << F.len_bits) - 1u));
+    else if (k < left)
+      len = chars ? (int32_t)key_kc[value] + 1 : (int32_t)key_ln[value].x;
     o12[3 * k + 0] = end - len;
     o12[3 * k + 1] = end;
     o12[3 * k + 2] = (int32_t)value;
@@ -704,18 +713,19 @@ __global__ __launch_bounds__(kUnpThreads) void k_unpack4(const uint32_t *land, S
 }
 
 void launch_hits_pack4(const int32_t *hits, uint64_t n, uint32_t *stream_words, unsigned long long *n_words,
-                       void *stream) {
+                       StreamFmt F, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const uint64_t nb = (n + kPk4Block - 1) / kPk4Block;
   uint32_t *words = stream_words, *blk = stream_words + n;
   int32_t *exc = reinterpret_cast<int32_t *>(stream_words + n + nb);
-  if (nb) hipLaunchKernelGGL(k_pack4_flags, dim3((uint32_t)nb), dim3(kPk4Block), 0, s, hits, n, blk);
+  if (nb) hipLaunchKernelGGL(k_pack4_flags, dim3((uint32_t)nb), dim3(kPk4Block), 0, s, hits, n, blk, F);
   hipLaunchKernelGGL(k_pack4_scan, dim3(1), dim3(1024), 0, s, blk, nb, n, n_words);
-  if (nb) hipLaunchKernelGGL(k_pack4_write, dim3((uint32_t)nb), dim3(kPk4Block), 0, s, hits, n, words, blk, exc);
+  if (nb) hipLaunchKernelGGL(k_pack4_write, dim3((uint32_t)nb), dim3(kPk4Block), 0, s, hits, n, words, blk, exc, F);
 }
 
 void launch_hits_unpack4_segs(const DevAut &A, const uint32_t *land, const uint64_t *word_off, const uint64_t *n_hits,
-                              const uint64_t *out_off, uint32_t n_segs, int chars, int32_t *hits, void *stream) {
+                              const uint64_t *out_off, uint32_t n_segs, int chars, int32_t *hits, StreamFmt F,
+                              void *stream) {
   SegTab S{};
   uint32_t blocks = 0;
   for (uint32_t k = 0; k < n_segs && S.n < kMaxSegs; k++) {
@@ -730,13 +740,13 @@ void launch_hits_unpack4_segs(const DevAut &A, const uint32_t *land, const uint6
   S.blk0[S.n] = blocks;
   if (!blocks) return;
   hipLaunchKernelGGL(k_unpack4, dim3(blocks), dim3(kUnpThreads), 0, (hipStream_t)stream, land, S, A.key_ln, A.key_kc,
-                     chars, hits);
+                     chars, hits, F);
 }
 
 void launch_hits_unpack4(const DevAut &A, const uint32_t *stream_words, uint64_t n, int chars, int32_t *hits,
-                         void *stream) {
+                         StreamFmt F, void *stream) {
   const uint64_t zero = 0;
-  launch_hits_unpack4_segs(A, stream_words, &zero, &n, &zero, 1, chars, hits, stream);
+  launch_hits_unpack4_segs(A, stream_words, &zero, &n, &zero, 1, chars, hits, F, stream);
 }
 
 // -------------------------------------------------- device-resident doc offsets

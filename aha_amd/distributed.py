@@ -55,12 +55,14 @@ def local_shard(corpus, doc_offsets, rank, world):
 
 
 PK4_BLOCK = 1024
-PK4_EXC = 4095
 
 
-def pack4_host(hits):
+def pack4_host(hits, fmt=(12, 0)):
     """CPU restatement of the 4-byte exchange stream (include/aha_hip.h, aha_ac_hits_pack4_device) for the gloo
-    rehearsal: hits [n,3] int32 CPU tensor -> int32 tensor words[n] . first_exception[nb] . exception_end[...]."""
+    rehearsal: hits [n,3] int32 CPU tensor -> int32 tensor words[n] . first_exception[nb] . exception_end[...].
+    fmt = (step_bits, len_bits) of the automaton (AC.stream_format)."""
+    sb, lb = fmt
+    PK4_EXC = (1 << sb) - 1
     n = int(hits.shape[0])
     nb = (n + PK4_BLOCK - 1) // PK4_BLOCK
     if n == 0:
@@ -71,7 +73,8 @@ def pack4_host(hits):
     exc = (step < 0) | (step >= PK4_EXC)
     exc[::PK4_BLOCK] = True
     step = torch.where(exc, torch.full_like(step, PK4_EXC), step)
-    words = (hits[:, 2].to(torch.int64) << 12) | step
+    ln = (end - hits[:, 0].to(torch.int64)) if lb else torch.zeros(n, dtype=torch.int64)
+    words = (hits[:, 2].to(torch.int64) << (sb + lb)) | (ln << sb) | step
     words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
     rank = torch.cumsum(exc.to(torch.int64), 0) - exc.to(torch.int64)
     blk = rank[::PK4_BLOCK].to(torch.int32)
@@ -79,16 +82,18 @@ def pack4_host(hits):
     return torch.cat([words, blk, hits[:, 1][exc].to(torch.int32)])
 
 
-def unpack4_host(stream, n, key_len):
-    """Inverse of pack4_host: -> hits [n,3] int32 (start = end - key length)."""
+def unpack4_host(stream, n, key_len, fmt=(12, 0)):
+    """Inverse of pack4_host: -> hits [n,3] int32 (start = end - key length: from the word, or from key_len[value])."""
+    sb, lb = fmt
+    PK4_EXC = (1 << sb) - 1
     out = torch.zeros((n, 3), dtype=torch.int32)
     if n == 0:
         return out
     nb = (n + PK4_BLOCK - 1) // PK4_BLOCK
     words = stream[:n].to(torch.int64) & 0xFFFFFFFF
     exc_end = stream[n + nb:].to(torch.int64)
-    step = words & 0xFFF
-    value = words >> 12
+    step = words & PK4_EXC
+    value = words >> (sb + lb)
     exc = step == PK4_EXC
     x = step.clone()
     x[exc] = exc_end[: int(exc.sum())]
@@ -99,7 +104,8 @@ def unpack4_host(stream, n, key_len):
     end = tot - head_tot[seg]
     out[:, 1] = end.to(torch.int32)
     out[:, 2] = value.to(torch.int32)
-    out[:, 0] = (end - key_len[value].to(torch.int64)).to(torch.int32)
+    ln = ((words >> sb) & ((1 << lb) - 1)) if lb else key_len[value].to(torch.int64)
+    out[:, 0] = (end - ln).to(torch.int32)
     return out
 
 
@@ -110,7 +116,8 @@ class HitGatherer:
     rank holds the same key lengths -- for anything but "triples"):
       "triples"  the 12-byte Hit triples as they are;
       "pairs"    {end, value}, 8 bytes per hit: Hit#start = Hit#end - len(key[value]) (src/aha/ac.cr:270-272);
-      "words"    the 4-byte stream of include/aha_hip.h (value << 12 | step of `end`; automata below 2^20 keys).
+      "words"    the 4-byte stream of include/aha_hip.h (value | key length | step of `end` in one word, field widths
+                 from the automaton: AC.stream_format).
     The triples are rebuilt on arrival (aha_ac_hits_*_device on device tensors; plain torch on CPU tensors, i.e. in
     the gloo rehearsal).  xGMI links are the scarce resource of the exchange (one link per peer: ~60 GB/s each way
     against 8 TB/s of HBM), so bytes are traded for two small kernels.  `packed=True` is the old name of "pairs"."""
@@ -138,7 +145,8 @@ class HitGatherer:
         if self.packed:
             if ac is None:
                 raise ValueError("a packed exchange needs the automaton (key lengths)")
-            if self.exchange == "words" and ac.n_keys > (1 << 20):
+            self._fmt = ac.stream_format() if self.exchange == "words" else (12, 0)
+            if self.exchange == "words" and self._fmt[1] == 0 and ac.n_keys > (1 << 20):
                 raise ValueError("the 4-byte exchange stream holds key ids below 2^20")
             self._klen = None if self._cuda else torch.from_numpy(ac.key_lengths(chars))
 
@@ -163,7 +171,7 @@ class HitGatherer:
         if hits.is_cuda:
             self.ac.hits_pack4_device(hits, n, send, self._mine[1:2])
             return send, None  # length in self._mine[1] (device)
-        w = pack4_host(hits[:n])
+        w = pack4_host(hits[:n], self._fmt)
         send[:w.numel()].copy_(w)
         return send, int(w.numel())
 
@@ -183,7 +191,7 @@ class HitGatherer:
             if land.is_cuda:
                 self.ac.hits_unpack4_device(land[elems_lo:], n, out_rows, chars=self.chars)
             else:
-                out_rows.copy_(unpack4_host(land[elems_lo:], n, self._klen))
+                out_rows.copy_(unpack4_host(land[elems_lo:], n, self._klen, self._fmt))
 
     def all_gatherv(self, hits, n):
         """hits: [cap,3] int32 on self.device, first n rows valid.  Returns

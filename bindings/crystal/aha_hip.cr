@@ -68,6 +68,7 @@ lib LibAhaHip
                          params : MatchParams*, out : Hit*, cap : UInt64,
                          doc_hit_offsets : UInt64*, n_hits : UInt64*) : Int32
 
+  fun aha_ac_stream_format(ac : Ac, step_bits : UInt32*, len_bits : UInt32*) : Int32
   # device-resident batches: upload a corpus once, match it many times, keep the hits in HBM until they are wanted
   fun aha_ac_match_batch_device(ac : Ac, d_corpus : UInt8*, d_doc_offsets : UInt64*, n_docs : UInt64, n_bytes : UInt64,
                                 params : MatchParams*, d_out : Hit*, cap : UInt64, d_doc_hit_offsets : UInt64*,

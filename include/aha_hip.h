@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AHA_ABI_VERSION 4
+#define AHA_ABI_VERSION 5
 
 /* Aha::Hit -- src/aha/matcher.cr:2-11.  Half-open [start,end) offsets
  * relative to the start of the sequence (document); value = key index in
@@ -198,12 +198,18 @@ int32_t aha_ac_hits_pack_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, i
 int32_t aha_ac_hits_unpack_device(aha_ac *ac, const int32_t *d_pairs, uint64_t n, int32_t char_offsets,
                                   aha_hit *d_hits, void *stream);
 
-/* The 4-byte form of the same exchange (automata with fewer than 2^20 keys).  Hits of a batch come in per-document
- * order with ascending `end`, so the stream carries value << 12 | (end - previous end) in one word per hit, and the
- * absolute `end` only for the first hit of every 1024, for a document change and for a gap of 4095 or more bytes:
+/* The 4-byte form of the same exchange.  Hits of a batch come in per-document order with ascending `end`, so the stream
+ * carries one word per hit, value << (step_bits + len_bits) | len << step_bits | step, with step = end - previous end
+ * and len = end - start (the key's length in the batch's offsets), and the absolute `end` only for the first hit of
+ * every 1024, for a document change and for a gap of 2^step_bits - 1 or more:
  *   d_words = words[n] . first_exception[ceil(n/1024)] . exception_end[...]
+ * The widths follow from the automaton (aha_ac_stream_format; every rank holds the same one): key ids take
+ * bit_width(n_keys - 1) bits, lengths bit_width(longest key in bytes); with at least 6 bits left the step gets what is
+ * left (at most 12) and the receiver rebuilds Hit#start without a table lookup; else len_bits = 0, step_bits = 12
+ * (key ids below 2^20) and the length is looked up on arrival.
  * pack4 needs cap_words >= 2 n + ceil(n/1024) (the worst case) and writes the real length -- what has to travel --
  * into *d_n_words (device memory); unpack4 takes the stream and n.  Asynchronous on `stream`. */
+int32_t aha_ac_stream_format(const aha_ac *ac, uint32_t *step_bits, uint32_t *len_bits);
 int32_t aha_ac_hits_pack4_device(aha_ac *ac, const aha_hit *d_hits, uint64_t n, uint32_t *d_words,
                                  uint64_t cap_words, uint64_t *d_n_words, void *stream);
 int32_t aha_ac_hits_unpack4_device(aha_ac *ac, const uint32_t *d_words, uint64_t n, int32_t char_offsets,

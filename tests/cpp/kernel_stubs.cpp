@@ -30,10 +30,10 @@ void v2_launch_hit_scan(const V2Args &, void *) { no_gpu("v2_launch_hit_scan"); 
 void v2_launch_lead_scan(const V2Args &, void *) { no_gpu("v2_launch_lead_scan"); }
 void launch_hits_pack(const int32_t *, uint64_t, int32_t *, void *) { no_gpu("launch_hits_pack"); }
 void launch_hits_unpack(const DevAut &, const int32_t *, uint64_t, int, int32_t *, void *) { no_gpu("launch_hits_unpack"); }
-void launch_hits_pack4(const int32_t *, uint64_t, uint32_t *, unsigned long long *, void *) { no_gpu("launch_hits_pack4"); }
-void launch_hits_unpack4(const DevAut &, const uint32_t *, uint64_t, int, int32_t *, void *) { no_gpu("launch_hits_unpack4"); }
+void launch_hits_pack4(const int32_t *, uint64_t, uint32_t *, unsigned long long *, StreamFmt, void *) { no_gpu("launch_hits_pack4"); }
+void launch_hits_unpack4(const DevAut &, const uint32_t *, uint64_t, int, int32_t *, StreamFmt, void *) { no_gpu("launch_hits_unpack4"); }
 void launch_hits_unpack4_segs(const DevAut &, const uint32_t *, const uint64_t *, const uint64_t *, const uint64_t *, uint32_t,
-                              int, int32_t *, void *) {
+                              int, int32_t *, StreamFmt, void *) {
   no_gpu("launch_hits_unpack4_segs");
 }
 void launch_check_docs(const uint64_t *, uint64_t, uint64_t, uint32_t *, void *) { no_gpu("launch_check_docs"); }

@@ -125,13 +125,14 @@ def test_pack4_host_round_trip_and_format():
         hits[:, 1] = torch.from_numpy(end.astype(np.int32))
         hits[:, 2] = torch.from_numpy(value.astype(np.int32))
         hits[:, 0] = hits[:, 1] - klen[hits[:, 2].long()]
-        w = pack4_host(hits)
-        nb = (n + PK4_BLOCK - 1) // PK4_BLOCK
-        assert w.dtype == torch.int32 and n + nb <= w.numel() <= 2 * n + nb
-        if n:
-            first = w[n:n + nb].tolist()
-            assert first[0] == 0 and first == sorted(first)
-        assert torch.equal(unpack4_host(w, n, klen), hits)
+        for fmt in ((12, 0), (7, 5)):  # key length looked up on arrival / carried in the word (20 + 5 + 7 bits)
+            w = pack4_host(hits, fmt)
+            nb = (n + PK4_BLOCK - 1) // PK4_BLOCK
+            assert w.dtype == torch.int32 and n + nb <= w.numel() <= 2 * n + nb
+            if n:
+                first = w[n:n + nb].tolist()
+                assert first[0] == 0 and first == sorted(first)
+            assert torch.equal(unpack4_host(w, n, klen if fmt[1] == 0 else None, fmt), hits)
 
 
 def test_partition_is_contiguous_and_balanced():

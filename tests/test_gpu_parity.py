@@ -771,7 +771,9 @@ def test_exchange_pairs_round_trip(chars):
 def test_exchange_words_round_trip(engine):
     """The 4-byte exchange stream (aha_ac_hits_pack4_device / _unpack4_device): bit-identical to its CPU restatement
     (aha_amd/distributed.py pack4_host) and a lossless round trip -- dense hits, sparse hits with gaps beyond the
-    12-bit step, many tiny documents, char offsets, zero hits, a count that is not a multiple of 1024."""
+    step field, many tiny documents, char offsets, zero hits, a count that is not a multiple of 1024 -- in both word
+    layouts: the key's length carried in the word (what 20 000 keys of at most 24 bytes get: 15 + 5 + 12 bits) and
+    looked up on arrival (keys long enough that id and length leave fewer than 6 bits for the step)."""
     if engine != "v2":
         pytest.skip("independent of the match engine")
     import torch
@@ -804,7 +806,9 @@ def test_exchange_words_round_trip(engine):
         n_words = torch.zeros(1, dtype=torch.int64, device=dev)
         g.hits_pack4_device(out, n, words, n_words)
         torch.cuda.synchronize()
-        want = pack4_host(out[:n].cpu())
+        fmt = g.stream_format()
+        assert fmt == (12, 5)
+        want = pack4_host(out[:n].cpu(), fmt)
         assert int(n_words[0]) == want.numel()
         assert torch.equal(words[: want.numel()].cpu(), want)
         back = torch.full((n + 3, 3), -7, dtype=torch.int32, device=dev)
@@ -830,6 +834,30 @@ def test_exchange_words_round_trip(engine):
     with pytest.raises(AhaError):
         g.hits_pack4_device(torch.zeros((5000, 3), dtype=torch.int32, device=dev), 5000,
                             torch.zeros(5000, dtype=torch.int32, device=dev), n_words)  # capacity below 2n + n/1024
+    # the other layout: one key of 5000 bytes beside the 20 000 -- 15 bits of id + 13 bits of length leave too few for the step
+    rng = np.random.default_rng(11)
+    long_key = rng.integers(0x61, 0x7B, size=5000, dtype=np.uint8)
+    blob2 = np.concatenate([blob[: int(offs[-1])], long_key])
+    offs2 = np.concatenate([offs, [int(offs[-1]) + 5000]]).astype(np.uint64)
+    g2 = AC.compile_packed(blob2, offs2)
+    assert g2.stream_format() == (12, 0)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 20, doc_bytes=1 << 16)
+    corpus = np.concatenate([corpus, long_key, corpus[:1000]])
+    doc = np.concatenate([doc, [corpus.size]]).astype(np.uint64)
+    dc = torch.from_numpy(corpus).to(dev)
+    dd = torch.from_numpy(doc.astype(np.int64)).to(dev)
+    out = torch.zeros((corpus.size // 4 + 16, 3), dtype=torch.int32, device=dev)
+    n = g2.match_batch_device(dc, dd, out, None)
+    assert n > 1000 and int((out[:n, 2] == 20_000).sum()) == 1
+    words = torch.full((2 * n + n // 1024 + 8,), -1, dtype=torch.int32, device=dev)
+    g2.hits_pack4_device(out, n, words, n_words)
+    torch.cuda.synchronize()
+    want = pack4_host(out[:n].cpu(), (12, 0))
+    assert int(n_words[0]) == want.numel() and torch.equal(words[: want.numel()].cpu(), want)
+    back = torch.full((n, 3), -7, dtype=torch.int32, device=dev)
+    g2.hits_unpack4_device(words, n, back)
+    torch.cuda.synchronize()
+    assert torch.equal(back, out[:n])
 
 
 class _LoopbackDist:

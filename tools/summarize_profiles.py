@@ -4,7 +4,7 @@ import collections, csv, glob, json, os, re, shutil, sys
 tag, rnd = sys.argv[1], sys.argv[2]  # e.g. prof_b r01b
 src = os.path.join("gpurun_out", tag)
 note = ("rocprofv3 --pmc, separate passes with --kernel-trace only, over `python3 bench.py --steps 2 --warmup 1 "
-        "--no-cpu-baseline` (cfg3: 100k keys, 1 GiB); averages per launch. FETCH_SIZE/WRITE_SIZE raw units are KB; "
+        "--no-cpu-baseline` (cfg3: 100k keys, 1 GiB); median over the FULL-SIZE launches of each kernel (largest grid). FETCH_SIZE/WRITE_SIZE raw units are KB; "
         "gfx950 FETCH_SIZE can under-report wide coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM) -- "
         "per-lane 16 B strided loads are uncalibrated, so raw values are quoted. SQ_* cycle counters are quad-cycles.")
 sys.path.insert(0, os.getcwd())
@@ -25,16 +25,22 @@ def short(k):
 
 
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        if "aha::" not in r["Kernel_Name"]:
-            continue
+    # the bench process launches a kernel at several sizes (the timed 1 GiB steps, the 64 MiB ranges of the end-to-end leg,
+    # capacity probes): only the FULL-SIZE dispatches -- the largest grid of each kernel -- are averaged
+    rows = [r for r in csv.DictReader(open(f)) if "aha::" in r["Kernel_Name"] and short(r["Kernel_Name"])]
+    top = collections.defaultdict(int)
+    for r in rows:
         k = short(r["Kernel_Name"])
-        if k:
+        top[k] = max(top[k], int(r["Grid_Size"]))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        if int(r["Grid_Size"]) == top[k]:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in agg.items():
         for c, v in cs.items():
-            out["kernels"].setdefault(k, {})[c] = round(sum(v) / len(v), 1)
+            v = sorted(v)
+            out["kernels"].setdefault(k, {})[c] = round(v[len(v) // 2], 1)  # median: a capacity probe writes no events
 # Calibration on the kernel's own access pattern (tools/calib_fetch.py, profiles/r01f_fetch_calibration.txt): with an
 # all-LDS automaton k2_traverse reads exactly the 1 GiB corpus and FETCH_SIZE reports 0.8953e9 bytes (x 0.834: the
 # per-lane 16-byte staging loads are tallied partly as half-size requests), WRITE_SIZE 1.06 MB.  The corpus part of

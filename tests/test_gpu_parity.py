@@ -522,6 +522,30 @@ def test_long_and_nested_keys():
     assert gpu_list(g.match_array(text)) == as_list(o.match(text))
 
 
+def test_dense_output_chains_through_the_expansion_windows(engine):
+    """Fifteen nested keys (every prefix of a run of one character): every position ends fifteen hits, so the
+    character-level engine's fused expansion stages far more hits per block of events than one window holds, and one
+    more key takes the chains beyond the record's 4-bit count -- that key set uses the general post passes.  Byte and
+    char offsets, one long document and many short ones."""
+    for n_keys, ch in ((15, "a"), (15, "中"), (16, "a")):
+        keys = [ch * k for k in range(1, n_keys + 1)]
+        g = AC.compile(keys)
+        o = orc.AC.compile(keys)
+        filler = "b" if ch == "a" else "国"
+        text = ((ch * 700 + filler) * 40).encode()
+        for doc in (np.array([0, len(text)], dtype=np.uint64),
+                    np.concatenate([np.arange(0, len(text), 997, dtype=np.uint64), [len(text)]]).astype(np.uint64)):
+            corpus = np.frombuffer(text, dtype=np.uint8)
+            for chars in (False, True):
+                if chars and ch == "中" and doc.size > 2:
+                    continue  # documents cut inside characters: char offsets are defined for valid UTF-8 only
+                gh, gd = g.match_batch(corpus, doc, chars=chars)
+                oh, od = o.match_batch(corpus, doc, chars=chars)
+                assert len(gh) == len(oh) > 200_000
+                assert np.array_equal(np.asarray(gh).view(np.int32), np.asarray(oh).view(np.int32))
+                assert np.array_equal(np.asarray(gd, dtype=np.uint64), np.asarray(od, dtype=np.uint64))
+
+
 def test_malformed_utf8_and_ragged_units(engine):
     """Text that is NOT valid UTF-8 around keys that are: truncated characters, stray continuation bytes, bytes >= 0xF0,
     NUL, characters outside the keys' alphabet, documents that start or end inside a character, characters that

@@ -958,8 +958,8 @@ def test_group_of_shards_on_one_device(engine, transport, monkeypatch):
     buffer is rebuilt from what RCCL delivered: dlopen of librccl.so, the symbol signatures, ncclInt32,
     ncclCommInitAll and the ordering behind the pack kernels run on this one GPU (only the n > 1 topology does not).
     Same hits and offsets as the single handle and the oracle, in EVERY shard's gathered buffer."""
-    if engine != "v2":
-        pytest.skip("once, on the default engine")
+    if engine not in ("v2", "u"):
+        pytest.skip("on the byte-level and on the character-level engine")
     from aha_amd import ACGroup
 
     if transport == "self-rccl":

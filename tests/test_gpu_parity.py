@@ -474,7 +474,7 @@ def test_engine_selected(engine, monkeypatch):
     assert ac.last_timing()["engine"] == (1 if engine == "v1" else 2)
 
 
-# ---- the position-parallel engine: keys of two bytes and more ---------------------
+# ---- ragged batches over random automata ------------------------------------------
 
 def _keys_ge2(rng, n, alphabet, maxlen):
     ks = set()

@@ -259,6 +259,11 @@ class HitGatherer:
                 lo, hi = base[self.rank], base[self.rank + 1]
                 self._rebuild(land, 0, lo, buf[:lo])
                 self._rebuild(land, ebase[self.rank + 1], total - hi, buf[hi:total])
+            elif land.is_cuda:  # the 4-byte streams of all peers rebuilt by ONE launch over a segment table
+                segs = [(ebase[peer], counts[peer], base[peer]) for peer in range(self.world)
+                        if peer != self.rank and counts[peer]]
+                if segs:
+                    self.ac.hits_unpack4_segs_device(land, segs, buf, chars=self.chars)
             else:
                 for peer in range(self.world):
                     if peer != self.rank:

@@ -75,14 +75,14 @@ while time.time() < t_end:
         if rng.random() < 0.3:
             cuts = sorted(cuts + cuts[1:3])  # empty documents
         doc = np.array(cuts, dtype=np.uint64)
-        chars = False
-        gh, gd = ac.match_batch(text, doc)
-        oh, od = o.match_batch(text, doc)
+        chars = rng.random() < 0.3  # char offsets: both sides count the bytes outside 0x80..0xBF, also in malformed text
+        gh, gd = ac.match_batch(text, doc, chars=chars)
+        oh, od = o.match_batch(text, doc, chars=chars)
         ok = len(gh) == len(oh) and np.array_equal(np.asarray(gh).view(np.int32), np.asarray(oh).view(np.int32)) and \
             np.array_equal(np.asarray(gd, dtype=np.uint64), np.asarray(od, dtype=np.uint64))
         if not ok:
             print("MISMATCH seed", seed, "alphabet", alpha[:8], "keys", len(keys), "env", env, "wide", wide,
-                  "n", text.size, "docs", doc.size - 1, "hits gpu/oracle", len(gh), len(oh), flush=True)
+                  "n", text.size, "docs", doc.size - 1, "chars", chars, "hits gpu/oracle", len(gh), len(oh), flush=True)
             sys.exit(1)
         n_cases += 1
         n_hits += len(gh)

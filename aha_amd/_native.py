@@ -30,7 +30,7 @@ AHA_OPT_HOST_ONLY = 1
 AHA_OPT_FORCE_WIDE = 2
 AHA_IMG_SLOTS, AHA_IMG_END_KEY, AHA_IMG_KEY_LN, AHA_IMG_KEY_CNT, AHA_IMG_KEY_KC = 0, 1, 2, 3, 4
 AHA_IMG_STALE_ENDS = 5
-AHA_IMG_UNIT_SLOTS, AHA_IMG_UNIT_ROOT, AHA_IMG_UNIT_END_KEY, AHA_IMG_UNIT_TABLES, AHA_IMG_UNIT_FAIL = 6, 7, 8, 9, 10
+AHA_IMG_UNIT_SLOTS, AHA_IMG_UNIT_ROOT, AHA_IMG_UNIT_END_KEY, AHA_IMG_UNIT_TABLES = 6, 7, 8, 9
 
 
 class aha_options(C.Structure):
@@ -49,7 +49,8 @@ class aha_ac_info_t(C.Structure):
                 ("slot_bytes", C.c_uint32), ("lds_slots", C.c_uint32), ("device", C.c_int32),
                 ("fail_s1_lo", C.c_uint32), ("fail_s2_lo", C.c_uint32), ("fail_hdr_lo", C.c_uint32),
                 ("reserved", C.c_uint32), ("unit_enabled", C.c_uint32), ("unit_slots", C.c_uint32),
-                ("unit_syms", C.c_uint32), ("unit_multi_permille", C.c_uint32)]
+                ("unit_syms", C.c_uint32), ("unit_multi_permille", C.c_uint32), ("unit_big_lo", C.c_uint32),
+                ("unit_big_block", C.c_uint32), ("unit_n_low", C.c_uint32), ("unit_n_big", C.c_uint32)]
 
 
 class aha_timing(C.Structure):

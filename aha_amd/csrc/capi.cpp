@@ -390,11 +390,12 @@ void v2_setup(aha_ac *ac) {
       ac->unit_fused = true;
     if (unit_prepare(ac->unit.n_syms) == 0 && upload(ac, ac->unit.slots, &us) == AHA_OK &&
         upload(ac, ac->unit.root, &ac->udev.root) == AHA_OK && upload(ac, ac->unit.tables, &ac->udev.tables) == AHA_OK &&
-        upload(ac, ac->unit.fail_tab, &ac->udev.fail_tab) == AHA_OK &&
         upload(ac, info, &ac->d_unit_end_info) == AHA_OK) {
       ac->udev.slots = reinterpret_cast<const uint2 *>(us);
       ac->udev.n_slots = ac->unit.n_slots;
-      ac->udev.n_shared = ac->unit.n_shared;
+      ac->udev.big_lo = ac->unit.n_shared;
+      ac->udev.n_low = ac->unit.n_low;
+      ac->udev.g0 = ac->unit.g0;
       ac->udev.n_syms = ac->unit.n_syms;
       ac->udev.max_len = a.max_key_len;
       ac->unit_ok = true;
@@ -935,6 +936,10 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->unit_slots = ac->unit.n_slots;
   info->unit_syms = ac->unit.n_syms;
   info->unit_multi_permille = ac->unit.multi_permille;
+  info->unit_big_lo = ac->unit.n_shared;
+  info->unit_big_block = ac->unit.big_block;
+  info->unit_n_low = ac->unit.n_low;
+  info->unit_n_big = ac->unit.n_big;
   return AHA_OK;
 }
 
@@ -1000,10 +1005,6 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
     case AHA_IMG_UNIT_END_KEY:
       src = ac->unit.end_key.data();
       bytes = ac->unit.end_key.size() * 4;
-      break;
-    case AHA_IMG_UNIT_FAIL:
-      src = ac->unit.fail_tab.data();
-      bytes = ac->unit.fail_tab.size() * 4;
       break;
     case AHA_IMG_UNIT_TABLES:
       src = ac->unit.tables.data();

@@ -126,10 +126,11 @@ struct V2Args {
 struct UnitDev {
   const uint2 *slots;      // [n_slots] {lo, hi} entries
   const uint32_t *root;    // [n_syms] the root's transitions by symbol
-  const uint32_t *fail_tab;  // [n_slots] the word of the fail state, at the base of a state whose fail link is not the root
   const uint32_t *tables;  // [kUTabWords] decode tables
   uint32_t n_slots;
-  uint32_t n_shared;       // slots of the shared XOR array (states with a region of their own have bases beyond it)
+  uint32_t big_lo;         // bases from here on are big states: a private block each (unit.hpp, BIG STATES)
+  uint32_t n_low;          // symbols below it index a big state's block directly, the others a group record
+  uint32_t g0;             // group record of symbol s: base + g0 + (s >> 5)
   uint32_t n_syms;
   uint32_t max_len;        // longest key, bytes
 };

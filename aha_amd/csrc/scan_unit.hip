@@ -251,25 +251,32 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const uint32_t rt = rl[code];
             const uint32_t rf = rl[pc];
             // ---- the state's own transition: at most one 8-byte probe.  The state word carries a filter over the
-            // symbols the state continues on: a clear bit is a miss without the probe (the root's word is 0)
+            // symbols the state continues on: a clear bit is a miss without the probe (the root's word is 0).
+            // What the probe is keyed by (unit.hpp, IMAGE): the unit's symbol; the group of 32 symbols around it when the
+            // state is a big one and the symbol a high one; 0 -- the header, which holds the word of the fail state --
+            // when the trip before asked for it.  A big state's base is its block's first slot: ^ is + there.
             const uint32_t Bq = u_child(E);
+            const bool hdr = u_hdr_pending(E);
+            const bool grp = Bq >= U.big_lo & code >= U.n_low & !hdr;
+            uint32_t se = grp ? (code >> 5) + U.g0 : code;
+            se = hdr ? 0u : se;
             // (bit 29 -- F1 -- stands in for the filter's eighth bit, which is always set)
             const bool probe = good & (((E | 0x20000000u) >> (22u + (code & 7u))) & 1u) != 0u & Bq != 0u;
-            const uint2 en = slots[probe ? (Bq ^ code) : 0u];
-            // the fail link of a state that fails neither to the root nor to a one-character state comes from a side
-            // array in HBM: rare per lane, but some lane of a wave needs it in every other trip -- so it is requested
-            // beside the probe, not after it, by every lane in such a state (a state with a fail link is not the
-            // root: its base is not 0)
-            const uint32_t ffb = ((E >> 29) & 3u) == 2u ? Bq : 0u;  // NFR and not F1
-            uint32_t fx = 0;
-            if (wany(ffb != 0u)) fx = U.fail_tab[ffb];
-            const bool hit = probe & u_sym(en.y) == code;
+            const uint2 en = slots[probe ? (Bq ^ se) : 0u];
+            const bool symhit = probe & u_sym(en.y) == se & !grp;  // (a group record's second word is a slot number)
+            const bool hit = symhit & !hdr;
+            // a big state continues on this high symbol: its child's entry is the slot `first child of the group + set
+            // bits below the symbol's`; the next trip probes it as the state "slot ^ symbol" and consumes the unit
+            const bool redir = grp & probe & ((en.x >> (code & 31u)) & 1u) != 0u;
+            const uint32_t rE = (__builtin_popcount(en.x & ~(~0u << (code & 31u))) + en.y ^ code) | kUAllFilter;
             // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip;
-            // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or the side array's word
-            const bool viaroot = !hit & (!u_nfr(E) | !good);
-            const uint32_t ft = ffb != 0u ? fx : (rf & 0x7FFFFFFFu);  // (falling into a state reports nothing: END is not carried)
-            const uint32_t missE = viaroot ? rt : ft;
-            E = hit ? en.x : missE;
+            // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or the state's header,
+            // fetched by the next trip (falling into a state reports nothing: END is not carried)
+            const bool viaroot = !symhit & !redir & (!u_nfr(E) | !good);
+            const uint32_t ft = u_f1(E) ? (rf & 0x7FFFFFFFu) : (Bq | kUAllFilter | 0x20000000u);
+            uint32_t missE = viaroot ? rt : ft;
+            missE = redir ? rE : missE;
+            E = symhit ? en.x : missE;
             const bool consumed = hit | viaroot;
             const bool end = consumed & u_end(E);
             const uint32_t c4 = hit ? u_c4(en.y) : 1u;

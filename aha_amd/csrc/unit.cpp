@@ -130,6 +130,9 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     const uint32_t cls = t.sym >> 16, p = t.sym & 0xFFFFu;
     t.sym = cls == 1 ? p : (cls == 2 ? 129 + (p - u.c2lo) : u.n2 + 1 + (p - u.c3lo));
   }
+  for (uint32_t s : ustates)  // ascending symbols (the byte-level children come in label order: already the case)
+    if (!std::is_sorted(tr.begin() + first[s], tr.begin() + first[s + 1], [](const UTrans &x, const UTrans &y) { return x.sym < y.sym; }))
+      std::sort(tr.begin() + first[s], tr.begin() + first[s + 1], [](const UTrans &x, const UTrans &y) { return x.sym < y.sym; });
   u.tables.assign(kUTabWords, 0u);
   for (uint32_t b = 0; b < 256; b++) {
     uint32_t a1 = 0, a2 = 0, L = 1, lo = 1, span = 127;
@@ -168,87 +171,206 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     u.tables[kUA2 + 256 + b] = cont ? (b & 0x3Fu) : kUPoison;
   }
 
-  // ---- placement: unique bases, the root at base 0 without slots; states with kUBigDegree transitions or more get a
-  // region of 2^15 slots each behind the shared array (unit.hpp)
-  uint64_t want = 0;
-  uint32_t n_big = 0;
+  // ---- characters from the root, saturating (BFS order: a state comes before the states its transitions lead to)
+  std::vector<uint8_t> udepth(S, 0);
+  for (uint32_t s : ustates)
+    for (uint32_t t = first[s]; t < first[s + 1]; t++) udepth[tr[t].child] = (uint8_t)std::min<uint32_t>(udepth[s] + 1u, 255u);
+  auto has_header = [&](uint32_t s) {  // the fail state is neither the root nor a one-character state: its word is kept in a slot
+    return s != 0 && a.fail[s] != 0 && udepth[a.fail[s]] != 1;
+  };
+
+  // ---- placement (unit.hpp, IMAGE): unique bases, the root at base 0 without slots.
+  // Big states -- kUBigDegree transitions or more -- get a private block of `bb` slots each behind the shared array; the
+  // children on high symbols go, group by group, into runs of free slots of the shared array.
+  u.n_low = std::min<uint32_t>((u.n2 + 1 + 31u) & ~31u, 512u);
+  u.g0 = u.n_low - (u.n_low >> 5);
+  const uint32_t n_groups = u.n_syms > u.n_low ? (u.n_syms - u.n_low + 31u) / 32u : 0u;
+  uint32_t bb = 64;
+  while (bb < u.n_low + n_groups) bb <<= 1;
+  u.big_block = bb;
+  constexpr uint32_t kBlk = 1u << 15;  // a base and base ^ symbol share a block of 2^15 slots (symbols are below 2^15)
+  constexpr uint32_t kMaxBlocks = kUMaxSlots / kBlk;
+  struct Bits {
+    std::vector<uint64_t> w;
+    explicit Bits(size_t n) : w((n + 63) / 64, 0ull) {}
+    bool get(uint32_t i) const { return (w[i >> 6] >> (i & 63)) & 1ull; }
+    void set(uint32_t i) { w[i >> 6] |= 1ull << (i & 63); }
+  };
+  Bits used(kUMaxSlots), isb(kUMaxSlots);
+  std::vector<uint32_t> freec(kMaxBlocks, kBlk), curw(kMaxBlocks, 0);
+  std::vector<uint32_t> base(S, 0);
+  used.set(0);  // index 0 stays empty: base 0 is the root
+  isb.set(0);
+  freec[0]--;
+  uint32_t n_open = 1, n_big = 0, n_bases = 1;
+  std::vector<uint32_t> order, bigs;
   for (uint32_t s : ustates) {
     if (s == 0) continue;
     const uint32_t deg = first[s + 1] - first[s];
-    if (deg >= kUBigDegree)
-      n_big++;
-    else
-      want += deg;
+    if (deg >= kUBigDegree) {
+      bigs.push_back(s);
+    } else if (deg + (has_header(s) ? 1u : 0u) > 0) {
+      order.push_back(s);
+    }
   }
-  const uint32_t n_shared = (uint32_t)(((want * 4 / 3 + 4096) + (1u << 16) - 1) >> 16) << 16;  // load <= 3/4
-  const uint64_t n_total = (((uint64_t)n_shared + (uint64_t)n_big * 32768u) + 65535u) & ~65535ull;
-  if (n_total > kUMaxSlots || u.n_states >= n_shared) {
-    u.why = "more transitions than the 22-bit bases address";
-    return;
-  }
-  const uint32_t n_slots = (uint32_t)n_total;
-  std::vector<uint8_t> used(n_slots, 0), is_base(n_slots, 0);
-  std::vector<uint32_t> base(S, 0);
-  used[0] = 1;  // index 0 stays empty: base 0 is the root
-  is_base[0] = 1;
-  uint32_t cursor = 1;  // lowest slot that may be free
-  uint32_t idc = 1;     // lowest identity that may be unused
-  uint32_t big_next = 0;
-  for (uint32_t s : ustates) {
-    if (s == 0) continue;
-    const uint32_t lo = first[s], hi = first[s + 1];
-    uint32_t b = 0;
-    if (hi - lo >= kUBigDegree) {  // a region of its own: base + symbol
-      b = n_shared + big_next * 32768u;
-      big_next++;
-    } else if (lo == hi) {  // owns no slot: any unused identity
-      while (is_base[idc]) idc++;  // (fewer states than slots: never runs off the end)
-      b = idc;
-    } else {
-      // candidates: put the first symbol on the free slots in turn
-      const uint32_t c0 = tr[lo].sym;
-      while (used[cursor]) cursor = cursor + 1 < n_shared ? cursor + 1 : 1;
-      uint32_t f = cursor;
-      for (uint32_t tries = 0;; tries++, f = f + 1 < n_shared ? f + 1 : 1) {
-        if (tries > n_shared) {
-          if (getenv("AHA_DEBUG")) {
-            fprintf(stderr, "unit placement: state %u depth %u with %u children, cursor %u of %u\n", s, a.depth[s], hi - lo,
-                    cursor, n_slots);
-            for (uint32_t blk = 0; blk < n_slots >> 16; blk++) {
-              uint32_t nu = 0, nbs = 0;
-              for (uint32_t i = 0; i < 65536; i++) nu += used[(blk << 16) + i], nbs += is_base[(blk << 16) + i];
-              fprintf(stderr, "  block %u: %u used, %u bases\n", blk, nu, nbs);
-            }
-            uint32_t mx = 0;
-            for (uint32_t t = lo; t < hi; t++) mx = std::max(mx, tr[t].sym);
-            fprintf(stderr, "  first sym %u max sym %u\n", tr[lo].sym, mx);
-          }
-          u.why = "placement failed";
-          return;
-        }
-        if (used[f]) continue;
-        const uint32_t cand = f ^ c0;  // same block of 2^16 slots as f
-        if (cand == 0 || is_base[cand]) continue;
+  n_big = (uint32_t)bigs.size();
+  auto nsym = [&](uint32_t s) { return first[s + 1] - first[s] + (has_header(s) ? 1u : 0u); };
+  // one-character states first (their transitions are what random text probes: they end up in the low blocks), then
+  // the others; wide states before narrow ones inside each class, so that they meet empty blocks and the single
+  // transitions of the deep states fill the holes
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    const uint32_t cx = udepth[x] == 1 ? 0u : 1u, cy = udepth[y] == 1 ? 0u : 1u;
+    if (cx != cy) return cx < cy;
+    return nsym(x) > nsym(y);
+  });
+  auto open_block = [&]() -> bool {
+    if ((uint64_t)(n_open + 1) * kBlk + (uint64_t)n_big * bb > kUMaxSlots) return false;
+    n_open++;
+    return true;
+  };
+  // a base for the state with symbols sy[0..k) (0 = its header) in block blk, or 0
+  uint32_t sy[kUBigDegree + 1];
+  auto try_block = [&](uint32_t blk, uint32_t k) -> uint32_t {
+    const uint32_t fr = freec[blk];
+    if (fr < k) return 0;
+    uint64_t budget = fr;
+    if (k > 1) {  // expected share of the candidates whose other k - 1 slots are free as well
+      double p = 1.0;
+      const double fl = (double)fr / kBlk;
+      for (uint32_t i = 1; i < k; i++) p *= fl;
+      if (p * fr < 0.5) return 0;
+      budget = std::min<uint64_t>(fr, (uint64_t)(8.0 / p) + 8);
+    }
+    const uint32_t w0 = blk * (kBlk / 64), nw = kBlk / 64;
+    uint32_t wi = curw[blk];
+    for (uint32_t step = 0; step < nw && budget; step++, wi = wi + 1 < nw ? wi + 1 : 0) {
+      uint64_t fw = ~used.w[w0 + wi];
+      while (fw && budget) {
+        const uint32_t f = ((w0 + wi) << 6) + (uint32_t)__builtin_ctzll(fw);
+        fw &= fw - 1;
+        budget--;
+        const uint32_t cand = f ^ sy[0];
+        if (cand == 0 || isb.get(cand)) continue;
         bool okc = true;
-        for (uint32_t t = lo; okc && t < hi; t++) okc = !used[cand ^ tr[t].sym];
+        for (uint32_t i = 1; okc && i < k; i++) okc = !used.get(cand ^ sy[i]);
         if (okc) {
-          b = cand;
-          break;
+          curw[blk] = wi;
+          return cand;
         }
       }
     }
+    return 0;
+  };
+  uint32_t lowest = 0;  // lowest block that may have a free slot
+  auto place = [&](uint32_t k) -> uint32_t {
+    while (lowest < n_open && freec[lowest] == 0) lowest++;
+    for (uint32_t blk = lowest;; blk++) {
+      if (blk == n_open && !open_block()) return 0;
+      const uint32_t b = try_block(blk, k);
+      if (b) {
+        for (uint32_t i = 0; i < k; i++) used.set(b ^ sy[i]);
+        freec[blk] -= k;
+        isb.set(b);
+        n_bases++;
+        return b;
+      }
+    }
+  };
+  // runs of free slots for the big states' children on high symbols: {first slot} per (big state, group); a child's
+  // slot t is probed as "state t ^ symbol" (unit.hpp), so that identity must not be a real state's, now or later
+  std::vector<std::vector<uint32_t>> big_runs(n_big);
+  auto place_runs = [&]() -> bool {
+    uint32_t t = kBlk;  // not in block 0: t ^ symbol != 0
+    for (uint32_t bi = 0; bi < n_big; bi++) {
+      const uint32_t s = bigs[bi];
+      big_runs[bi].assign(n_groups, 0u);
+      for (uint32_t q = first[s]; q < first[s + 1];) {
+        if (tr[q].sym < u.n_low) {
+          q++;
+          continue;
+        }
+        const uint32_t g = (tr[q].sym - u.n_low) >> 5;
+        uint32_t q2 = q;
+        while (q2 < first[s + 1] && ((tr[q2].sym - u.n_low) >> 5) == g) q2++;
+        const uint32_t cnt = q2 - q;
+        for (;; t++) {
+          if (t + cnt > n_open * kBlk) {
+            if (!open_block()) return false;
+          }
+          if ((t & (kBlk - 1)) + cnt > kBlk) {  // a run stays inside one block
+            t = (t | (kBlk - 1));
+            continue;
+          }
+          bool okr = true;
+          for (uint32_t j = 0; okr && j < cnt; j++) okr = !used.get(t + j) && !isb.get((t + j) ^ tr[q + j].sym);
+          if (okr) break;
+        }
+        for (uint32_t j = 0; j < cnt; j++) {
+          used.set(t + j);
+          if (!isb.get((t + j) ^ tr[q + j].sym)) {
+            isb.set((t + j) ^ tr[q + j].sym);
+            n_bases++;
+          }
+        }
+        freec[t / kBlk] -= cnt;
+        big_runs[bi][g] = t;
+        t += cnt;
+        q = q2;
+      }
+    }
+    return true;
+  };
+  bool runs_done = n_big == 0 || n_groups == 0;
+  for (size_t oi = 0; oi < order.size(); oi++) {
+    const uint32_t s = order[oi];
+    if (!runs_done && udepth[s] != 1) {  // behind the one-character states
+      if (!place_runs()) {
+        u.why = "more transitions than the 22-bit bases address";
+        return;
+      }
+      runs_done = true;
+    }
+    uint32_t k = 0;
+    for (uint32_t t = first[s]; t < first[s + 1]; t++) sy[k++] = tr[t].sym;
+    if (has_header(s)) sy[k++] = 0u;
+    const uint32_t b = place(k);
+    if (!b) {
+      u.why = "more transitions than the 22-bit bases address";
+      return;
+    }
     base[s] = b;
-    is_base[b] = 1;
-    for (uint32_t t = lo; t < hi; t++) used[b ^ tr[t].sym] = 1;
   }
+  if (!runs_done && !place_runs()) {
+    u.why = "more transitions than the 22-bit bases address";
+    return;
+  }
+  // states that own no slot: any unused identity (fewer states than slots: blocks are opened for them if need be)
+  {
+    uint32_t n_ids = 0;
+    for (uint32_t s : ustates)
+      if (s != 0 && first[s + 1] == first[s] && !has_header(s)) n_ids++;
+    while ((uint64_t)n_open * kBlk < (uint64_t)n_bases + n_ids + 1)
+      if (!open_block()) {
+        u.why = "more states than the 22-bit bases address";
+        return;
+      }
+    uint32_t idc = 1;
+    for (uint32_t s : ustates) {
+      if (s == 0 || first[s + 1] != first[s] || has_header(s)) continue;
+      while (isb.get(idc)) idc++;
+      base[s] = idc;
+      isb.set(idc);
+    }
+  }
+  const uint32_t n_shared = n_open * kBlk;
+  const uint32_t n_slots = ((n_shared + n_big * bb) + kBlk - 1) & ~(kBlk - 1);
+  for (uint32_t bi = 0; bi < n_big; bi++) base[bigs[bi]] = n_shared + bi * bb;
 
   // ---- the image
-  std::vector<uint8_t> udepth(S, 0);  // characters from the root, saturating
-  for (uint32_t s : ustates)           // BFS order: a state comes before the states its transitions lead to
-    for (uint32_t t = first[s]; t < first[s + 1]; t++) udepth[tr[t].child] = (uint8_t)std::min<uint32_t>(udepth[s] + 1u, 255u);
   auto word = [&](uint32_t st) -> uint32_t {  // the state as one word (unit.hpp)
     uint32_t flt = 0;
     for (uint32_t q = first[st]; q < first[st + 1]; q++) flt |= 1u << (tr[q].sym & 7u);
+    if (first[st + 1] - first[st] >= kUBigDegree) flt = 0x7Fu;  // (a big state always probes: its group records answer)
     const bool nfr = a.fail[st] != 0, f1 = nfr && udepth[a.fail[st]] == 1;
     return base[st] | ((flt & 0x7Fu) << 22) | (f1 ? (1u << 29) : 0u) | (nfr ? (1u << 30) : 0u) |
            (a.key_of[st] >= 0 ? 0x80000000u : 0u);
@@ -258,23 +380,34 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
   };
   u.n_slots = n_slots;
   u.n_shared = n_shared;
+  u.n_big = n_big;
   u.slots.assign(n_slots, 0ull);
-  u.fail_tab.assign(n_slots, 0u);
   u.end_key.assign(n_slots, -1);
   u.root.assign(u.n_syms, 0u);
+  std::vector<uint32_t> big_index(n_big ? S : 0, 0u);
+  for (uint32_t bi = 0; bi < n_big; bi++) big_index[bigs[bi]] = bi;
   for (uint32_t s : ustates) {
     const uint32_t b = base[s];
-    if (s != 0 && a.fail[s] != 0 && udepth[a.fail[s]] != 1) {
-      u.fail_tab[b] = word(a.fail[s]) & 0x7FFFFFFFu;  // (falling into a state reports nothing: END is not carried)
+    const bool big = s != 0 && first[s + 1] - first[s] >= kUBigDegree;
+    if (has_header(s)) {
+      u.slots[b] = (uint64_t)(word(a.fail[s]) & 0x7FFFFFFFu);  // symbol 0 (falling into a state reports nothing: END is not carried)
       u.n_nfr++;
     }
     if (a.key_of[s] >= 0) u.end_key[b] = a.key_of[s];
     for (uint32_t t = first[s]; t < first[s + 1]; t++) {
-      const uint32_t c = tr[t].child;
-      if (s == 0)
-        u.root[tr[t].sym] = word(c);
-      else
-        u.slots[b ^ tr[t].sym] = ((uint64_t)(tr[t].sym | u_c4_of(a, c) << 16) << 32) | word(c);
+      const uint32_t c = tr[t].child, sym = tr[t].sym;
+      const uint64_t entry = ((uint64_t)(sym | u_c4_of(a, c) << 16) << 32) | word(c);
+      if (s == 0) {
+        u.root[sym] = word(c);
+      } else if (!big || sym < u.n_low) {
+        u.slots[b ^ sym] = entry;
+      } else {  // group record {symbols present, slot of the group's first child} + the child in the group's run
+        const uint32_t g = (sym - u.n_low) >> 5, run = big_runs[big_index[s]][g];
+        uint64_t &rec = u.slots[b + u.n_low + g];
+        const uint32_t bits = (uint32_t)rec, rank = (uint32_t)__builtin_popcount(bits);  // (symbols come in ascending order)
+        rec = ((uint64_t)run << 32) | (bits | 1u << ((sym - u.n_low) & 31u));
+        u.slots[run + rank] = entry;
+      }
     }
   }
   u.ok = true;

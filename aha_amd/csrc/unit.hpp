@@ -37,7 +37,7 @@
 // to look up its second and third byte (A1, A2: the payload contribution of a valid continuation byte, a poison
 // value otherwise) and the class's first symbol and window width.
 //
-// Image: an XOR double array with unique bases over the symbols, 8-byte slots, at most 2^22 of them.  A state is
+// IMAGE: an XOR double array with unique bases over the symbols, 8-byte slots, at most 2^22 of them.  A state is
 // carried around as ONE word -- the low word of the entry that led to it:
 //   transition  lo = child base (22 bits) | filter of the child (7 bits) << 22 | F1 << 29 | NFR << 30 | END << 31
 //               hi = symbol (16 bits) | min(hits an event in the child stands for, 15) << 16  (0 unless the child is END)
@@ -48,11 +48,28 @@
 // root, every one-character state, most others) is answered by the root's table in the same trip.  A miss in an NFR
 // state tries the unit again in the fail state: with F1 -- the fail state is a one-character state, the case of every
 // two-character key -- that is root[the symbol that led here], an LDS read; else (rare: a partial match of three
-// characters or more whose suffix is one of two or more) it comes from a side array in HBM, fail_tab[state base].
-// States with many transitions (an ASCII letter that starts a thousand keys) cannot be fitted into a shared XOR
-// array over a dense alphabet -- all their slots would have to be free at once.  Each of them gets a region of 2^15
-// slots of its own behind the shared part, at a base aligned to 2^15: base ^ symbol = base + symbol there, so the
-// kernel does not know the difference.
+// characters or more whose suffix is one of two or more) the state owns a HEADER: the slot of symbol 0 (no unit
+// decodes to 0), slots[base] = {word of the fail state, 0}.  The walk fetches it in a trip of its own: it marks its
+// state word as "header pending" (F1 set, NFR clear -- a combination no entry holds), and the next trip's probe is the
+// header instead of the unit (round 4: a side array indexed by base, 9.7 MB for cfg 3 and requested beside the probe
+// by every lane in such a state, was the second source of L2 misses of the walk).
+//
+// BIG STATES.  A state with kUBigDegree transitions or more (an ASCII or Cyrillic letter that starts hundreds of keys)
+// cannot be fitted into a shared XOR array over a dense alphabet -- all its slots would have to be free at once.
+// Round 3 gave each a region of 2^15 slots of its own (cfg 3: 60 states, 15.7 MB: most of the walk's L2 misses and
+// five sixths of its fabric traffic).  Now a big state owns a private block of `big_block` slots (a power of two; its
+// base is the block's first slot, at or beyond `big_lo`, so base ^ x = base + x for x below the block size):
+//   base + s                       s < n_low: the transition on the LOW symbol s (one- and two-byte units), as anywhere else
+//   base + g0 + (s >> 5)           s >= n_low: the GROUP RECORD of the 32 symbols around s,
+//                                  {bit (s & 31): the state continues on s,  slot of the group's first child}
+//   base + 0                       its header, if it has one
+// (n_low is a multiple of 32, g0 = n_low - n_low / 32.)  The children on high symbols lie, in symbol order, in a run of
+// free slots of the shared array, as ordinary transition entries.  A set bit does not consume the unit: the state
+// word becomes "the state whose transition on s is slot t" = (t ^ s) with an all-ones filter, t = first child + the
+// number of set bits below s, and the next trip's ordinary probe hits it.  That identity t ^ s is reserved like a
+// base, so no real state's probe ever lands on a child's slot.  cfg 3: 60 blocks of 1024 slots (0.5 MB) and 33 k
+// children in runs instead of 15.7 MB; the letters after a letter -- most of the hits at such states -- are low
+// symbols and take one trip as before, a CJK character after a letter takes two when it continues a key (2.7 %).
 #pragma once
 
 #include <cstdint>
@@ -80,14 +97,17 @@ AHA_HD inline bool u_nfr(uint32_t lo) { return ((lo >> 30) & 1u) != 0; }
 AHA_HD inline bool u_end(uint32_t lo) { return (lo >> 31) != 0; }
 AHA_HD inline uint32_t u_sym(uint32_t hi) { return hi & 0xFFFFu; }
 AHA_HD inline uint32_t u_c4(uint32_t hi) { return (hi >> 16) & 15u; }
+AHA_HD inline bool u_hdr_pending(uint32_t lo) { return ((lo >> 29) & 3u) == 1u; }  // F1 without NFR: fetch the header next
+constexpr uint32_t kUAllFilter = 0x7Fu << 22;
 
 struct UnitImage {
   bool ok = false;
   const char *why = "";
-  uint32_t n_slots = 0;             // a multiple of 2^16 (a base and base ^ symbol share a block of 2^16 slots)
-  uint32_t n_shared = 0;            // the shared XOR array; behind it the regions of the states with many transitions
+  uint32_t n_slots = 0;             // a multiple of 2^15 (a base and base ^ symbol share a block of 2^15 slots)
+  uint32_t n_shared = 0;            // the shared XOR array (= big_lo); behind it the blocks of the big states
+  uint32_t n_big = 0, big_block = 0;  // big states, slots of the block each of them owns
+  uint32_t n_low = 0, g0 = 0;       // symbols below n_low index a big state's block directly, the others by groups of 32
   std::vector<uint64_t> slots;      // [n_slots]
-  std::vector<uint32_t> fail_tab;   // [n_slots] at the base of an NFR state without F1: the word of its fail state
   std::vector<int32_t> end_key;     // [n_slots] key id at the base of an END state, else -1
   std::vector<uint32_t> root;       // [n_syms]
   std::vector<uint32_t> tables;     // [kUTabWords] decode tables

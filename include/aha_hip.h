@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AHA_ABI_VERSION 5
+#define AHA_ABI_VERSION 6
 
 /* Aha::Hit -- src/aha/matcher.cr:2-11.  Half-open [start,end) offsets
  * relative to the start of the sequence (document); value = key index in
@@ -119,6 +119,14 @@ typedef struct {
   uint32_t unit_slots;          /* 8-byte slots of its double array */
   uint32_t unit_syms;           /* symbols of its dense alphabet (the root's transitions: 4 bytes each, in LDS) */
   uint32_t unit_multi_permille; /* key bytes in multi-byte units, per 1000 */
+  /* ABI 6: how the image's big states are laid out (aha_amd/csrc/unit.hpp, BIG STATES) -- what a reader of
+   * AHA_IMG_UNIT_SLOTS needs beside the slots: a state with base >= unit_big_lo owns unit_big_block slots; the symbols
+   * below unit_n_low index them directly, the others select a group record at base + unit_n_low - unit_n_low / 32 +
+   * (symbol >> 5). */
+  uint32_t unit_big_lo;
+  uint32_t unit_big_block;
+  uint32_t unit_n_low;
+  uint32_t unit_n_big;
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded
@@ -233,8 +241,10 @@ enum {
   AHA_IMG_KEY_LN = 2,  /* {uint32 len, int32 next}[K] */
   AHA_IMG_KEY_CNT = 3, /* uint32[K] */
   AHA_IMG_KEY_KC = 4,  /* uint32[K] */
-  AHA_IMG_UNIT_SLOTS = 6,     /* uint64[unit_slots]: lo = child base | filter << 21 | NFR << 29 | END << 31, hi = symbol (unit.hpp) */
-  AHA_IMG_UNIT_FAIL = 10,     /* uint32[unit_slots]: the word of the fail state at the base of a state that does not fail to the root */
+  AHA_IMG_UNIT_SLOTS = 6,     /* uint64[unit_slots]: a transition is lo = child base (22 bits) | filter (7) << 22 | F1 << 29 |
+                                 NFR << 30 | END << 31, hi = symbol (16 bits) | min(hits, 15) << 16; slots[base] of a state with
+                                 NFR and without F1 is its header {word of the fail state, 0}; group records and child runs of
+                                 the big states: aha_amd/csrc/unit.hpp, IMAGE and BIG STATES */
   AHA_IMG_UNIT_ROOT = 7,      /* uint32[unit_syms]: the root's transitions by symbol */
   AHA_IMG_UNIT_END_KEY = 8,   /* int32[unit_slots]: key id at the base of an END state, else -1 */
   AHA_IMG_UNIT_TABLES = 9,    /* uint32[2816]: the decode tables (unit.hpp, SYMBOLS) */

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/aha_hip.h but not exported"
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
-    assert N.lib().aha_abi_version() == 5
+    assert N.lib().aha_abi_version() == 6
 
 
 def test_compile_errors_follow_reference():

@@ -88,4 +88,4 @@ def test_fewer_steps_than_bytes(monkeypatch):
     sim = UnitSim(ac)
     text = "".join(rng.choice(CHARS[6:12]) for _ in range(3000)).encode()
     assert sim.match(text) == as_list(orc.AC.compile(keys).match(text))
-    assert sim.trips < len(text) * 0.7  # 3000 characters, a tiny alphabet: many retries from fail states
+    assert sim.trips < len(text) * 0.9  # 3000 characters, a tiny alphabet: many retries from fail states, a header trip for most

@@ -1,6 +1,7 @@
 """CPU twin of the character-level engine (aha_amd/csrc/unit.hpp, scan_unit.hip): interprets the unit image the library
 built (aha_ac_export) exactly as the kernel does -- table-driven unit decoding into the dense alphabet, one probe per
-unit behind the root entry's filter, fail links carried by the entries, headers for fail targets, root table -- and
+unit behind the state word's filter, fail links carried by the entries or fetched from headers in a trip of their own,
+group records of the big states, root table -- and
 expands the events with the key tables.  Test infrastructure: checks the image builder and the unit-level algorithm
 against the oracle without a GPU."""
 import numpy as np
@@ -19,10 +20,11 @@ class UnitSim:
         self.root = ac.export(N.AHA_IMG_UNIT_ROOT, np.uint32)
         self.end_key = ac.export(N.AHA_IMG_UNIT_END_KEY, np.int32)
         self.tab = ac.export(N.AHA_IMG_UNIT_TABLES, np.uint32)
-        self.fail_tab = ac.export(N.AHA_IMG_UNIT_FAIL, np.uint32)
         self.key_ln = ac.export(N.AHA_IMG_KEY_LN, np.uint32).reshape(-1, 2)
         self.n_slots = info["unit_slots"]
-        assert self.slots.size == self.n_slots and self.n_slots % (1 << 16) == 0
+        self.big_lo, self.n_low = info["unit_big_lo"], info["unit_n_low"]
+        self.g0 = self.n_low - (self.n_low >> 5)
+        assert self.slots.size == self.n_slots and self.n_slots % (1 << 15) == 0 and self.n_low % 32 == 0
         assert self.root.size == info["unit_syms"] and int(self.root[0]) == 0
 
     def unit_at(self, t, p, end):
@@ -53,24 +55,36 @@ class UnitSim:
             good = code != 0
             while True:  # the trips of this unit
                 trips += 1
-                hit = False
                 B = E & 0x3FFFFF
-                if good and B != 0 and ((((E >> 22) & 0x7F) | 0x80) >> (code & 7)) & 1:
+                hdr = ((E >> 29) & 3) == 1  # header pending (F1 without NFR: no entry holds that)
+                grp = B >= self.big_lo and code >= self.n_low and not hdr
+                se = 0 if hdr else (self.g0 + (code >> 5) if grp else code)  # what the probe is keyed by
+                lo = hi = 0
+                probe = good and B != 0 and bool(((((E >> 22) & 0x7F) | 0x80) >> (code & 7)) & 1)
+                if probe:
                     self.probes += 1
-                    e = int(self.slots[B ^ code])
+                    e = int(self.slots[B ^ se])
                     lo, hi = e & 0xFFFFFFFF, e >> 32
-                    hit = (hi & 0xFFFF) == code
-                if hit:
+                symhit = probe and not grp and (hi & 0xFFFF) == se
+                if hdr:  # the header: the fail state's word; the unit is tried again there
+                    assert symhit and lo & 0x3FFFFF, "missing header"
+                    E = lo
+                    continue
+                if symhit:
                     E = lo
                     break
+                if grp and probe and (lo >> (code & 31)) & 1:  # a big state continues on this high symbol: its child's slot
+                    child_slot = hi + bin(lo & ((1 << (code & 31)) - 1)).count("1")
+                    E = (child_slot ^ code) | (0x7F << 22)
+                    continue
                 if not good or not (E >> 30) & 1:  # the fail link is the root (or nothing matches): its table
                     E = int(self.root[code])
                     break
                 if (E >> 29) & 1:  # F1: the fail state is the one-character state of the symbol that led here
                     E = int(self.root[pc]) & 0x7FFFFFFF
+                    assert E & 0x3FFFFF, "missing fail link"
                 else:
-                    E = int(self.fail_tab[B])  # fall to the fail state, try the unit again there
-                assert E & 0x3FFFFF, "missing fail link"
+                    E = B | (0x7F << 22) | (1 << 29)  # fetch the header in the next trip
             pc = code
             p += L
             if E >> 31:

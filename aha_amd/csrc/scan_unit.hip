@@ -21,6 +21,14 @@
 #include "image.hpp"
 #include "unit.hpp"
 
+// timing-only lab variants live in tools/lab/ (make lab): the product build defines none of them
+#ifdef AHA_LAB_INCLUDE
+#include AHA_LAB_INCLUDE
+#endif
+#ifndef AHA_LAB_PROBE_INDEX
+#define AHA_LAB_PROBE_INDEX(i) (i)
+#endif
+
 namespace aha {
 
 namespace {
@@ -262,7 +270,11 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             se = hdr ? 0u : se;
             // (bit 29 -- F1 -- stands in for the filter's eighth bit, which is always set)
             const bool probe = good & (((E | 0x20000000u) >> (22u + (code & 7u))) & 1u) != 0u & Bq != 0u;
-            const uint2 en = slots[probe ? (Bq ^ se) : 0u];
+#ifdef AHA_LAB_NO_PROBE
+            const uint2 en = make_uint2(0u, 0u);
+#else
+            const uint2 en = slots[AHA_LAB_PROBE_INDEX(probe ? (Bq ^ se) : 0u)];
+#endif
             const bool symhit = probe & u_sym(en.y) == se & !grp;  // (a group record's second word is a slot number)
             const bool hit = symhit & !hdr;
             // a big state continues on this high symbol: its child's entry is the slot `first child of the group + set
@@ -296,6 +308,9 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const int32_t last = (int32_t)rel - 1;  // row index of the unit's last byte
             // is_end? -> fetch later (ac.cr:183-185); this lane reports the end positions in [a, e)
             evc = (end & last >= a_rel & last < e_rel) ? c4 : 0u;
+#ifdef AHA_LAB_NO_EVENTS
+            evc = 0u;
+#endif
           }
           const uint64_t evm = wballot(evc != 0u);
           if (evm) {

@@ -82,6 +82,7 @@ struct aha_ac {
   const uint2 *d_unit_end_chars = nullptr;  // ... with the key's length in characters (char offsets)
   const uint2 *d_unit_end = nullptr;  // fused expansion (scan_unit.hip ku_expand_groups): key, key length, chain offset per END base
   bool unit_fused = false;            // ... usable: flattened chains of at most 15 keys, key lengths below 2^16
+  int unit_walks = 1;                 // chunks a lane of the character-level traversal walks (AHA_UNIT_WALKS; 2 where the LDS allows)
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
   // match_longest only (cedar_replay.cpp): the states that carry one of Cedar's stale END flags, derived on the first
   // match_longest call (it replays every insert: as long again as the rest of compile); dev_longest = dev + the bitmap
@@ -399,6 +400,9 @@ void v2_setup(aha_ac *ac) {
       ac->udev.n_syms = ac->unit.n_syms;
       ac->udev.max_len = a.max_key_len;
       ac->unit_ok = true;
+      const char *uw = getenv("AHA_UNIT_WALKS");
+      // (two walks per lane -- ku2_traverse -- lose to one on every box measured: profiles/r04_two_walks.txt; on request only)
+      ac->unit_walks = (unit2_event_buffer(ac->unit.n_syms) >= kU2MinEventBuffer && uw && strcmp(uw, "2") == 0) ? 2 : 1;
     }
   }
 }
@@ -431,7 +435,10 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   const uint32_t Lmax = ac->aut.max_key_len;
   uint64_t s_min = std::max<uint64_t>(64, ((8ull * Lmax + 63) / 64) * 64);
   if (s_min > kV2MaxS) return 1;
-  uint64_t lanes = (uint64_t)ac->v2_grid * kV2Threads;
+  // (the character-level traversal walks two chunks per lane where its LDS allows: twice the chunks, half the size)
+  const char *de = getenv("AHA_DIRECT");
+  const int walks = (ac->unit_ok && ac->unit_walks == 2 && !M1.sep && mode != kSlabs && !(de && strcmp(de, "0") == 0)) ? 2 : 1;
+  uint64_t lanes = (uint64_t)ac->v2_grid * kV2Threads * walks;
   uint64_t S = ((N + lanes - 1) / lanes + 63) / 64 * 64;
   S = std::min<uint64_t>(std::max<uint64_t>(S, s_min), kV2MaxS);
   V2Args M{};
@@ -450,7 +457,6 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.cap = M1.cap;
   M.doc_hit_off = M1.doc_hit_off;
   // plain mode (byte offsets or char offsets, no separator filter): per-chunk event regions, no sort
-  const char *de = getenv("AHA_DIRECT");
   const bool dense = M1.cap / 4 > N / 16;          // more than one hit per 4 input bytes expected
   const bool sparse = M1.cap < 16ull * M.n_chunks;  // fewer than 16 hits per chunk expected
   if (de && strcmp(de, "0") == 0) mode = kSlabs;
@@ -528,7 +534,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (unit) {
     post.end_info = ac->d_unit_end_info;  // events carry bases of the unit image
     post.compact = 1;
-    unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+    const uint64_t u_tiles = (M.n_chunks + (uint64_t)kV2Threads * walks - 1) / ((uint64_t)kV2Threads * walks);
+    unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, u_tiles), s, walks);
   } else {
     v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   }

@@ -136,7 +136,11 @@ struct UnitDev {
 };
 size_t unit_lds_bytes(uint32_t n_syms);
 int unit_prepare(uint32_t n_syms);  // raises the dynamic-LDS limit; hipError_t as int
-void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream);
+// walks = 2: every lane walks two chunks (ku2_traverse; a tile is 2048 chunks), needs unit2_event_buffer(n_syms) >=
+// kU2MinEventBuffer records of LDS left beside the root table
+constexpr uint32_t kU2MinEventBuffer = 16;
+uint32_t unit2_event_buffer(uint32_t n_syms);
+void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream, int walks);
 void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream);  // evg -> evd + chunk_hits (replaces k2d_count)
 // evg + hit_base -> out, doc_hit_off: the whole expansion in one pass over the wave-ordered events.  uend[base] of an END
 // state = {key | (key length & 255) << 24, offset of its flattened output chain | (key length >> 8) << 24}

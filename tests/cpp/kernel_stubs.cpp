@@ -16,7 +16,8 @@ namespace aha {
 size_t v2_lds_bytes(uint32_t, bool) { return 0; }
 size_t unit_lds_bytes(uint32_t) { return 0; }
 int unit_prepare(uint32_t) { return 0; }
-void unit_launch_traverse(const UnitDev &, const V2Args &, uint32_t, void *) { no_gpu("unit_launch_traverse"); }
+void unit_launch_traverse(const UnitDev &, const V2Args &, uint32_t, void *, int) { no_gpu("unit_launch_traverse"); }
+uint32_t unit2_event_buffer(uint32_t) { return 0; }
 int v2_prepare(bool, size_t) { return 0; }
 void v2_launch_traverse(const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("v2_launch_traverse"); }
 void v2_launch_chunk_scan(const V2Args &, void *) { no_gpu("v2_launch_chunk_scan"); }

@@ -10,4 +10,9 @@
 #define AHA_LAB_NO_PROBE 1
 #elif AHA_UNIT_LAB == 4  // nothing is reported: the cost of the event path
 #define AHA_LAB_NO_EVENTS 1
+#elif AHA_UNIT_LAB == 5  // two-walk kernel: the 16 input bytes are loaded (and waited for) by the refill that needs them
+#define AHA_LAB_W2_BLOCKQ 1
+#elif AHA_UNIT_LAB == 6  // no probe, nothing reported: the walk's instruction floor
+#define AHA_LAB_NO_PROBE 1
+#define AHA_LAB_NO_EVENTS 1
 #endif

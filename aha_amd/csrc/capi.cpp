@@ -680,6 +680,25 @@ int32_t aha_device_count(void) {
   return n;
 }
 
+// uploads the host image of `ac` to `device` (< 0: the current one) and sets the engines up there
+static int32_t attach_device(aha_ac *ac, int device) {
+  const int n = aha_device_count();
+  if (n <= 0) return AHA_E_NO_DEVICE;
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  if (device >= n) return AHA_E_INVALID;
+  ac->device = device;
+  DeviceGuard g(device);
+  const int32_t rc = upload_image(ac, ac->img);
+  if (rc != AHA_OK) {
+    fprintf(stderr, "aha_ac_compile: %s\n", tls_err.c_str());
+    return rc;
+  }
+  v2_setup(ac);
+  return AHA_OK;
+}
+
 int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, uint32_t n_keys,
                        const aha_options *opts, aha_ac **out, uint32_t *err_key) {
   if (!out || !key_offsets || (n_keys && !key_bytes && key_offsets[n_keys] != key_offsets[0]))
@@ -739,27 +758,46 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     if (getenv("AHA_DEBUG") && !ac->unit.ok) fprintf(stderr, "aha: no character-level image: %s\n", ac->unit.why);
   }
   if (!(flags & AHA_OPT_HOST_ONLY)) {
-    int n = aha_device_count();
-    if (n <= 0) {
-      delete ac;
-      return AHA_E_NO_DEVICE;
-    }
-    if (device < 0) {
-      if (hipGetDevice(&device) != hipSuccess) device = 0;
-    }
-    if (device >= n) {
-      delete ac;
-      return AHA_E_INVALID;
-    }
-    ac->device = device;
-    DeviceGuard g(device);
-    int32_t rc = upload_image(ac, img);
+    const int32_t rc = attach_device(ac, device);
     if (rc != AHA_OK) {
-      fprintf(stderr, "aha_ac_compile: %s\n", tls_err.c_str());
       aha_ac_free(ac);
       return rc;
     }
-    v2_setup(ac);
+  }
+  *out = ac;
+  return AHA_OK;
+}
+
+// A second handle for the same keys on another device: the host side of `src` (automaton, both images, key tables) is
+// copied, nothing is compiled again -- compile once, upload per device (SURVEY.md section 8 e; aha_group_compile).
+int32_t aha_ac_replicate(const aha_ac *src, int32_t device, aha_ac **out) {
+  if (!src || !out) return AHA_E_INVALID;
+  *out = nullptr;
+  aha_ac *ac = nullptr;
+  try {
+    ac = new aha_ac();
+    ac->aut = src->aut;
+    ac->img = src->img;
+    ac->n_slots = src->n_slots;
+    ac->slot_bytes = src->slot_bytes;
+    ac->compact = src->compact;
+    ac->chunk = src->chunk;
+    ac->v2_lds_slots = src->v2_lds_slots;
+    ac->v2_bpc = src->v2_bpc;
+    ac->s1_lo = src->s1_lo;
+    ac->s2_lo = src->s2_lo;
+    ac->s2_hi = src->s2_hi;
+    ac->unit = src->unit;
+    ac->seg2 = src->seg2;
+    ac->state_base = src->state_base;
+  } catch (...) {
+    delete ac;
+    return AHA_E_NOMEM;
+  }
+  const int32_t rc = attach_device(ac, device);
+  if (rc != AHA_OK) {
+    aha_ac_free(ac);
+    return rc;
   }
   *out = ac;
   return AHA_OK;
@@ -1315,9 +1353,32 @@ bool host_streams(Scratch *sc) {
 }
 }  // namespace
 
+// The host entry: upload, match and download pipelined over ranges of whole documents.  d_keep != null: the hits stay
+// on the device, in the caller's buffer d_keep[0 .. cap) (aha_ac_match_batch_keep: what the shards of a group call), and
+// only the per-document offsets come back to the host.
+static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                                const aha_match_params *params, aha_hit *out, aha_hit *d_keep, uint64_t cap,
+                                uint64_t *doc_hit_offsets, uint64_t *n_hits);
+
 int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets,
                            uint64_t n_docs, const aha_match_params *params, aha_hit *out,
                            uint64_t cap, uint64_t *doc_hit_offsets, uint64_t *n_hits) {
+  if (cap && !out) return AHA_E_INVALID;
+  return match_batch_host(ac, corpus, doc_offsets, n_docs, params, out, nullptr, cap, doc_hit_offsets, n_hits);
+}
+
+int32_t aha_ac_match_batch_keep(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                                const aha_match_params *params, aha_hit *d_hits, uint64_t cap,
+                                uint64_t *doc_hit_offsets, uint64_t *n_hits) {
+  if (cap && !d_hits) return AHA_E_INVALID;
+  static aha_hit none;  // (cap == 0: counting only; the pointer only says "keep")
+  return match_batch_host(ac, corpus, doc_offsets, n_docs, params, nullptr, d_hits ? d_hits : &none, cap, doc_hit_offsets,
+                          n_hits);
+}
+
+static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                                const aha_match_params *params, aha_hit *out, aha_hit *d_keep, uint64_t cap,
+                                uint64_t *doc_hit_offsets, uint64_t *n_hits) {
   if (!ac || !doc_offsets || !n_hits) return AHA_E_INVALID;
   if (ac->device < 0) {
     tls_err = aha_strerror(AHA_E_NO_DEVICE);
@@ -1330,7 +1391,6 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
   }
   const uint64_t n_bytes = doc_offsets[n_docs];
   if (n_bytes && !corpus) return AHA_E_INVALID;
-  if (cap && !out) return AHA_E_INVALID;
   *n_hits = 0;
   DeviceGuard g(ac->device);
   // device staging buffers are kept in the leased scratch set (grow-only): the reference's
@@ -1380,7 +1440,7 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
   uint8_t *d_corpus = (uint8_t *)reserve(0, dev_off[R] + 64);
   uint64_t *d_doc = (uint64_t *)reserve(1, (n_docs + R + 1) * sizeof(uint64_t));
   uint64_t *d_dho = (uint64_t *)reserve(2, (n_docs + R + 1) * sizeof(uint64_t));
-  aha_hit *d_out = cap ? (aha_hit *)reserve(3, cap * sizeof(aha_hit)) : nullptr;
+  aha_hit *d_out = !cap ? nullptr : d_keep ? d_keep : (aha_hit *)reserve(3, cap * sizeof(aha_hit));
   if (!d_corpus || !d_doc || !d_dho || (cap && !d_out) || !host_streams(sc)) {
     tls_err = "hipMalloc / hipStreamCreate failed for the staging buffers";
     return AHA_E_HIP;
@@ -1418,8 +1478,8 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
         if (P.failed) return;
       }
       const uint64_t D = bounds[k + 1] - bounds[k];
-      if (got[k] && hipMemcpyAsync(out + base[k], d_out + base[k], got[k] * sizeof(aha_hit), hipMemcpyDeviceToHost,
-                                   s_down) != hipSuccess)
+      if (got[k] && !d_keep && hipMemcpyAsync(out + base[k], d_out + base[k], got[k] * sizeof(aha_hit), hipMemcpyDeviceToHost,
+                                              s_down) != hipSuccess)
         return P.fail(AHA_E_HIP, "download of the hits failed");
       if (doc_hit_offsets) {
         try {

@@ -138,7 +138,9 @@ int32_t aha_group_compile(const uint8_t *key_bytes, const uint64_t *key_offsets,
     o.flags = flags;
     Shard &s = g->shards[(size_t)r];
     s.device = devices[r];
-    int32_t rc = aha_ac_compile(key_bytes, key_offsets, n_keys, &o, &s.ac, err_key);  // the automaton is replicated
+    // the automaton is replicated: compiled ONCE (the first shard), the others copy its host image and upload it
+    int32_t rc = r == 0 || (flags & AHA_OPT_HOST_ONLY) ? aha_ac_compile(key_bytes, key_offsets, n_keys, &o, &s.ac, err_key)
+                                                        : aha_ac_replicate(g->shards[0].ac, devices[r], &s.ac);
     if (rc != AHA_OK) {
       aha_group_free(g);
       return rc;
@@ -240,25 +242,18 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     // front (a denser shard reports its exact count and is matched once more)
     uint64_t want = N ? (uint64_t)((__uint128_t)cap * nb / N) * 3 / 2 + 1024 : 1024;
     want = std::max<uint64_t>(1024, std::min<uint64_t>(want, nb / 4 + 4096));
-    if (!s.corpus.reserve(nb + 64) || !s.doc.reserve((D + 1) * 8) || !s.dho.reserve((D + 1) * 8) ||
-        !s.out.reserve(want * sizeof(aha_hit))) {
+    if (!s.out.reserve(want * sizeof(aha_hit))) {
       s.rc = AHA_E_HIP;
       s.err = "hipMalloc failed for the shard's buffers";
       return;
     }
-    if ((nb && hipMemcpyAsync(s.corpus.p, corpus + b0, nb, hipMemcpyHostToDevice, s.stream) != hipSuccess) ||
-        hipMemcpyAsync(s.doc.p, rel.data(), (D + 1) * 8, hipMemcpyHostToDevice, s.stream) != hipSuccess ||
-        hipStreamSynchronize(s.stream) != hipSuccess) {
-      s.rc = AHA_E_HIP;
-      s.err = "upload failed";
-      return;
-    }
+    // the shard's range goes through the handle's pipelined host entry (upload, match and offsets of ~64 MiB document
+    // ranges on three private streams), the hits stay on the device for the exchange
     const auto t0 = std::chrono::steady_clock::now();
     for (int attempt = 0; attempt < 2; attempt++) {
       uint64_t nh = 0;
-      s.rc = aha_ac_match_batch_device(s.ac, (const uint8_t *)s.corpus.p, (const uint64_t *)s.doc.p, D, nb, params,
-                                       (aha_hit *)s.out.p, s.out.bytes / sizeof(aha_hit), (uint64_t *)s.dho.p, &nh,
-                                       s.stream);
+      s.rc = aha_ac_match_batch_keep(s.ac, corpus + b0, rel.data(), D, params, (aha_hit *)s.out.p,
+                                     s.out.bytes / sizeof(aha_hit), s.h_dho.data(), &nh);
       s.n_hits = nh;
       if (s.rc != AHA_E_CAPACITY) break;
       if (!s.out.reserve(nh * sizeof(aha_hit))) {  // the call told the exact count: once more with room
@@ -268,14 +263,7 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
       }
     }
     s.ms_match = ms_since(t0);
-    if (s.rc != AHA_OK) {
-      s.err = aha_last_error(s.ac);  // the text is the calling thread's: take it along
-      return;
-    }
-    if (hipMemcpy(s.h_dho.data(), s.dho.p, (D + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) {
-      s.rc = AHA_E_HIP;
-      s.err = "download of the document offsets failed";
-    }
+    if (s.rc != AHA_OK) s.err = aha_last_error(s.ac);  // the text is the calling thread's: take it along
   };
   for (size_t r = 0; r < n; r++) {
     Shard &s = g->shards[r];

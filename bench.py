@@ -219,7 +219,8 @@ def main():
     t0 = time.time()
     ac = AC.compile_packed(blob, offs, device=local_rank, force_wide=args.force_wide)
     info = ac.info
-    log(f"compiled in {time.time() - t0:.2f}s: {info}")
+    compile_s = time.time() - t0
+    log(f"compiled in {compile_s:.2f}s: {info}")
     ac.set_profiling(True)
 
     t0 = time.time()
@@ -468,13 +469,36 @@ def main():
 
         dev_plus_download()
         t_dl = best_of(dev_plus_download)
+        # the group API's host path on this one device: three shards of the batch, each through the same pipelined host
+        # entry (aha_ac_match_batch_keep), then the exchange by device-to-device copies (device ids repeat)
+        group_gbs = group_ms = None
+        try:
+            from aha_amd import ACGroup as Group
+            grp = Group.compile_packed(blob, offs, [local_rank] * 3)
+            gout = np.ones(n_hits + 1024, dtype=np.dtype([("start", "<i4"), ("end", "<i4"), ("value", "<i4")]))
+
+            def group_entry():
+                rc = N.lib().aha_group_match_batch(grp._h, corpus.ctypes.data, doc_u64.ctypes.data, D, C.byref(prm),
+                                                   gout.ctypes.data, gout.size, host_dho.ctypes.data, C.byref(got))
+                assert rc == 0 and got.value == n_hits, (rc, got.value)
+
+            group_entry()
+            t_grp = best_of(group_entry)
+            assert gout[:n_hits].tobytes() == host_out[:n_hits].tobytes(), "group hits differ from the single handle's"
+            group_gbs, group_ms = round(n_bytes / t_grp / 1e9, 2), round(t_grp * 1e3, 2)
+            del grp
+        except Exception as e:  # the leg is informational
+            log(f"group host entry leg failed: {e!r}")
         end_to_end = {"host_entry_gbs": round(n_bytes / t_host / 1e9, 2), "host_entry_ms": round(t_host * 1e3, 2),
                       "with_download_gbs": round(n_bytes / t_dl / 1e9, 2), "with_download_ms": round(t_dl * 1e3, 2),
                       "pcie_h2d_gbs": round(n_bytes / t_h2d / 1e9, 2),
                       "host_entry_vs_pcie": round(t_h2d / t_host, 3),
+                      "group_host_entry_gbs": group_gbs, "group_host_entry_ms": group_ms,
                       "note": "host_entry = aha_ac_match_batch on pageable host buffers (upload, match and download "
                               "pipelined over document ranges); with_download = device-resident match + D2H of the "
-                              "hits; pcie_h2d = one blocking upload of the same corpus; best of 3; never `value`"}
+                              "hits; pcie_h2d = one blocking upload of the same corpus; group_host_entry = aha_group_match_batch over "
+                              "three shards on this one device (upload and match pipelined per shard, hits gathered on the "
+                              "device and downloaded); best of 3; never `value`"}
         log(f"end to end: {end_to_end}")
 
     # ---- parity gate: no throughput figure without a bit-exact comparison on this run's hits.
@@ -508,6 +532,7 @@ def main():
                        "keys": K, "bytes_per_gpu": n_bytes, "docs_per_gpu": D, "hits_per_gpu": n_hits,
                        "slots": info["n_slots"], "slot_bytes": info["slot_bytes"], "max_key_len": info["max_key_len"],
                        "offsets": "chars" if args.chars else "bytes",
+                       "compile_s": round(compile_s, 3), "unit_slots": info.get("unit_slots"),
                        "parallelism": f"doc-sharded x{world}" + (f" + {args.gather} ({args.exchange})" if world > 1 else "")
                                       + (" (overlapped)" if overlap else "")},
             "roofline": roofline,

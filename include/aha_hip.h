@@ -159,6 +159,10 @@ int32_t aha_device_count(void);
 int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, uint32_t n_keys,
                        const aha_options *opts, aha_ac **out, uint32_t *err_key);
 void aha_ac_free(aha_ac *ac);
+/* A second handle for the same keys on `device` (< 0: the current one): the host side of `ac` is copied and uploaded,
+ * nothing is compiled again.  What aha_group_compile does for every device after the first -- the reference's compile
+ * is one call (src/aha/ac.cr:62-69), so n devices must not cost n compiles. */
+int32_t aha_ac_replicate(const aha_ac *ac, int32_t device, aha_ac **out);
 int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info);
 
 /* AC#[](sid : Int) : String and AC#[](key) : Int -- delegated to the trie in
@@ -166,6 +170,14 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info);
  * aha_ac_key returns the key length (copies min(len,cap) bytes) or <0. */
 int32_t aha_ac_key(const aha_ac *ac, int32_t id, uint8_t *buf, int32_t cap);
 int32_t aha_ac_id(const aha_ac *ac, const uint8_t *key, int32_t len);
+
+/* The batch entry below with the hits left on the device: host corpus and offsets in (uploaded range by range beside
+ * the matches, like aha_ac_match_batch), hits into d_hits[0 .. cap) -- device memory of the handle's device --, per-document
+ * offsets (optional) and the count to the host.  For callers that go on working with the hits on the GPU; each shard of
+ * aha_group_match_batch is one such call.  AHA_E_CAPACITY: *n_hits is the required count. */
+int32_t aha_ac_match_batch_keep(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                                const aha_match_params *params, aha_hit *d_hits, uint64_t cap,
+                                uint64_t *doc_hit_offsets, uint64_t *n_hits);
 
 /* AC#match on ONE sequence held in host memory (uploads, matches on the GPU,
  * downloads).  Hits come back in the reference's order: ascending end

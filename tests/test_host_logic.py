@@ -288,3 +288,30 @@ def test_stale_end_replay_matches_the_oracles_cedar():
         want = orc.AC.compile_packed(blob, offs).stale_paths()
         assert len(want) == n_stale
         assert _stale_paths_of(AC.compile_packed(blob, offs, host_only=True), keys) == want
+
+
+def test_compile_time_of_the_headline_key_set():
+    """Row a7 (src/aha/ac.cr:62-112): compile is the drop-in's first call.  cfg 3's 100k keys with the character-level
+    image: 0.6 s here (round 3: 21 s, the unit image's first-fit scan); the bound leaves room for a loaded CI host."""
+    import time
+
+    from aha_amd import synth
+    blob, offs, _ = synth.keys(3)
+    t0 = time.time()
+    ac = AC.compile_packed(blob, offs, host_only=True)
+    dt = time.time() - t0
+    info = ac.info
+    assert info["unit_enabled"] == 1 and info["unit_slots"] <= 1 << 20
+    assert dt < 2.0, dt
+
+
+def test_replicate_needs_a_device_and_a_handle():
+    import ctypes as C
+    ac = AC.compile(["ab", "b"], host_only=True)
+    out = C.c_void_p()
+    assert N.lib().aha_ac_replicate(None, 0, C.byref(out)) == N.AHA_E_INVALID
+    assert N.lib().aha_ac_replicate(ac._h, 0, None) == N.AHA_E_INVALID
+    rc = N.lib().aha_ac_replicate(ac._h, 0, C.byref(out))  # no GPU in the CPU suite: fails loudly, no CPU path
+    assert rc in (N.AHA_E_NO_DEVICE, N.AHA_OK)
+    if rc == N.AHA_OK:
+        N.lib().aha_ac_free(out)

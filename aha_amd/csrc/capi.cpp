@@ -723,7 +723,8 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   bool shadow = !(sf && strcmp(sf, "0") == 0);
   // A small automaton that fits LDS with a header for every state keeps them: its kernel (ALL_LDS) reads the
   // header beside the probe, which is cheaper than keeping the shadow state.
-  bool try_headers_first = shadow && (size_t)ac->aut.n_states * 2 * 8 <= kLdsPerCU;
+  const char *hf = getenv("AHA_HEADERS_FIRST");
+  bool try_headers_first = shadow && (size_t)ac->aut.n_states * 2 * 8 <= kLdsPerCU && !(hf && strcmp(hf, "0") == 0);
   if (try_headers_first) shadow = false;
   for (;;) {
     place_states(ac->aut, pl, shadow, shadow);

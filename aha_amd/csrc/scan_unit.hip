@@ -251,74 +251,92 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
           const bool act = rel < lim2;
           all_left = wall(rel >= (uint32_t)(4 + kUPiece) || rel >= lim);
           if (all_left || !wany(act)) break;
-          uint32_t evc = 0;  // the lane reports: the hits the event stands for (a one-character state: its own key and no more)
-          if (act) {
-            uint32_t n_code, n_L;
-            bool n_later;
-            const bool good = code != 0u;
-            const uint32_t Lb = CHARS ? (L & 0xFFu) : L;  // (CHARS: bit 8 = the unit is a character)
-            decode(rel + Lb, n_code, n_L, n_later);  // rows are padded: rel + 3 + 8 bytes stay inside LDS
-            // Every select below picks between values that are already computed (plain locals): that keeps them
-            // v_cndmask instead of nested divergent branches, which cost more than the work they skip.
-            // ---- the root's transitions (LDS) on the unit (symbol 0 -- a bad unit or one outside the alphabet -- has
-            // none) and on the symbol that led to the current state: the one-character state a two-character state
-            // fails to
-            const uint32_t rt = rl[code];
-            const uint32_t rf = rl[pc];
+          // The probe is issued and waited for by hand (cdna_hip_programming.md 5.7: an asm load hidden from hipcc): the load
+          // first, by every lane (the idle ones ask for slot 0), then the trip's LDS work, then ONE wait right in front of the
+          // first use.  Left to hipcc the same trip is 9 % slower (2.44 against 2.20 ms on one box): its wait insertion
+          // is conservative around the exec-masked region.  The ISA is audited for reads or copies of the destination
+          // between load and wait (tools/audit_probe.py, tests/test_host_logic.py).
+          // (Tried on top and dropped: the store of a full event buffer behind the NEXT trip's probe, that probe consumed
+          // at vmcnt(1) -- 2.33 against 2.20 ms: profiles/r04_two_walks.txt.)
+          auto trip = [&]() -> uint32_t {
+            uint32_t evc = 0;  // the lane reports: the hits the event stands for (a one-character state: its own key and no more)
             // ---- the state's own transition: at most one 8-byte probe.  The state word carries a filter over the
             // symbols the state continues on: a clear bit is a miss without the probe (the root's word is 0).
             // What the probe is keyed by (unit.hpp, IMAGE): the unit's symbol; the group of 32 symbols around it when the
             // state is a big one and the symbol a high one; 0 -- the header, which holds the word of the fail state --
             // when the trip before asked for it.  A big state's base is its block's first slot: ^ is + there.
+            // (requested by every lane -- the idle ones ask for slot 0 -- so that the store below runs unmasked)
+            const bool good = code != 0u;
             const uint32_t Bq = u_child(E);
             const bool hdr = u_hdr_pending(E);
             const bool grp = Bq >= U.big_lo & code >= U.n_low & !hdr;
             uint32_t se = grp ? (code >> 5) + U.g0 : code;
             se = hdr ? 0u : se;
             // (bit 29 -- F1 -- stands in for the filter's eighth bit, which is always set)
-            const bool probe = good & (((E | 0x20000000u) >> (22u + (code & 7u))) & 1u) != 0u & Bq != 0u;
-#ifdef AHA_LAB_NO_PROBE
-            const uint2 en = make_uint2(0u, 0u);
-#else
-            const uint2 en = slots[AHA_LAB_PROBE_INDEX(probe ? (Bq ^ se) : 0u)];
-#endif
-            const bool symhit = probe & u_sym(en.y) == se & !grp;  // (a group record's second word is a slot number)
-            const bool hit = symhit & !hdr;
-            // a big state continues on this high symbol: its child's entry is the slot `first child of the group + set
-            // bits below the symbol's`; the next trip probes it as the state "slot ^ symbol" and consumes the unit
-            const bool redir = grp & probe & ((en.x >> (code & 31u)) & 1u) != 0u;
-            const uint32_t rE = (__builtin_popcount(en.x & ~(~0u << (code & 31u))) + en.y ^ code) | kUAllFilter;
-            // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip;
-            // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or the state's header,
-            // fetched by the next trip (falling into a state reports nothing: END is not carried)
-            const bool viaroot = !symhit & !redir & (!u_nfr(E) | !good);
-            const uint32_t ft = u_f1(E) ? (rf & 0x7FFFFFFFu) : (Bq | kUAllFilter | 0x20000000u);
-            uint32_t missE = viaroot ? rt : ft;
-            missE = redir ? rE : missE;
-            E = symhit ? en.x : missE;
-            const bool consumed = hit | viaroot;
-            const bool end = consumed & u_end(E);
-            const uint32_t c4 = hit ? u_c4(en.y) : 1u;
-            pc = consumed ? code : pc;
-            const uint32_t adv = consumed ? Lb : 0u;
-            if (CHARS) {  // characters that START in the lane's chunk (the rest of a chunk's bytes are continuation bytes)
-              const uint32_t isl = (consumed & (int32_t)rel >= a_rel) ? (L >> 8) : 0u;
-              lc += isl;
-              lead_total += isl;
+            const bool probe = act & good & (((E | 0x20000000u) >> (22u + (code & 7u))) & 1u) != 0u & Bq != 0u;
+            unsigned long long enw = 0;
+#ifndef AHA_LAB_NO_PROBE
+            {
+              const uint2 *ap = slots + AHA_LAB_PROBE_INDEX(probe ? (Bq ^ se) : 0u);
+              asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(enw) : "v"(ap) : "memory");
             }
-            rel += adv;
-            const bool park = consumed & n_later;  // the next unit waits for the next round
-            lim2 = park ? rel : lim2;
-            lim = park ? rel : lim;
-            code = consumed ? n_code : code;  // (a trip that falls to the fail state tries the same unit again)
-            L = consumed ? n_L : L;
-            const int32_t last = (int32_t)rel - 1;  // row index of the unit's last byte
-            // is_end? -> fetch later (ac.cr:183-185); this lane reports the end positions in [a, e)
-            evc = (end & last >= a_rel & last < e_rel) ? c4 : 0u;
-#ifdef AHA_LAB_NO_EVENTS
-            evc = 0u;
 #endif
-          }
+            if (act) {
+              uint32_t n_code, n_L;
+              bool n_later;
+              const uint32_t Lb = CHARS ? (L & 0xFFu) : L;  // (CHARS: bit 8 = the unit is a character)
+              decode(rel + Lb, n_code, n_L, n_later);  // rows are padded: rel + 3 + 8 bytes stay inside LDS
+              // Every select below picks between values that are already computed (plain locals): that keeps them
+              // v_cndmask instead of nested divergent branches, which cost more than the work they skip.
+              // ---- the root's transitions (LDS) on the unit (symbol 0 -- a bad unit or one outside the alphabet -- has
+              // none) and on the symbol that led to the current state: the one-character state a two-character state
+              // fails to
+              const uint32_t rt = rl[code];
+              const uint32_t rf = rl[pc];
+#ifndef AHA_LAB_NO_PROBE
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(enw) : : "memory");
+#endif
+              const uint32_t enx = (uint32_t)enw, eny = (uint32_t)(enw >> 32);
+              const bool symhit = probe & u_sym(eny) == se & !grp;  // (a group record's second word is a slot number)
+              const bool hit = symhit & !hdr;
+              // a big state continues on this high symbol: its child's entry is the slot `first child of the group + set
+              // bits below the symbol's`; the next trip probes it as the state "slot ^ symbol" and consumes the unit
+              const bool redir = grp & probe & ((enx >> (code & 31u)) & 1u) != 0u;
+              const uint32_t rE = (__builtin_popcount(enx & ~(~0u << (code & 31u))) + eny ^ code) | kUAllFilter;
+              // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip;
+              // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or the state's header,
+              // fetched by the next trip (falling into a state reports nothing: END is not carried)
+              const bool viaroot = !symhit & !redir & (!u_nfr(E) | !good);
+              const uint32_t ft = u_f1(E) ? (rf & 0x7FFFFFFFu) : (Bq | kUAllFilter | 0x20000000u);
+              uint32_t missE = viaroot ? rt : ft;
+              missE = redir ? rE : missE;
+              E = symhit ? enx : missE;
+              const bool consumed = hit | viaroot;
+              const bool end = consumed & u_end(E);
+              const uint32_t c4 = hit ? u_c4(eny) : 1u;
+              pc = consumed ? code : pc;
+              const uint32_t adv = consumed ? Lb : 0u;
+              if (CHARS) {  // characters that START in the lane's chunk (the rest of a chunk's bytes are continuation bytes)
+                const uint32_t isl = (consumed & (int32_t)rel >= a_rel) ? (L >> 8) : 0u;
+                lc += isl;
+                lead_total += isl;
+              }
+              rel += adv;
+              const bool park = consumed & n_later;  // the next unit waits for the next round
+              lim2 = park ? rel : lim2;
+              lim = park ? rel : lim;
+              code = consumed ? n_code : code;  // (a trip that falls to the fail state tries the same unit again)
+              L = consumed ? n_L : L;
+              const int32_t last = (int32_t)rel - 1;  // row index of the unit's last byte
+              // is_end? -> fetch later (ac.cr:183-185); this lane reports the end positions in [a, e)
+              evc = (end & last >= a_rel & last < e_rel) ? c4 : 0u;
+#ifdef AHA_LAB_NO_EVENTS
+              evc = 0u;
+#endif
+            }
+            return evc;
+          };
+          const uint32_t evc = trip();
           const uint64_t evm = wballot(evc != 0u);
           if (evm) {
             // (a lane may send more than its region holds -- the call is repeated with larger regions then, see below --

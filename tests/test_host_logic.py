@@ -315,3 +315,17 @@ def test_replicate_needs_a_device_and_a_handle():
     assert rc in (N.AHA_E_NO_DEVICE, N.AHA_OK)
     if rc == N.AHA_OK:
         N.lib().aha_ac_free(out)
+
+
+def test_hand_issued_probe_is_not_touched_before_its_wait():
+    """ku_traverse issues its probe by inline asm (invisible to hipcc's wait insertion): the ISA must not read, copy or
+    overwrite the destination registers between the load and the hand-written s_waitcnt (tools/audit_probe.py)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_probe.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

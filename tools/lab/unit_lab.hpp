@@ -15,4 +15,6 @@
 #elif AHA_UNIT_LAB == 6  // no probe, nothing reported: the walk's instruction floor
 #define AHA_LAB_NO_PROBE 1
 #define AHA_LAB_NO_EVENTS 1
+#elif AHA_UNIT_LAB == 7  // a full event buffer is stored where it fills (round 3's way), not behind the next trip's probe
+#define AHA_LAB_IMMEDIATE_FLUSH 1
 #endif

@@ -19,9 +19,14 @@ def audit(isa):
             seen += 1
             j = i + 3  # behind ASMEND
             ok = False
+            in_asm = False
             while j < len(lines):
                 t = lines[j]
-                if "s_waitcnt vmcnt" in t and "#ASMSTART" in lines[j - 1]:
+                if "#ASMSTART" in t:
+                    in_asm = True
+                elif "#ASMEND" in t:
+                    in_asm = False
+                if in_asm and "s_waitcnt vmcnt" in t:  # the hand-written wait (hipcc's own are outside asm statements)
                     ok = True
                     break
                 if t.strip().startswith(("s_endpgm", "s_setpc")):

@@ -57,7 +57,7 @@ class aha_timing(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_kernels", C.c_uint32), ("ms_total", C.c_float),
                 ("ms_count", C.c_float), ("ms_scan", C.c_float), ("ms_write", C.c_float),
                 ("ms_aux", C.c_float), ("n_chunks", C.c_uint64), ("n_hits", C.c_uint64), ("engine", C.c_uint32),
-                ("chunk_bytes", C.c_uint32)]
+                ("chunk_bytes", C.c_uint32), ("repeats", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class aha_stream_seg(C.Structure):

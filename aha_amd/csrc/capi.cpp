@@ -180,6 +180,13 @@ uint64_t scratch_bytes(const Scratch *sc) {
   return n;
 }
 
+// adds the passes that were thrown away to the timing the last pass published (profiling on)
+void note_repeats(aha_ac *ac, uint32_t repeats) {
+  if (!ac->profiling.load()) return;
+  std::lock_guard<std::mutex> lk(ac->last_mu);
+  ac->last.repeats = repeats;
+}
+
 void publish_timing(aha_ac *ac, const aha_timing &t) {
   std::lock_guard<std::mutex> lk(ac->last_mu);
   ac->last = t;
@@ -619,6 +626,7 @@ struct DeviceGuard {
 // beside the image and only the match_longest kernels read it.
 int32_t ensure_stale(aha_ac *ac) {
   std::call_once(ac->stale_once, [ac]() {
+   try {
     cedar_stale_ends(ac->aut, ac->stale_states);
     ac->dev_longest = ac->dev;
     ac->dev_longest.stale_bits = nullptr;
@@ -640,6 +648,9 @@ int32_t ensure_stale(aha_ac *ac) {
     std::vector<uint32_t> bits(((size_t)ac->n_slots + 31) / 32, 0u);
     for (uint32_t s : ac->stale_states) bits[ac->state_base[s] >> 5] |= 1u << (ac->state_base[s] & 31);
     ac->stale_rc = upload(ac, bits, &ac->dev_longest.stale_bits);
+   } catch (...) {  // bad_alloc of the replay or of a bitmap: no exception crosses the C boundary
+    ac->stale_rc = AHA_E_NOMEM;
+   }
   });
   return ac->stale_rc;
 }
@@ -721,11 +732,8 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
   // AHA_SHADOW_FAIL=0 keeps a header for every state.
   const char *sf = getenv("AHA_SHADOW_FAIL");
   bool shadow = !(sf && strcmp(sf, "0") == 0);
-  // A small automaton that fits LDS with a header for every state keeps them: its kernel (ALL_LDS) reads the
-  // header beside the probe, which is cheaper than keeping the shadow state.
-  const char *hf = getenv("AHA_HEADERS_FIRST");
-  bool try_headers_first = shadow && (size_t)ac->aut.n_states * 2 * 8 <= kLdsPerCU && !(hf && strcmp(hf, "0") == 0);
-  if (try_headers_first) shadow = false;
+  // (until round 4 a small automaton that fits LDS kept a header for every state and ran a trip of its own; the shadow
+  // fail links take cfg 2 from 1.55 to 1.02 trips per byte, so it gets the same image and trip as everyone else)
   for (;;) {
     place_states(ac->aut, pl, shadow, shadow);
     if (!encode_image(ac->aut, pl, (flags & AHA_OPT_FORCE_WIDE) != 0, img)) {
@@ -736,12 +744,6 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     ac->compact = img.compact;
     ac->slot_bytes = img.compact ? 4 : 8;
     plan_engine(ac, pl);
-    if (try_headers_first) {
-      try_headers_first = false;
-      if (ac->v2_lds_slots >= ac->n_slots) break;  // fits: done
-      shadow = true;
-      continue;
-    }
     // the traversal probes the depth-1 rows in LDS to keep the shadow state: they must all be resident
     if (!shadow || pl.seg_start[2] <= ac->v2_lds_slots) break;
     shadow = false;
@@ -844,7 +846,9 @@ static StreamFmt stream_fmt(const aha_ac *ac) {
     return b;
   };
   const uint32_t vb = std::max(1u, bits(ac->aut.n_keys ? ac->aut.n_keys - 1 : 0)), lb = std::max(1u, bits(ac->aut.max_key_len));
-  if (vb + lb + 6 <= 32) return StreamFmt{std::min(12u, 32 - vb - lb), lb};
+  // (a step field below 10 bits makes every gap of 1 KiB an exception -- 4 more bytes on the link --, which costs a
+  // sparse hit stream more than the key-length lookup on arrival saves: then the word carries id and a 12-bit step only)
+  if (vb + lb + 10 <= 32) return StreamFmt{std::min(12u, 32 - vb - lb), lb};
   return StreamFmt{12, 0};
 }
 
@@ -1222,13 +1226,13 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
       launch_has_nul(d_corpus, n_bytes, sc->d_totals + 1, s);
       HIPCHK(ac, hipMemcpyAsync(sc->h_totals, sc->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
       HIPCHK(ac, hipStreamSynchronize(s));
-      if (sc->h_totals[1]) mode = 3;
+      M.has_nul = sc->h_totals[1] ? 1 : 0;  // the chunks' warm-ups then reach back past the NULs they cross (kernels.hip)
     }
     M.chunk = 1024;
     while (M.chunk < 16ull * ac->aut.max_key_len && M.chunk < (1u << 20)) M.chunk *= 2;  // the warm-up is 2 * Lmax
     M.n_chunks = (n_bytes + M.chunk - 1) / M.chunk;
     const uint64_t units = mode == 2 ? M.n_chunks : n_docs + 1;
-    const uint64_t n_blocks = (units + kBlock - 1) / kBlock;
+    uint64_t n_blocks = (units + kBlock - 1) / kBlock;
     if ((rc = ensure_scratch(ac, sc, units, n_blocks, n_docs))) return rc;
     M.counts = sc->d_counts;
     M.leads = sc->d_leads;
@@ -1239,6 +1243,23 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
     const int chars = M.chars;
     if ((rc = ensure_stale(ac))) return rc;
     launch_longest(ac->dev_longest, M, mode, false, s);
+    if (mode == 2 && M.has_nul) {  // a chunk whose warm-up would not end (a NUL every few bytes) gave up: document by document
+      HIPCHK(ac, hipMemcpyAsync(sc->h_totals, sc->d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+      HIPCHK(ac, hipStreamSynchronize(s));
+      if (sc->h_totals[1] == 2) {
+        mode = 3;
+        const uint64_t units3 = n_docs + 1, blocks3 = (units3 + kBlock - 1) / kBlock;
+        if ((rc = ensure_scratch(ac, sc, units3, blocks3, n_docs))) return rc;
+        M.counts = sc->d_counts;
+        M.leads = sc->d_leads;
+        M.blk_hits = sc->d_blk_hits;
+        M.blk_leads = sc->d_blk_leads;
+        M.docg = sc->d_docg;
+        M.totals = sc->d_totals;
+        n_blocks = blocks3;
+        launch_longest(ac->dev_longest, M, mode, false, s);
+      }
+    }
     M.chars = 0;  // the block scan has no lead counts to scan here
     launch_scan_blocks(M, n_blocks, s);
     M.chars = chars;
@@ -1253,10 +1274,15 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
     }
     return AHA_OK;
   }
+  uint32_t repeats = 0;  // passes thrown away (aha_timing.repeats)
   if (ac->v2_ok) {
     rc = match_v2(ac, sc, M, s, n_hits, kRegions);
-    if (rc == 2) rc = match_v2(ac, sc, M, s, n_hits, kFullRegions);  // denser than cap said: regions of one event per byte
-    if (rc == 2) rc = match_v2(ac, sc, M, s, n_hits, kSlabs);        // (not reached: full-size regions cannot overflow)
+    if (rc == 2) {  // denser than cap said: regions of one event per byte
+      repeats++;
+      rc = match_v2(ac, sc, M, s, n_hits, kFullRegions);
+    }
+    if (rc == 2) rc = match_v2(ac, sc, M, s, n_hits, kSlabs);  // (not reached: full-size regions cannot overflow)
+    if (rc == AHA_OK && repeats) note_repeats(ac, repeats);
     if (rc < 0) return rc;
     if (rc == AHA_OK) {
       if (*n_hits > cap) {
@@ -1266,6 +1292,7 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
       return AHA_OK;
     }
     *n_hits = 0;  // rc == 1: fall through to the two-pass engine
+    repeats++;
   }
   M.chunk = ac->chunk;
   // warm-up is Lmax-1 bytes per chunk: keep it a small fraction of the chunk
@@ -1311,6 +1338,7 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
     t.n_hits = *n_hits;
     t.engine = 1;
     t.chunk_bytes = M.chunk;
+    t.repeats = repeats;
     publish_timing(ac, t);
   }
   if (*n_hits > cap) {

@@ -324,7 +324,10 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   aha_ac_info_t info{};
   info.struct_size = sizeof(info);
   (void)aha_ac_info(g->shards[0].ac, &info);
-  const bool words = (n > 1 || via == kSelfRccl) && info.n_keys <= (1u << 20);
+  // (the 4-byte stream's own condition, aha_ac_hits_pack4_device: ids beyond 2^20 need the length in the word)
+  uint32_t sf_step = 0, sf_len = 0;
+  const bool fits = aha_ac_stream_format(g->shards[0].ac, &sf_step, &sf_len) == AHA_OK && (sf_len != 0 || info.n_keys <= (1u << 20));
+  const bool words = (n > 1 || via == kSelfRccl) && fits;
   const int chars = (params && params->char_offsets) ? 1 : 0;
   std::vector<uint64_t> ebase(n + 1, 0);  // in 32-bit elements
   if (words) {

@@ -49,6 +49,7 @@ struct MatchArgs {
   int32_t chars;             // 1: String overload, char offsets (matcher.cr:34-39)
   int32_t sep;               // 1: match(seq, sep) (ac.cr:321-340)
   uint32_t sep_block[8];     // bit c set <=> (c < sep.size && !sep[c])
+  int32_t has_nul;           // match_longest, chunked form: the batch holds NUL bytes (the warm-ups look for them)
   // scratch
   uint32_t *counts;          // [n_chunks] hits per chunk
   uint32_t *leads;           // [n_chunks] UTF-8 lead bytes per chunk (chars mode)

@@ -364,7 +364,36 @@ __global__ __launch_bounds__(kBlock) void k_longest_chunks(DevAut A, MatchArgs M
     uint64_t p = a;
     if (nb != a) {
       doc_start = M.doc_off[dn - 1];
-      p = a - min<uint64_t>(a - doc_start, 2ull * A.max_len);
+      const uint64_t W = 2ull * A.max_len;
+      p = a - min<uint64_t>(a - doc_start, W);
+      if (M.has_nul) {
+        // A NUL makes the byte behind it vanish or not depending on the state it meets (kValueNode), so the state behind
+        // a NUL is exact only if the state AT the NUL was: the warm-up must reach 2 * Lmax NUL-free bytes in front of the
+        // earliest NUL it crosses (or the start of the document, or two NULs in a row: whatever the first one did, the
+        // state behind the second is the root).  Text with a NUL every few bytes (UTF-16) would walk back for ever: past
+        // kNulBack bytes the chunk gives up and the host runs the batch document by document (totals[1] = 2).
+        constexpr uint64_t kNulBack = 4096;
+        uint64_t hi = a;  // [p, hi) has not been searched yet
+        for (;;) {
+          uint64_t z = ~0ull;
+          for (uint64_t q = p; q < hi; q++)
+            if (M.text[q] == 0) {
+              z = q;
+              break;
+            }
+          if (z == ~0ull || p == doc_start) break;  // a clean warm-up, or the walk starts with the document: exact
+          if (z > doc_start && M.text[z - 1] == 0) {  // two in a row: the root behind them
+            p = z + 1;
+            break;
+          }
+          if (a - z > kNulBack) {
+            M.totals[1] = 2ull;
+            break;
+          }
+          hi = z;
+          p = z - min<uint64_t>(z - doc_start, W);
+        }
+      }
     }
     uint32_t B = A.root;
     const uint32_t lc = 0;  // byte offsets only: char offsets take the per-document kernel (launch_longest)

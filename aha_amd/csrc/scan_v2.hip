@@ -110,7 +110,10 @@ __device__ uint32_t g_diag_stamps[256 * (kV2Threads / 64) * 16];
 #define AHA_STAMP(t) (void)(t)
 #endif
 
-// ALL_LDS: the whole image fits the LDS budget (cfg 2): no HBM probe path at all.
+// ALL_LDS: the whole image fits the LDS budget (cfg 2): the same trip, every lookup a ds_read (no far path).  (Until round 4
+// such automata kept a fail header for every state and ran a trip of their own that read the header beside the probe:
+// 1.55 trips per byte on cfg 2; with the shadow fail links of the partial-prefix trip 1.02, 6 % less time even through the
+// flat path -- profiles/r04_bench_cfg2_*.)
 #ifndef AHA_V2_WAVES_PER_SIMD
 #define AHA_V2_WAVES_PER_SIMD 4  // one 1024-thread workgroup per CU; 8 = two (lab: does the occupancy pay?)
 #endif
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
         }
         const uint32_t lim2 = min(lim, nb_rel);  // lanes park at the next boundary: no boundary test per trip
         uint32_t bcur = 0;
-        if constexpr (!ALL_LDS) bcur = inl[min(rel, (uint32_t)kV2Piece)];  // first byte of this run of trips
+        bcur = inl[min(rel, (uint32_t)kV2Piece)];  // first byte of this run of trips
       for (;;) {
         const bool act = rel < lim2;
         if (!__any(act)) break;
@@ -319,186 +322,125 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
         [[maybe_unused]] unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dt3 = 0, dt4 = 0, dt5 = 0;
         [[maybe_unused]] bool dg_anyfar = false;
         if (act) {
-          if constexpr (ALL_LDS) {
-            const uint32_t b = inl[rel];
-            const uint32_t idx = hdr ? B : (B ^ b);
-            // the root row is always LDS resident: its probe is issued beside the
-            // state's own lookup, so "fail to root, retry the byte there" costs no extra trip
-            const slot_t e0 = lt[root ^ b];
-            // ALL_LDS (small automata, a fail header for every state): the header of the current state is loaded
-            // beside the probe and used on a non-root miss -- cfg 2 runs 1.55 instead of 2.1 trips per byte.
-            slot_t eh = e0;
-            if constexpr (ALL_LDS) eh = lt[B];
-            slot_t en;
-            if (ALL_LDS || idx < T)
+          // Partial prefix: the trip with few mask operations.  A header trip is a probe with label 0 (the
+          // header slot is slot[B ^ 0] and carries label 0), so one compare serves goto and header alike;
+          // `hm` is 0xFF in a probe trip and 0 in a header trip.
+          // the byte comes from a register: the next one was loaded during the previous trip (nearly every trip
+          // consumes), which takes the LDS round trip of the byte out of the dependent chain
+          const uint32_t b = bcur;
+          if constexpr (DG == kDgStamp) AHA_STAMP(dt0);
+          const uint32_t bnext = inl[rel + 1];                    // rows are padded: rel + 1 <= piece + 3
+          const uint32_t c = b & hm;
+          if constexpr (kLeanPack) B = (uint32_t)S_::base((slot_t)E);
+          uint32_t idx = B ^ c;
+          // timing-only variants redirect PROBE trips only: a header trip (hm == 0) that never finds its header would
+          // repeat forever
+          if constexpr (DG == kDgNoFar || DG == kDgNoFarNoStore) idx = (idx < T || hm == 0) ? idx : (idx & 16383u);
+          if constexpr (DG == kDgFarHalf)
+            idx = (idx >= T && hm != 0 && ((idx * 0x9E3779B1u) >> 31)) ? (idx & 16383u) : idx;
+          if constexpr (DG == kDgFar40)
+            idx = (idx >= T && hm != 0 && ((idx * 0x9E3779B1u) >> 24) < 102u) ? (idx & 16383u) : idx;
+          if constexpr (DG == kDgFarL1) idx = (idx < T || hm == 0) ? idx : T + (idx & 2047u);
+          if constexpr (DG == kDgStamp) dg_anyfar = __any(idx >= T);
+          const slot_t e0 = lt[root ^ b];                         // root row: always LDS resident
+          const slot_t e2 = lt[S_::base(r1) ^ b];                 // depth-1 rows: always LDS resident
+          const slot_t sx = B < A.s2_lo ? r1 : s2;                // shadow fail target of B (if B has one)
+          const uint32_t i3 = S_::base(sx) ^ b;
+          const bool near3 = i3 < T;
+          const slot_t e3 = lt[near3 ? i3 : 0u];                  // sx's row (depth <= 2: mostly LDS resident)
+          slot_t en;
+          if constexpr (DG == kDgSplit || DG == kDgFarNt || DG == kDgFarSc1 || DG == kDgFarWide) {
+            en = lt[idx < T ? idx : 0u];
+            if (idx >= T) {
+              if constexpr (DG == kDgFarNt) {  // hipcc drops __builtin_nontemporal_* on gfx950: buffer load with aux = nt
+                en = __builtin_amdgcn_raw_buffer_load_b32(
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<slot_t *>(gt), 0, (int)(A.n_slots * 4u), 0x00020000),
+                    (int)(idx * 4u), 0, 2);
+              } else if constexpr (DG == kDgFarSc1) {
+                en = __hip_atomic_load(gt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              } else if constexpr (DG == kDgFarWide) {
+                const uint2 w2 = *reinterpret_cast<const uint2 *>(gt + (idx & ~1u));
+                en = (idx & 1u) ? w2.y : w2.x;
+              } else {
+                en = gt[idx];
+              }
+            }
+          } else if constexpr (kLeanSplit) {
+            en = lt[min(idx, T)];                                 // slot[T] is the first input row: readable, never used
+            if (idx >= T) en = gt[idx];
+          } else if constexpr (ALL_LDS) {
+            en = lt[idx];                                         // the whole image is in LDS: no far path
+          } else {
+            if (idx < T)
               en = lt[idx];
             else
               en = gt[idx];
-            const bool bz = b == 0;                                 // NUL contract: state := root
-            const bool m = !hdr && !bz && S_::match(en, b);         // goto (cedar.cr:441-447)
-            const bool take = hdr || m;                             // state := the entry's target
-            const bool viaroot = !take && (B == root || fr != 0 || bz);  // nid = fails[nid] = root, then probe there
-            const bool mr = !bz && S_::match(e0, b);                // b has a depth-1 state
-            const bool m0 = viaroot && mr;                          // goto from root
-            const bool consumed = m || viaroot;                     // at root a miss consumes the byte (ac.cr:188)
-            // fails[nid] of a deep state = the depth<=2 state of the last two bytes (s2), of a depth-2 state = the
-            // depth-1 state of the last byte (r1): continue there right away -- no header trip, and such states own
-            // no header slot at all (automaton.hpp, Placement::headerless).  All ranges are empty when off.
-            bool s2go = false;
-            slot_t e2 = e0, sx = e0;
-            if constexpr (!ALL_LDS) {
-              const bool s1go = !take && !viaroot && (B - A.s1_lo) < (A.s2_lo - A.s1_lo);
-              s2go = !take && !viaroot && (B - A.s2_lo) < (A.s2_hi - A.s2_lo);
-              e2 = lt[S_::base(r1) ^ b];                            // depth-1 rows are always LDS resident
-              sx = s1go ? r1 : s2;
-              s2go = s2go || s1go;
-            }
-            hdr = !take && !viaroot && !s2go;                       // next trip loads fails[nid] (ac.cr:189)
-            const slot_t ex = s2go ? sx : (m0 ? e0 : en);
-            const bool land = take || m0 || s2go;
-            B = land ? S_::base(ex) : (viaroot ? root : B);
-            fr = land ? S_::failroot(ex) : (viaroot ? 0u : fr);
-            if constexpr (ALL_LDS) {
-              if (hdr) {  // follow the fail link in this trip instead of spending one on the header
-                B = S_::base(eh);
-                fr = S_::failroot(eh);
-                hdr = false;
-              }
-            }
-            ev = (m || m0) && S_::end(ex) && emit_ok;               // is_end? -> fetch later (ac.cr:183-185)
-            if constexpr (!ALL_LDS) {
-              // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
-              const bool m2 = !bz && S_::match(e2, b);
-              const slot_t s2n = m2 ? e2 : (mr ? e0 : slot_t{});
-              s2 = consumed ? s2n : s2;
-              r1 = consumed ? (mr ? e0 : slot_t{}) : r1;
-            }
-            if (CHARS) {
-              const uint32_t isl = (consumed && emit_ok && (b & 0xC0u) != 0x80u) ? 1u : 0u;
-              lc += isl;
-              lead_total += isl;
-            }
-            rel += consumed ? 1u : 0u;
-            en_keep = S_::payload(ex);
-          } else {
-            // Partial prefix: the trip with few mask operations.  A header trip is a probe with label 0 (the
-            // header slot is slot[B ^ 0] and carries label 0), so one compare serves goto and header alike;
-            // `hm` is 0xFF in a probe trip and 0 in a header trip.
-            // the byte comes from a register: the next one was loaded during the previous trip (nearly every trip
-            // consumes), which takes the LDS round trip of the byte out of the dependent chain
-            const uint32_t b = bcur;
-            if constexpr (DG == kDgStamp) AHA_STAMP(dt0);
-            const uint32_t bnext = inl[rel + 1];                    // rows are padded: rel + 1 <= piece + 3
-            const uint32_t c = b & hm;
-            if constexpr (kLeanPack) B = (uint32_t)S_::base((slot_t)E);
-            uint32_t idx = B ^ c;
-            // timing-only variants redirect PROBE trips only: a header trip (hm == 0) that never finds its header would
-            // repeat forever
-            if constexpr (DG == kDgNoFar || DG == kDgNoFarNoStore) idx = (idx < T || hm == 0) ? idx : (idx & 16383u);
-            if constexpr (DG == kDgFarHalf)
-              idx = (idx >= T && hm != 0 && ((idx * 0x9E3779B1u) >> 31)) ? (idx & 16383u) : idx;
-            if constexpr (DG == kDgFar40)
-              idx = (idx >= T && hm != 0 && ((idx * 0x9E3779B1u) >> 24) < 102u) ? (idx & 16383u) : idx;
-            if constexpr (DG == kDgFarL1) idx = (idx < T || hm == 0) ? idx : T + (idx & 2047u);
-            if constexpr (DG == kDgStamp) dg_anyfar = __any(idx >= T);
-            const slot_t e0 = lt[root ^ b];                         // root row: always LDS resident
-            const slot_t e2 = lt[S_::base(r1) ^ b];                 // depth-1 rows: always LDS resident
-            const slot_t sx = B < A.s2_lo ? r1 : s2;                // shadow fail target of B (if B has one)
-            const uint32_t i3 = S_::base(sx) ^ b;
-            const bool near3 = i3 < T;
-            const slot_t e3 = lt[near3 ? i3 : 0u];                  // sx's row (depth <= 2: mostly LDS resident)
-            slot_t en;
-            if constexpr (DG == kDgSplit || DG == kDgFarNt || DG == kDgFarSc1 || DG == kDgFarWide) {
-              en = lt[idx < T ? idx : 0u];
-              if (idx >= T) {
-                if constexpr (DG == kDgFarNt) {  // hipcc drops __builtin_nontemporal_* on gfx950: buffer load with aux = nt
-                  en = __builtin_amdgcn_raw_buffer_load_b32(
-                      __builtin_amdgcn_make_buffer_rsrc(const_cast<slot_t *>(gt), 0, (int)(A.n_slots * 4u), 0x00020000),
-                      (int)(idx * 4u), 0, 2);
-                } else if constexpr (DG == kDgFarSc1) {
-                  en = __hip_atomic_load(gt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if constexpr (DG == kDgFarWide) {
-                  const uint2 w2 = *reinterpret_cast<const uint2 *>(gt + (idx & ~1u));
-                  en = (idx & 1u) ? w2.y : w2.x;
-                } else {
-                  en = gt[idx];
-                }
-              }
-            } else if constexpr (kLeanSplit) {
-              en = lt[min(idx, T)];                                 // slot[T] is the first input row: readable, never used
-              if (idx >= T) en = gt[idx];
-            } else {
-              if (idx < T)
-                en = lt[idx];
-              else
-                en = gt[idx];
-            }
-            if constexpr (DG == kDgAddFar) {
-              if (idx >= T) dg_dummy ^= (uint32_t)gt[(idx * 2654435761u) >> dg_shift];
-            }
-            if constexpr (DG == kDgAddLds) dg_dummy ^= (uint32_t)lt[(idx ^ 0x1555u) & 16383u];
-            if constexpr (DG == kDgStamp) AHA_STAMP(dt1);           // the LDS reads are back (the stamp waits lgkmcnt(0))
-            const bool nz = kLeanNoNul ? true : b != 0;
-            const bool probe = hm != 0;
-            const bool bzp = !nz && probe;                          // NUL contract: state := root, byte consumed
-            bool atroot = B == root || fr != 0 || bzp;              // fails[nid] = root: probe the root row now
-            if constexpr (kLeanPack) atroot = (E & C_FAILROOT) != 0;
-            const bool mr = nz && S_::match(e0, b);                 // b has a depth-1 state
-            // fails[nid] of a state in [s1_lo, s2_hi) follows from the last bytes: sx = r1 (depth-2 state) or s2.
-            // Its row, the row of ITS fail target (r1: e2) and the root row (e0) are probed in this same trip, so
-            // the whole rest of the fail chain is resolved here and the byte is consumed (1.19 -> 1.02 trips per
-            // byte); only when sx's row lies beyond the LDS prefix the walk continues in sx without consuming.
-            const bool m3 = nz && S_::match(e3, b);
-            const bool m2 = nz && S_::match(e2, b);
-            const slot_t chain = m3 ? e3 : (m2 ? e2 : (mr ? e0 : slot_t{}));   // first goto along sx -> r1 -> root
-            // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
-            const slot_t r1n = mr ? e0 : slot_t{};
-            const slot_t s2n = m2 ? e2 : r1n;
-            const bool shadow = !atroot && (B - A.s1_lo) < (A.s2_hi - A.s1_lo);
-            if constexpr (DG == kDgAddValu) {
-              asm volatile("v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
-                           "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
-                           "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
-                           "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
-                           : "+v"(dg_dummy)
-                           : "v"(b));
-            }
-            if constexpr (DG == kDgStamp) {
-              AHA_STAMP(dt2);                                       // everything that does not need the probe is done
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(en)::"memory");
-              AHA_STAMP(dt3);                                       // the probe (and the previous trip's event store) is back
-            }
-            const bool t = S_::match(en, c) && !bzp;                // goto (cedar.cr:441-447), or the header itself
-            const bool sgo = !t && shadow;
-            const bool sres = sgo && near3;
-            slot_t ex = t ? en : (sgo ? (near3 ? chain : sx) : (mr ? e0 : slot_t{}));
-            if constexpr (kLeanPack) {  // "no state" is the root's entry: base 0, fails to the root
-              const slot_t re = (slot_t)C_FAILROOT;
-              const slot_t chain_r = m3 ? e3 : (m2 ? e2 : (mr ? e0 : re));
-              ex = t ? en : (sgo ? (near3 ? chain_r : sx) : (mr ? e0 : re));
-            }
-            const bool land = t || atroot || sgo;                   // else: the next trip loads fails[nid] (ac.cr:189)
-            const bool consumed = (t && probe) || (!t && atroot) || sres;  // at root a miss consumes (ac.cr:188)
-            if constexpr (kLeanPack) {
-              E = land ? (uint32_t)ex : E;
-            } else {
-              B = land ? S_::base(ex) : B;
-              fr = land ? S_::failroot(ex) : fr;
-            }
-            hm = land ? 0xFFu : 0u;
-            ev = consumed && S_::end(ex) && emit_ok;                // is_end? -> fetch later (ac.cr:183-185)
-            s2 = consumed ? s2n : s2;
-            r1 = consumed ? r1n : r1;
-            if (CHARS) {
-              const uint32_t isl = (consumed && emit_ok && (b & 0xC0u) != 0x80u) ? 1u : 0u;
-              lc += isl;
-              lead_total += isl;
-            }
-            rel += consumed ? 1u : 0u;
-            bcur = consumed ? bnext : bcur;
-            if constexpr (DG == kDgStamp) AHA_STAMP(dt4);
-            en_keep = S_::payload(ex);
           }
+          if constexpr (DG == kDgAddFar) {
+            if (idx >= T) dg_dummy ^= (uint32_t)gt[(idx * 2654435761u) >> dg_shift];
+          }
+          if constexpr (DG == kDgAddLds) dg_dummy ^= (uint32_t)lt[(idx ^ 0x1555u) & 16383u];
+          if constexpr (DG == kDgStamp) AHA_STAMP(dt1);           // the LDS reads are back (the stamp waits lgkmcnt(0))
+          const bool nz = kLeanNoNul ? true : b != 0;
+          const bool probe = hm != 0;
+          const bool bzp = !nz && probe;                          // NUL contract: state := root, byte consumed
+          bool atroot = B == root || fr != 0 || bzp;              // fails[nid] = root: probe the root row now
+          if constexpr (kLeanPack) atroot = (E & C_FAILROOT) != 0;
+          const bool mr = nz && S_::match(e0, b);                 // b has a depth-1 state
+          // fails[nid] of a state in [s1_lo, s2_hi) follows from the last bytes: sx = r1 (depth-2 state) or s2.
+          // Its row, the row of ITS fail target (r1: e2) and the root row (e0) are probed in this same trip, so
+          // the whole rest of the fail chain is resolved here and the byte is consumed (1.19 -> 1.02 trips per
+          // byte); only when sx's row lies beyond the LDS prefix the walk continues in sx without consuming.
+          const bool m3 = nz && S_::match(e3, b);
+          const bool m2 = nz && S_::match(e2, b);
+          const slot_t chain = m3 ? e3 : (m2 ? e2 : (mr ? e0 : slot_t{}));   // first goto along sx -> r1 -> root
+          // the byte was consumed: new depth<=2 state of the last two bytes, new depth-1 entry
+          const slot_t r1n = mr ? e0 : slot_t{};
+          const slot_t s2n = m2 ? e2 : r1n;
+          const bool shadow = !atroot && (B - A.s1_lo) < (A.s2_hi - A.s1_lo);
+          if constexpr (DG == kDgAddValu) {
+            asm volatile("v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
+                         "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
+                         "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
+                         "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
+                         : "+v"(dg_dummy)
+                         : "v"(b));
+          }
+          if constexpr (DG == kDgStamp) {
+            AHA_STAMP(dt2);                                       // everything that does not need the probe is done
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(en)::"memory");
+            AHA_STAMP(dt3);                                       // the probe (and the previous trip's event store) is back
+          }
+          const bool t = S_::match(en, c) && !bzp;                // goto (cedar.cr:441-447), or the header itself
+          const bool sgo = !t && shadow;
+          const bool sres = sgo && near3;
+          slot_t ex = t ? en : (sgo ? (near3 ? chain : sx) : (mr ? e0 : slot_t{}));
+          if constexpr (kLeanPack) {  // "no state" is the root's entry: base 0, fails to the root
+            const slot_t re = (slot_t)C_FAILROOT;
+            const slot_t chain_r = m3 ? e3 : (m2 ? e2 : (mr ? e0 : re));
+            ex = t ? en : (sgo ? (near3 ? chain_r : sx) : (mr ? e0 : re));
+          }
+          const bool land = t || atroot || sgo;                   // else: the next trip loads fails[nid] (ac.cr:189)
+          const bool consumed = (t && probe) || (!t && atroot) || sres;  // at root a miss consumes (ac.cr:188)
+          if constexpr (kLeanPack) {
+            E = land ? (uint32_t)ex : E;
+          } else {
+            B = land ? S_::base(ex) : B;
+            fr = land ? S_::failroot(ex) : fr;
+          }
+          hm = land ? 0xFFu : 0u;
+          ev = consumed && S_::end(ex) && emit_ok;                // is_end? -> fetch later (ac.cr:183-185)
+          s2 = consumed ? s2n : s2;
+          r1 = consumed ? r1n : r1;
+          if (CHARS) {
+            const uint32_t isl = (consumed && emit_ok && (b & 0xC0u) != 0x80u) ? 1u : 0u;
+            lc += isl;
+            lead_total += isl;
+          }
+          rel += consumed ? 1u : 0u;
+          bcur = consumed ? bnext : bcur;
+          if constexpr (DG == kDgStamp) AHA_STAMP(dt4);
+          en_keep = S_::payload(ex);
         }
         if (__any(ev)) {
           if (M.direct) {
@@ -1106,7 +1048,7 @@ void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *s
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = v2_lds_bytes(M.lds_slots, A.compact != 0);
   {
-    const bool all = M.lds_slots >= A.n_slots && A.s2_hi == 0;  // whole image in LDS and a header for every state
+    const bool all = M.lds_slots >= A.n_slots;  // the whole image is in LDS
 #ifdef AHA_DIAG
     if (g_diag_knob != kDgNone && A.compact && !M.chars && !all) {
       diag_launch(A, M, grid, lds, s);

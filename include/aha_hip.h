@@ -143,6 +143,12 @@ typedef struct {
   uint64_t n_hits;
   uint32_t engine;          /* 4 = character-level traversal, 2 = single-traversal engine, 1 = two-pass engine */
   uint32_t chunk_bytes;     /* bytes per lane chunk */
+  /* ABI 6: passes over the batch that were thrown away before this one: 1 when a chunk's event region overflowed -- the
+   * batch was denser than `cap` said -- and the match ran once more with full-size regions (the call took about twice
+   * the time: give a capacity nearer to the hits to avoid it); +1 when the event temp overflowed and the two-pass engine
+   * took over. */
+  uint32_t repeats;
+  uint32_t reserved;
 } aha_timing;
 
 const char *aha_strerror(int32_t code);

@@ -159,7 +159,11 @@ def test_match_longest_random(seed):
     assert stale_paths_of(g, keys) == stale
     docs = [bytes(rng.choice(alphabet + b" ") for _ in range(rng.choice([0, 1, 2, 7, 100, 1023, 1024, 1025, 5000])))
             for _ in range(40)] + [bytes(rng.choice(alphabet) for _ in range(40000))] + \
-           [bytes(rng.choice(alphabet + b"\x00") for _ in range(n)) for n in (3, 50, 3000, 30000)]
+           [bytes(rng.choice(alphabet + b"\x00") for _ in range(n)) for n in (3, 50, 3000, 30000)] + \
+           [bytes(0 if rng.random() < 1 / 300 else rng.choice(alphabet) for _ in range(40000))]  # a NUL now and then: the
+    # chunks' warm-ups reach back past it (kernels.hip, k_longest_chunks); the dense ones above end at a double NUL or give up
+    if seed == 0:  # a NUL behind every byte (UTF-16 read as bytes): the chunked form gives up, document by document
+        docs.append(b"".join(bytes([rng.choice(alphabet), 0]) for _ in range(6000)))
     offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
     corpus = np.frombuffer(b"".join(docs), dtype=np.uint8)
     for inter in (False, True):
@@ -343,6 +347,31 @@ def test_capacity_error_when_event_temp_overflows():
     rc = N.lib().aha_ac_match_bytes(ac._h, t.ctypes.data, t.size, None, out.ctypes.data, 4, C.byref(n))
     assert rc == N.AHA_E_CAPACITY and n.value == 2 * n_bytes - 1
     assert gpu_list(out) == [(0, 1, 0), (0, 2, 1), (1, 2, 0), (1, 3, 1)]
+
+
+def test_a_repeated_pass_is_reported(engine):
+    """A batch denser than the capacity said overflows a chunk's event region: the match runs once more with full-size
+    regions, bit-exact -- and aha_timing.repeats tells the caller that the call cost two passes."""
+    if engine == "v1":
+        pytest.skip("the two-pass engine has no event regions")
+    import torch
+
+    keys = ["ab", "b", "中", "中国"]
+    ac = AC.compile(keys)
+    ac.set_profiling(True)
+    text = ("ab" * 20000 + "中国" * 20000).encode() + b"x" * 3_000_000  # hits in the first chunks only
+    corpus = np.frombuffer(text, dtype=np.uint8)
+    doc = np.array([0, corpus.size], dtype=np.int64)
+    exp, _ = orc.AC.compile(keys).match_batch(corpus, doc.astype(np.uint64))
+    dc, dd = torch.from_numpy(corpus.copy()).cuda(), torch.from_numpy(doc).cuda()
+    out = torch.zeros((len(exp) + 64, 3), dtype=torch.int32, device="cuda")
+    assert ac.match_batch_device(dc, dd, out) == len(exp)
+    assert out[:len(exp)].cpu().numpy().tobytes() == exp.tobytes()
+    assert ac.last_timing()["repeats"] == 1
+    # with room for one hit per byte the regions are full size at once
+    out = torch.zeros((corpus.size, 3), dtype=torch.int32, device="cuda")
+    assert ac.match_batch_device(dc, dd, out) == len(exp)
+    assert ac.last_timing()["repeats"] == 0
 
 
 # ---- the BASELINE configs at oracle-sized scale ------------------------------

@@ -91,6 +91,7 @@ struct Shard {
   aha_ac *ac = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t dstream = nullptr;  // the shard's download of its own hits (beside the exchange on `stream`)
   DevBuf corpus, doc, dho, out, all;
   DevBuf pk, land, nw;  // 4-byte exchange stream: packed own hits, landing area of the peers' streams, stream length
   // per call
@@ -171,6 +172,7 @@ void aha_group_free(aha_group *g) {
     s.land.release();
     s.nw.release();
     if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.dstream) (void)hipStreamDestroy(s.dstream);
     if (s.ac) aha_ac_free(s.ac);
   }
   delete g;
@@ -310,6 +312,35 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   // the caller's buffer is too small: say so before anything is exchanged (count and offsets are already final)
   if (total > cap) return fail(AHA_E_CAPACITY, "output buffer too small");
 
+  // ---- the caller's copy: every device sends ITS hits to the host over its own PCIe link (a private stream per shard),
+  // beside the exchange between the devices -- not one device the whole gathered stream behind it
+  const auto t_d = std::chrono::steady_clock::now();
+  std::vector<std::thread> dl;
+  std::vector<int> dl_rc(n, 0);
+  struct JoinAll {
+    std::vector<std::thread> &t;
+    ~JoinAll() {
+      for (auto &x : t)
+        if (x.joinable()) x.join();
+    }
+  } join_dl{dl};
+  if (out)
+    for (size_t r = 0; r < n; r++) {
+      if (!g->shards[r].n_hits) continue;
+      try {
+        dl.emplace_back([&, r]() {
+          Shard &s = g->shards[r];
+          if (hipSetDevice(s.device) != hipSuccess ||
+              (!s.dstream && hipStreamCreateWithFlags(&s.dstream, hipStreamNonBlocking) != hipSuccess) ||
+              hipMemcpyAsync(out + base[r], s.out.p, s.n_hits * sizeof(aha_hit), hipMemcpyDeviceToHost, s.dstream) != hipSuccess ||
+              hipStreamSynchronize(s.dstream) != hipSuccess)
+            dl_rc[r] = 1;
+        });
+      } catch (...) {
+        dl_rc[r] = 1;
+      }
+    }
+
   // ---- all-gatherv of the hit buffers: every device gets the whole ordered stream
   const auto t_x = std::chrono::steady_clock::now();
   for (size_t r = 0; r < n; r++) {
@@ -444,12 +475,11 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   T.exchange = (uint32_t)via;
   T.packed = words ? 1u : 0u;
   g->gathered = total;
-  const auto t_d = std::chrono::steady_clock::now();
-  Shard &s0 = g->shards[0];
-  if (total && (hipSetDevice(s0.device) != hipSuccess ||
-                hipMemcpy(out, s0.all.p, total * sizeof(aha_hit), hipMemcpyDeviceToHost) != hipSuccess))
-    return fail(AHA_E_HIP, "download of the gathered hits failed");
-  T.ms_download = (float)ms_since(t_d);
+  for (auto &x : dl)
+    if (x.joinable()) x.join();
+  for (size_t r = 0; r < n; r++)
+    if (dl_rc[r]) return fail(AHA_E_HIP, "download of a shard's hits failed");
+  T.ms_download = (float)ms_since(t_d);  // (from the first download's start: it runs beside the exchange)
   return AHA_OK;
 }
 

@@ -15,8 +15,9 @@ run() {  # name, args...
   timeout -k 10 280 python3 bench.py --no-cpu-baseline "$@" > "$out/$name.json" 2> "$out/$name.log" || { echo "$name failed"; tail -3 "$out/$name.log"; exit 1; }
   echo "$name done"
 }
-run bench_cfg2_64MiB --config 2 --steps 20 --warmup 3
-run bench_cfg2_1GiB --config 2 --bytes 1073741824 --steps 10 --warmup 3
-run bench_cfg5 --config 5 --steps 5 --warmup 2
-run bench_cfg3_chars --chars --steps 10 --warmup 3
-AHA_ENGINE=v1 run bench_cfg3_v1 --steps 3 --warmup 1
+run bench_cfg2_64MiB --config 2 --steps 20 --warmup 3 --no-end-to-end
+run bench_cfg2_1GiB --config 2 --bytes 1073741824 --steps 10 --warmup 3 --no-end-to-end
+run bench_cfg5 --config 5 --steps 5 --warmup 2 --no-end-to-end
+run bench_cfg3_chars --chars --steps 10 --warmup 3 --no-end-to-end
+AHA_ENGINE=v1 run bench_cfg3_v1 --steps 3 --warmup 1 --no-end-to-end
+AHA_ENGINE=v2 run bench_cfg3_v2 --steps 5 --warmup 2 --no-end-to-end

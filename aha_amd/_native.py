@@ -50,7 +50,8 @@ class aha_ac_info_t(C.Structure):
                 ("fail_s1_lo", C.c_uint32), ("fail_s2_lo", C.c_uint32), ("fail_hdr_lo", C.c_uint32),
                 ("reserved", C.c_uint32), ("unit_enabled", C.c_uint32), ("unit_slots", C.c_uint32),
                 ("unit_syms", C.c_uint32), ("unit_multi_permille", C.c_uint32), ("unit_big_lo", C.c_uint32),
-                ("unit_big_block", C.c_uint32), ("unit_n_low", C.c_uint32), ("unit_n_big", C.c_uint32)]
+                ("unit_big_block", C.c_uint32), ("unit_n_low", C.c_uint32), ("unit_n_big", C.c_uint32),
+                ("unit_base_bits", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class aha_timing(C.Structure):

@@ -379,7 +379,7 @@ void v2_setup(aha_ac *ac) {
     uint32_t max_cnt = 0;
     for (uint32_t k = 0; k < a.n_keys; k++) max_cnt = std::max(max_cnt, a.key_cnt[k]);
     const char *upost = getenv("AHA_UNIT_POST");  // "regroup": the general post passes (tests)
-    const bool fused = !ac->key_info.empty() && max_cnt <= 15 && a.max_key_len < 65536 &&
+    const bool fused = !ac->key_info.empty() && max_cnt <= u_max_c4(ac->unit.base_bits) && a.max_key_len < 65536 &&
                        !(upost && strcmp(upost, "regroup") == 0);
     std::vector<uint2> uend, uendc;
     if (fused) {
@@ -404,12 +404,14 @@ void v2_setup(aha_ac *ac) {
       ac->udev.big_lo = ac->unit.n_shared;
       ac->udev.n_low = ac->unit.n_low;
       ac->udev.g0 = ac->unit.g0;
+      ac->udev.base_bits = ac->unit.base_bits;
       ac->udev.n_syms = ac->unit.n_syms;
       ac->udev.max_len = a.max_key_len;
       ac->unit_ok = true;
       const char *uw = getenv("AHA_UNIT_WALKS");
       // (two walks per lane -- ku2_traverse -- lose to one on every box measured: profiles/r04_two_walks.txt; on request only)
-      ac->unit_walks = (unit2_event_buffer(ac->unit.n_syms) >= kU2MinEventBuffer && uw && strcmp(uw, "2") == 0) ? 2 : 1;
+      ac->unit_walks = (unit2_event_buffer(ac->unit.n_syms) >= kU2MinEventBuffer && ac->unit.base_bits == 22 && uw &&
+                        strcmp(uw, "2") == 0) ? 2 : 1;
     }
   }
 }
@@ -463,6 +465,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.out = M1.out;
   M.cap = M1.cap;
   M.doc_hit_off = M1.doc_hit_off;
+  M.unit_bb = ac->unit.base_bits;
   // plain mode (byte offsets or char offsets, no separator filter): per-chunk event regions, no sort
   const bool dense = M1.cap / 4 > N / 16;          // more than one hit per 4 input bytes expected
   const bool sparse = M1.cap < 16ull * M.n_chunks;  // fewer than 16 hits per chunk expected
@@ -990,6 +993,7 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->unit_big_block = ac->unit.big_block;
   info->unit_n_low = ac->unit.n_low;
   info->unit_n_big = ac->unit.n_big;
+  info->unit_base_bits = ac->unit.ok ? ac->unit.base_bits : 0;
   return AHA_OK;
 }
 

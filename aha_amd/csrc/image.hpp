@@ -116,6 +116,7 @@ struct V2Args {
                              // in the document, hits of the chunk before the event}
   uint32_t *doc_hit_rank;    // [D+1] character-level traversal: hits of the chunk before the document start (exact when no
                              // event stands for more than 15 hits: the record carries the count in bits 28..31 then)
+  uint32_t unit_bb;          // character-level traversal: base width of the image (event records: base | lane << bb | hits << bb + 6)
   uint32_t *chunk_hits;      // [n_chunks]
   uint64_t *hit_base;        // [n_chunks] exclusive scan of chunk_hits
   aha_hit *out;
@@ -132,6 +133,7 @@ struct UnitDev {
   uint32_t big_lo;         // bases from here on are big states: a private block each (unit.hpp, BIG STATES)
   uint32_t n_low;          // symbols below it index a big state's block directly, the others a group record
   uint32_t g0;             // group record of symbol s: base + g0 + (s >> 5)
+  uint32_t base_bits;      // 22 or 23 (unit.hpp, BASE WIDTH)
   uint32_t n_syms;
   uint32_t max_len;        // longest key, bytes
 };

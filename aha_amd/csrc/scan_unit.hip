@@ -78,7 +78,7 @@ __host__ __device__ inline size_t u_lds(uint32_t n_syms) {
 // 0x80..0xBF: one per unit that does not start with a stray continuation byte -- of the lane's chunk up to and
 // including the unit, << 1 | "counted from the start of the document" (the format of k2_traverse<.., CHARS>: the
 // expansion adds the characters between the start of the document and the chunk).
-template <bool CHARS>
+template <bool CHARS, int BB>
 __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // LDS: decode tables (16-byte aligned), the root's transitions (child base | filter << 21 | END << 31), input rows
@@ -267,13 +267,15 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             // when the trip before asked for it.  A big state's base is its block's first slot: ^ is + there.
             // (requested by every lane -- the idle ones ask for slot 0 -- so that the store below runs unmasked)
             const bool good = code != 0u;
-            const uint32_t Bq = u_child(E);
+            const uint32_t Bq = u_child(E, BB);
             const bool hdr = u_hdr_pending(E);
             const bool grp = Bq >= U.big_lo & code >= U.n_low & !hdr;
             uint32_t se = grp ? (code >> 5) + U.g0 : code;
             se = hdr ? 0u : se;
             // (bit 29 -- F1 -- stands in for the filter's eighth bit, which is always set)
-            const bool probe = act & good & (((E | 0x20000000u) >> (22u + (code & 7u))) & 1u) != 0u & Bq != 0u;
+            // (with 23-bit bases the filter has six bits: classes 6 and 7 share the forced one)
+            const uint32_t fc = BB == 22 ? (code & 7u) : min(code & 7u, 6u);
+            const bool probe = act & good & (((E | 0x20000000u) >> ((uint32_t)BB + fc)) & 1u) != 0u & Bq != 0u;
             unsigned long long enw = 0;
 #ifndef AHA_LAB_NO_PROBE
             {
@@ -302,12 +304,12 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
               // a big state continues on this high symbol: its child's entry is the slot `first child of the group + set
               // bits below the symbol's`; the next trip probes it as the state "slot ^ symbol" and consumes the unit
               const bool redir = grp & probe & ((enx >> (code & 31u)) & 1u) != 0u;
-              const uint32_t rE = (__builtin_popcount(enx & ~(~0u << (code & 31u))) + eny ^ code) | kUAllFilter;
+              const uint32_t rE = (__builtin_popcount(enx & ~(~0u << (code & 31u))) + eny ^ code) | u_all_filter(BB);
               // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip;
               // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or the state's header,
               // fetched by the next trip (falling into a state reports nothing: END is not carried)
               const bool viaroot = !symhit & !redir & (!u_nfr(E) | !good);
-              const uint32_t ft = u_f1(E) ? (rf & 0x7FFFFFFFu) : (Bq | kUAllFilter | 0x20000000u);
+              const uint32_t ft = u_f1(E) ? (rf & 0x7FFFFFFFu) : (Bq | u_all_filter(BB) | 0x20000000u);
               uint32_t missE = viaroot ? rt : ft;
               missE = redir ? rE : missE;
               E = symhit ? enx : missE;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const bool ev = evc != 0u;
             const uint32_t my = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(evm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)evm, 0u));
             // {END state | lane | hits it stands for, end offset in the document, hits of the chunk before it}
-            const uint32_t rx = u_child(E) | (uint32_t)lane << 22 | evc << 28, ry = CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel);
+            const uint32_t rx = u_child(E, BB) | (uint32_t)lane << BB | evc << (BB + 6), ry = CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel);
             if (ev && my < 64u) {
               uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + __umul24(my, 12u)));
               d[0] = rx;
@@ -601,11 +603,11 @@ __global__ __launch_bounds__(kV2Threads) void ku2_traverse(UnitDev U, V2Args M) 
     const bool hit = symhit & !t.hdr;
     // a big state continues on this high symbol: the next trip probes its child's slot as the state "slot ^ symbol"
     const bool redir = t.grp & t.probe & ((t.en.x >> (code & 31u)) & 1u) != 0u;
-    const uint32_t rE = (__builtin_popcount(t.en.x & ~(~0u << (code & 31u))) + t.en.y ^ code) | kUAllFilter;
+    const uint32_t rE = (__builtin_popcount(t.en.x & ~(~0u << (code & 31u))) + t.en.y ^ code) | u_all_filter(22u);
     // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip; else the
     // unit is tried again in the fail state: root[the symbol that led here] (F1), or the header, fetched by the next trip
     const bool viaroot = !symhit & !redir & (!u_nfr(X.E) | !t.good);
-    const uint32_t ft = u_f1(X.E) ? (t.rf & 0x7FFFFFFFu) : (t.Bq | kUAllFilter | 0x20000000u);
+    const uint32_t ft = u_f1(X.E) ? (t.rf & 0x7FFFFFFFu) : (t.Bq | u_all_filter(22u) | 0x20000000u);
     uint32_t nE = viaroot ? t.rt : ft;
     nE = redir ? rE : nE;
     nE = symhit ? t.en.x : nE;
@@ -777,6 +779,7 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
   const uint32_t stride = M.ev_stride;
+  const uint32_t bb = M.unit_bb, bmask = (1u << bb) - 1u;  // the image's base width (unit.hpp, BASE WIDTH)
   for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     __syncthreads();
     if (wv == 0) {
@@ -807,11 +810,11 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
         nxt[q] = i + kRgBlock < total ? make_uint2(src[(size_t)(i + kRgBlock) * 3], src[(size_t)(i + kRgBlock) * 3 + 1])
                                       : make_uint2(0, 0);
         // key id, or (flattened chains) the offset of its chain, | min(chain length, 255) << 24
-        x[q] = live[q] ? A.end_info[rec[q].x & 0x3FFFFFu] : 0u;
+        x[q] = live[q] ? A.end_info[rec[q].x & bmask] : 0u;
       }
 #pragma unroll
       for (int q = 0; q < kRgPer; q++) {
-        l[q] = (rec[q].x >> 22) & 63u;
+        l[q] = (rec[q].x >> bb) & 63u;
         uint64_t same = __ballot(live[q]), mine = same;  // records of the sub-batch with this record's tag / with tag == lane
 #pragma unroll
         for (int b = 0; b < 6; b++) {
@@ -900,6 +903,7 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
   const uint32_t stride = M.ev_stride;
+  const uint32_t bb = M.unit_bb, bmask = (1u << bb) - 1u;  // the image's base width (unit.hpp, BASE WIDTH)
   for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     __syncthreads();
     const uint64_t c = g * 64 + lane;
@@ -936,8 +940,8 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
         live[q] = i < total;
         rec[q] = nxt[q];
         nxt[q] = i + kXgBlock < total ? *reinterpret_cast<const v3u *>(src + (size_t)(i + kXgBlock) * 3) : v3u{0, 0, 0};
-        ue[q] = live[q] ? uend[rec[q].x & 0x3FFFFFu] : make_uint2(0, 0);
-        if (live[q]) atomicAdd(&s_tot[par][(rec[q].x >> 22) & 63u], rec[q].x >> 28);
+        ue[q] = live[q] ? uend[rec[q].x & bmask] : make_uint2(0, 0);
+        if (live[q]) atomicAdd(&s_tot[par][(rec[q].x >> bb) & 63u], rec[q].x >> (bb + 6u));
       }
       __syncthreads();
       if (wv == 0) {
@@ -953,7 +957,7 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
 #pragma unroll
         for (int q = 0; q < kXgPer; q++) {
           if (live[q]) {
-            const uint32_t l = (rec[q].x >> 22) & 63u, n = rec[q].x >> 28;
+            const uint32_t l = (rec[q].x >> bb) & 63u, n = rec[q].x >> (bb + 6u);
             const uint32_t pos = s_start[l] + (rec[q].z - s_run[l]);
             const uint32_t end = CHARS ? (rec[q].y >> 1) + ((rec[q].y & 1u) ? 0u : s_adj[l]) : rec[q].y, co = ue[q].y & 0xFFFFFFu;
             // Hit(idx - len + 1, idx + 1, value) ac.cr:271-273: the state's own key, then its output chain (ac.cr:265-278)
@@ -1009,11 +1013,11 @@ size_t unit_lds_bytes(uint32_t n_syms) { return u_lds(n_syms); }
 uint32_t unit2_event_buffer(uint32_t n_syms) { return u2_ev_cap(n_syms); }
 
 int unit_prepare(uint32_t n_syms) {
-  int e = (int)hipFuncSetAttribute((const void *)ku_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)unit_lds_bytes(n_syms));
-  if (!e)
-    e = (int)hipFuncSetAttribute((const void *)ku_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)unit_lds_bytes(n_syms));
+  const int lds = (int)unit_lds_bytes(n_syms);
+  int e = (int)hipFuncSetAttribute((const void *)ku_traverse<false, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<true, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<false, 23>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<true, 23>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (!e && u2_ev_cap(n_syms) >= kU2MinEventBuffer) {
     e = (int)hipFuncSetAttribute((const void *)ku2_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)u2_lds(n_syms));
     if (!e)
@@ -1023,17 +1027,21 @@ int unit_prepare(uint32_t n_syms) {
 }
 
 void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream, int walks) {
-  if (walks == 2) {
+  if (walks == 2 && U.base_bits == 22) {
     if (M.chars)
       hipLaunchKernelGGL(ku2_traverse<true>, dim3(grid), dim3(kV2Threads), u2_lds(U.n_syms), (hipStream_t)stream, U, M);
     else
       hipLaunchKernelGGL(ku2_traverse<false>, dim3(grid), dim3(kV2Threads), u2_lds(U.n_syms), (hipStream_t)stream, U, M);
     return;
   }
-  if (M.chars)
-    hipLaunchKernelGGL(ku_traverse<true>, dim3(grid), dim3(kV2Threads), unit_lds_bytes(U.n_syms), (hipStream_t)stream, U, M);
-  else
-    hipLaunchKernelGGL(ku_traverse<false>, dim3(grid), dim3(kV2Threads), unit_lds_bytes(U.n_syms), (hipStream_t)stream, U, M);
+  const size_t lds = unit_lds_bytes(U.n_syms);
+#define AHA_LAUNCH_KU(C, B) hipLaunchKernelGGL((ku_traverse<C, B>), dim3(grid), dim3(kV2Threads), lds, (hipStream_t)stream, U, M)
+  if (U.base_bits == 23) {
+    if (M.chars) AHA_LAUNCH_KU(true, 23); else AHA_LAUNCH_KU(false, 23);
+  } else {
+    if (M.chars) AHA_LAUNCH_KU(true, 22); else AHA_LAUNCH_KU(false, 22);
+  }
+#undef AHA_LAUNCH_KU
 }
 
 void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream) {

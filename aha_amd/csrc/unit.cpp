@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 
 namespace aha {
 
@@ -17,8 +18,10 @@ struct UTrans {
 
 }  // namespace
 
-void build_unit(const Automaton &a, UnitImage &u, bool force) {
+static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32_t base_bits) {
   u = UnitImage();
+  u.base_bits = base_bits;
+  const uint32_t max_slots = 1u << base_bits;
   const uint32_t S = a.n_states;
   if (a.n_keys == 0 || S < 2) {
     u.why = "no keys";
@@ -113,6 +116,11 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
   first[S] = (uint32_t)tr.size();
   u.n_states = (uint32_t)ustates.size();
   u.n_trans = (uint32_t)tr.size();
+  if (getenv("AHA_DEBUG")) fprintf(stderr, "aha: unit image: %u states, %u transitions, %u-bit bases\n", u.n_states, u.n_trans, base_bits);
+  if ((uint64_t)u.n_states + u.n_states / 8 + 1 > max_slots) {  // every state needs an identity below the array's end
+    u.why = "more states than the bases address";
+    return;
+  }
 
   // ---- the dense alphabet (unit.hpp, SYMBOLS)
   u.c2lo = hi2 ? lo2 : 0;
@@ -198,10 +206,12 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
   };
   Bits used(kUMaxSlots), isb(kUMaxSlots);
   std::vector<uint32_t> freec(kMaxBlocks, kBlk), curw(kMaxBlocks, 0);
+  std::vector<uint32_t> idfree(kMaxBlocks, kBlk);  // identities of the block that are no state's yet (a base lies in its slots' block)
   std::vector<uint32_t> base(S, 0);
   used.set(0);  // index 0 stays empty: base 0 is the root
   isb.set(0);
   freec[0]--;
+  idfree[0]--;
   uint32_t n_open = 1, n_big = 0, n_bases = 1;
   std::vector<uint32_t> order, bigs;
   for (uint32_t s : ustates) {
@@ -224,7 +234,12 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     return nsym(x) > nsym(y);
   });
   auto open_block = [&]() -> bool {
-    if ((uint64_t)(n_open + 1) * kBlk + (uint64_t)n_big * bb > kUMaxSlots) return false;
+    if ((uint64_t)(n_open + 1) * kBlk + (uint64_t)n_big * bb > max_slots) {
+      if (getenv("AHA_DEBUG"))
+        fprintf(stderr, "aha: unit image: %u blocks open, %u big states of %u slots, %u bases so far: no room for another block\n",
+                n_open, n_big, bb, n_bases);
+      return false;
+    }
     n_open++;
     return true;
   };
@@ -234,12 +249,16 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     const uint32_t fr = freec[blk];
     if (fr < k) return 0;
     uint64_t budget = fr;
+    // expected number of free slots whose identity is still free (with millions of single transitions the blocks run
+    // out of identities before they run out of slots, and every later state would search them to the end)
+    if ((double)fr * idfree[blk] / kBlk < 0.5) return 0;
     if (k > 1) {  // expected share of the candidates whose other k - 1 slots are free as well
-      double p = 1.0;
+      double p = (double)idfree[blk] / kBlk;
       const double fl = (double)fr / kBlk;
       for (uint32_t i = 1; i < k; i++) p *= fl;
       if (p * fr < 0.5) return 0;
-      budget = std::min<uint64_t>(fr, (uint64_t)(8.0 / p) + 8);
+      // (+ 1024: the symbols of wide states cluster -- the letters --, so neighbouring candidates fail together)
+      budget = std::min<uint64_t>(fr, (uint64_t)(4.0 / p) + 1024);
     }
     const uint32_t w0 = blk * (kBlk / 64), nw = kBlk / 64;
     uint32_t wi = curw[blk];
@@ -262,15 +281,22 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     return 0;
   };
   uint32_t lowest = 0;  // lowest block that may have a free slot
+  // dead[blk]: a state of that many slots found no place there; blocks only fill up, so wider ones need not look (with a
+  // million keys the one-character states alone are 20 000 states of ~30 transitions: without this every one of them
+  // walks through every block that is a quarter full -- minutes)
+  std::vector<uint32_t> dead(kMaxBlocks, ~0u);
   auto place = [&](uint32_t k) -> uint32_t {
     while (lowest < n_open && freec[lowest] == 0) lowest++;
     for (uint32_t blk = lowest;; blk++) {
       if (blk == n_open && !open_block()) return 0;
+      if (k >= dead[blk]) continue;
       const uint32_t b = try_block(blk, k);
+      if (!b && (k > 1 || (double)freec[blk] * idfree[blk] / kBlk < 8.0)) dead[blk] = k;
       if (b) {
         for (uint32_t i = 0; i < k; i++) used.set(b ^ sy[i]);
         freec[blk] -= k;
         isb.set(b);
+        idfree[blk]--;
         n_bases++;
         return b;
       }
@@ -309,6 +335,7 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
           used.set(t + j);
           if (!isb.get((t + j) ^ tr[q + j].sym)) {
             isb.set((t + j) ^ tr[q + j].sym);
+            idfree[t / kBlk]--;
             n_bases++;
           }
         }
@@ -321,11 +348,17 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     return true;
   };
   bool runs_done = n_big == 0 || n_groups == 0;
+  const auto t_place = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (getenv("AHA_DEBUG"))
+      fprintf(stderr, "aha: unit image: %s at %.2f s, %u blocks\n", what,
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t_place).count(), n_open);
+  };
   for (size_t oi = 0; oi < order.size(); oi++) {
     const uint32_t s = order[oi];
     if (!runs_done && udepth[s] != 1) {  // behind the one-character states
       if (!place_runs()) {
-        u.why = "more transitions than the 22-bit bases address";
+        u.why = "more transitions than the bases address";
         return;
       }
       runs_done = true;
@@ -335,15 +368,16 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     if (has_header(s)) sy[k++] = 0u;
     const uint32_t b = place(k);
     if (!b) {
-      u.why = "more transitions than the 22-bit bases address";
+      u.why = "more transitions than the bases address";
       return;
     }
     base[s] = b;
   }
   if (!runs_done && !place_runs()) {
-    u.why = "more transitions than the 22-bit bases address";
+    u.why = "more transitions than the bases address";
     return;
   }
+  lap("states with slots placed");
   // states that own no slot: any unused identity (fewer states than slots: blocks are opened for them if need be)
   {
     uint32_t n_ids = 0;
@@ -351,7 +385,7 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
       if (s != 0 && first[s + 1] == first[s] && !has_header(s)) n_ids++;
     while ((uint64_t)n_open * kBlk < (uint64_t)n_bases + n_ids + 1)
       if (!open_block()) {
-        u.why = "more states than the 22-bit bases address";
+        u.why = "more states than the bases address";
         return;
       }
     uint32_t idc = 1;
@@ -370,13 +404,15 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
   auto word = [&](uint32_t st) -> uint32_t {  // the state as one word (unit.hpp)
     uint32_t flt = 0;
     for (uint32_t q = first[st]; q < first[st + 1]; q++) flt |= 1u << (tr[q].sym & 7u);
-    if (first[st + 1] - first[st] >= kUBigDegree) flt = 0x7Fu;  // (a big state always probes: its group records answer)
+    if (first[st + 1] - first[st] >= kUBigDegree) flt = 0xFFu;  // (a big state always probes: its group records answer)
     const bool nfr = a.fail[st] != 0, f1 = nfr && udepth[a.fail[st]] == 1;
-    return base[st] | ((flt & 0x7Fu) << 22) | (f1 ? (1u << 29) : 0u) | (nfr ? (1u << 30) : 0u) |
+    // (the filter's classes beyond its stored bits -- 7, and 6 with 23-bit bases -- always probe)
+    return base[st] | ((flt << base_bits) & u_all_filter(base_bits)) | (f1 ? (1u << 29) : 0u) | (nfr ? (1u << 30) : 0u) |
            (a.key_of[st] >= 0 ? 0x80000000u : 0u);
   };
-  auto u_c4_of = [](const Automaton &au, uint32_t st) -> uint32_t {  // hits an event in this state stands for, at most 15
-    return au.key_of[st] >= 0 ? std::min<uint32_t>(au.key_cnt[au.key_of[st]], 15u) : 0u;
+  const uint32_t c4_max = u_max_c4(base_bits);
+  auto u_c4_of = [c4_max](const Automaton &au, uint32_t st) -> uint32_t {  // hits an event in this state stands for, capped
+    return au.key_of[st] >= 0 ? std::min<uint32_t>(au.key_cnt[au.key_of[st]], c4_max) : 0u;
   };
   u.n_slots = n_slots;
   u.n_shared = n_shared;
@@ -411,6 +447,12 @@ void build_unit(const Automaton &a, UnitImage &u, bool force) {
     }
   }
   u.ok = true;
+}
+
+void build_unit(const Automaton &a, UnitImage &u, bool force) {
+  build_unit_bits(a, u, force, 22u);
+  // (only the size of the image asks for wider bases: every other refusal holds for them too)
+  if (!u.ok && strstr(u.why, "bases address")) build_unit_bits(a, u, force, 23u);
 }
 
 }  // namespace aha

@@ -79,7 +79,7 @@
 
 namespace aha {
 
-constexpr uint32_t kUMaxSlots = 1u << 22;
+constexpr uint32_t kUMaxSlots = 1u << 23;  // the widest image: 23-bit bases (see BASE WIDTH)
 constexpr uint32_t kUBigDegree = 48;     // transitions from which on a state gets a region of its own
 constexpr uint32_t kUMaxSyms = 21756;    // root table (4 bytes per symbol) + decode tables + input rows + the waves' event buffers fit 160 KiB of
                                          // LDS (scan_unit.hip u_lds); < 2^15: a big state's region holds every symbol
@@ -90,15 +90,18 @@ constexpr uint32_t kUPoison = 1u << 24;  // contribution of a byte that is not a
 constexpr uint32_t kUT0a = 0, kUT0b = 1024, kUA1 = 1536, kUA2 = 2304, kUTabWords = 2816;
 
 // decoding of a state word / an entry (device code and the CPU twin in tests/ use the same arithmetic)
-AHA_HD inline uint32_t u_child(uint32_t lo) { return lo & 0x3FFFFFu; }
-AHA_HD inline uint32_t u_filter(uint32_t lo) { return ((lo >> 22) & 0x7Fu) | 0x80u; }
+// BASE WIDTH.  An image of at most 2^22 slots has 22-bit bases and a 7-bit filter (classes symbol & 7: 0..6 stored, 7
+// always probes); a larger one (cfg 5: 1 M keys) 23-bit bases and a 6-bit filter (classes 0..5 stored, 6 and 7 always
+// probe), and an event record leaves 3 instead of 4 bits for the hits it stands for.  The flags stay at bits 29..31.
+AHA_HD inline uint32_t u_child(uint32_t lo, uint32_t bb = 22u) { return lo & ((1u << bb) - 1u); }
+AHA_HD inline uint32_t u_all_filter(uint32_t bb) { return ((1u << (29u - bb)) - 1u) << bb; }
+AHA_HD inline uint32_t u_max_c4(uint32_t bb) { return (1u << (26u - bb)) - 1u; }  // hits an event record can stand for
 AHA_HD inline bool u_f1(uint32_t lo) { return ((lo >> 29) & 1u) != 0; }
 AHA_HD inline bool u_nfr(uint32_t lo) { return ((lo >> 30) & 1u) != 0; }
 AHA_HD inline bool u_end(uint32_t lo) { return (lo >> 31) != 0; }
 AHA_HD inline uint32_t u_sym(uint32_t hi) { return hi & 0xFFFFu; }
 AHA_HD inline uint32_t u_c4(uint32_t hi) { return (hi >> 16) & 15u; }
 AHA_HD inline bool u_hdr_pending(uint32_t lo) { return ((lo >> 29) & 3u) == 1u; }  // F1 without NFR: fetch the header next
-constexpr uint32_t kUAllFilter = 0x7Fu << 22;
 
 struct UnitImage {
   bool ok = false;
@@ -107,6 +110,7 @@ struct UnitImage {
   uint32_t n_shared = 0;            // the shared XOR array (= big_lo); behind it the blocks of the big states
   uint32_t n_big = 0, big_block = 0;  // big states, slots of the block each of them owns
   uint32_t n_low = 0, g0 = 0;       // symbols below n_low index a big state's block directly, the others by groups of 32
+  uint32_t base_bits = 22;          // 22 or 23 (BASE WIDTH)
   std::vector<uint64_t> slots;      // [n_slots]
   std::vector<int32_t> end_key;     // [n_slots] key id at the base of an END state, else -1
   std::vector<uint32_t> root;       // [n_syms]

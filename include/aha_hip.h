@@ -127,6 +127,9 @@ typedef struct {
   uint32_t unit_big_block;
   uint32_t unit_n_low;
   uint32_t unit_n_big;
+  uint32_t unit_base_bits;      /* 22, or 23 for an image beyond 2^22 slots: width of the base field of a state word; the
+                                 * filter takes the bits from there up to bit 28 (7 or 6 of them) */
+  uint32_t reserved2;
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded

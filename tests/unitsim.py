@@ -24,6 +24,8 @@ class UnitSim:
         self.n_slots = info["unit_slots"]
         self.big_lo, self.n_low = info["unit_big_lo"], info["unit_n_low"]
         self.g0 = self.n_low - (self.n_low >> 5)
+        self.bb = info["unit_base_bits"]  # 22, or 23 for a large image: base | filter (29 - bb bits) | F1 | NFR | END
+        self.bmask, self.nf = (1 << self.bb) - 1, 29 - self.bb
         assert self.slots.size == self.n_slots and self.n_slots % (1 << 15) == 0 and self.n_low % 32 == 0
         assert self.root.size == info["unit_syms"] and int(self.root[0]) == 0
 
@@ -55,19 +57,20 @@ class UnitSim:
             good = code != 0
             while True:  # the trips of this unit
                 trips += 1
-                B = E & 0x3FFFFF
+                B = E & self.bmask
                 hdr = ((E >> 29) & 3) == 1  # header pending (F1 without NFR: no entry holds that)
                 grp = B >= self.big_lo and code >= self.n_low and not hdr
                 se = 0 if hdr else (self.g0 + (code >> 5) if grp else code)  # what the probe is keyed by
                 lo = hi = 0
-                probe = good and B != 0 and bool(((((E >> 22) & 0x7F) | 0x80) >> (code & 7)) & 1)
+                # (the classes beyond the filter's stored bits always probe: 7, and 6 with 23-bit bases)
+                probe = good and B != 0 and bool((((E >> self.bb) | (1 << self.nf)) >> min(code & 7, self.nf)) & 1)
                 if probe:
                     self.probes += 1
                     e = int(self.slots[B ^ se])
                     lo, hi = e & 0xFFFFFFFF, e >> 32
                 symhit = probe and not grp and (hi & 0xFFFF) == se
                 if hdr:  # the header: the fail state's word; the unit is tried again there
-                    assert symhit and lo & 0x3FFFFF, "missing header"
+                    assert symhit and lo & self.bmask, "missing header"
                     E = lo
                     continue
                 if symhit:
@@ -75,20 +78,20 @@ class UnitSim:
                     break
                 if grp and probe and (lo >> (code & 31)) & 1:  # a big state continues on this high symbol: its child's slot
                     child_slot = hi + bin(lo & ((1 << (code & 31)) - 1)).count("1")
-                    E = (child_slot ^ code) | (0x7F << 22)
+                    E = (child_slot ^ code) | (((1 << self.nf) - 1) << self.bb)
                     continue
                 if not good or not (E >> 30) & 1:  # the fail link is the root (or nothing matches): its table
                     E = int(self.root[code])
                     break
                 if (E >> 29) & 1:  # F1: the fail state is the one-character state of the symbol that led here
                     E = int(self.root[pc]) & 0x7FFFFFFF
-                    assert E & 0x3FFFFF, "missing fail link"
+                    assert E & self.bmask, "missing fail link"
                 else:
-                    E = B | (0x7F << 22) | (1 << 29)  # fetch the header in the next trip
+                    E = B | (((1 << self.nf) - 1) << self.bb) | (1 << 29)  # fetch the header in the next trip
             pc = code
             p += L
             if E >> 31:
-                k = int(self.end_key[E & 0x3FFFFF])
+                k = int(self.end_key[E & self.bmask])
                 assert k >= 0
                 while k >= 0:
                     ln, nxt = int(self.key_ln[k][0]), int(np.int32(self.key_ln[k][1]))

@@ -550,22 +550,6 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   }
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
-#ifdef AHA_DIAG
-  // lab build (make diag): time the traversal alone; its timing-only variants leave nothing the post passes may read
-  if (getenv("AHA_DIAG_TRAVERSE_ONLY")) {
-    HIPCHK(ac, hipStreamSynchronize(s));
-    aha_timing t;
-    memset(&t, 0, sizeof(t));
-    t.struct_size = sizeof(t);
-    t.engine = 2;
-    t.chunk_bytes = M.S;
-    t.n_chunks = M.n_chunks;
-    if (prof) (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], sc->ev[1]);
-    publish_timing(ac, t);
-    *n_hits = 0;
-    return AHA_OK;
-  }
-#endif
   if (direct) {
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
     if (unit && ac->unit_fused) {  // the traversal counted the hits: bases, then the expansion straight from the wave-ordered events

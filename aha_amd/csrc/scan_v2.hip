@@ -71,45 +71,6 @@ struct Slot<false> {
 constexpr int kInStride = kV2Piece + 4;           // bytes per lane in the LDS input window (odd dword stride)
 constexpr int kWaveIn2 = 64 * kInStride;
 
-// Lab variants of the partial-prefix trip (tools/lab_traverse.py, `make diag`): the product instantiates DG = 0 only
-// and every `if constexpr (DG == ...)` below disappears from it.  Variants marked (T) break the walk on purpose
-// (timing only): the lab build stops after the traversal and reads nothing it wrote.
-enum : int {
-  kDgNone = 0,
-  kDgNoFar = 1,         // (T) every probe beyond the LDS prefix is answered from LDS
-  kDgFarHalf = 2,       // (T) half of them (hash of the slot index)
-  kDgNoStore = 3,       // (T) events are counted but not stored
-  kDgNoFarNoStore = 4,  // (T)
-  kDgAddFar = 5,        // exact walk; every far lane issues a second, independent far load
-  kDgAddValu = 6,       // exact walk; 16 more dependent VALU instructions per trip
-  kDgAddLds = 7,        // exact walk; one more random ds_read_b32 per trip
-  kDgStamp = 8,         // exact walk; s_memtime stamps around the segments of the trip
-  kDgSplit = 9,         // exact walk; ds_read for the near lanes + global_load for the far lanes instead of one flat_load
-  kDgFarL1 = 10,        // (T) far probes go to an 8 KiB window of the global image (L1 hits): the flat path without L2
-  kDgStorePlain = 11,   // (the product since round 3: plain event stores; kept so that the variant numbers stay)
-  kDgFarNt = 12,        // exact walk; split loads, the far load non-temporal (nt)
-  kDgFarSc1 = 13,       // exact walk; split loads, the far load agent-coherent (sc1: served by L2, no L1 allocation)
-  kDgFarWide = 14,      // exact walk; split loads, the far load 8 bytes wide (the slot and its neighbour)
-  kDgFar40 = 15,        // (T) 40 % of the far PROBES (not headers) answered from LDS as misses: a perfect 8-bit child filter
-  kDgStoreNt = 16,      // exact walk; event stores really non-temporal (buffer store, aux = nt; regions below 4 GiB only)
-  kDgNoNul = 17,        // exact on NUL-free text: the trip without the NUL contract's instructions
-  kDgPackE = 18,        // + the state kept as its whole entry (base and "fail is root" flag in one register)
-  kDgSplitMin = 19,     // + ds_read of slot[min(idx, T)] and an exec-masked global_load instead of one flat_load
-  kDgCount = 20
-};
-#ifdef AHA_DIAG
-// per wave: 16 words = cycles of the segments A..E for wave-trips without / with a far lane, then the two trip counts
-__device__ uint32_t g_diag_stamps[256 * (kV2Threads / 64) * 16];
-#define AHA_STAMP(t)                                                               \
-  do {                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");      \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-  } while (0)
-#else
-#define AHA_STAMP(t) (void)(t)
-#endif
-
 // ALL_LDS: the whole image fits the LDS budget (cfg 2): the same trip, every lookup a ds_read (no far path).  (Until round 4
 // such automata kept a fail header for every state and ran a trip of their own that read the header beside the probe:
 // 1.55 trips per byte on cfg 2; with the shadow fail links of the partial-prefix trip 1.02, 6 % less time even through the
@@ -117,7 +78,7 @@ __device__ uint32_t g_diag_stamps[256 * (kV2Threads / 64) * 16];
 #ifndef AHA_V2_WAVES_PER_SIMD
 #define AHA_V2_WAVES_PER_SIMD 4  // one 1024-thread workgroup per CU; 8 = two (lab: does the occupancy pay?)
 #endif
-template <bool COMPACT, bool CHARS, bool ALL_LDS, int DG = kDgNone>
+template <bool COMPACT, bool CHARS, bool ALL_LDS>
 __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse(DevAut A, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   using S_ = Slot<COMPACT>;
@@ -184,13 +145,6 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
     slab_used_n += n;
   };
 
-  constexpr bool kLeanNoNul = DG >= kDgNoNul && DG <= kDgSplitMin;
-  constexpr bool kLeanPack = DG >= kDgPackE && DG <= kDgSplitMin;
-  constexpr bool kLeanSplit = DG == kDgSplitMin;
-  [[maybe_unused]] uint32_t dg_dummy = 0;             // lab: keeps the added loads / instructions alive
-  [[maybe_unused]] uint32_t dg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // lab: stamp sums (wave-uniform)
-  [[maybe_unused]] const uint32_t dg_shift = 32u - (31u - (uint32_t)__clz((int)A.n_slots));
-
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t chunk = tile * kV2Threads + threadIdx.x;
@@ -203,8 +157,6 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
     uint64_t dn = 0;
     int64_t nb = INT64_MAX, doc_start = a, pos = e;
     uint32_t B = root, fr = 0, seq = 0;
-    [[maybe_unused]] uint32_t E = C_FAILROOT;  // lab (kDgPackE): the state as its entry; the root (base 0) fails to the root
-    bool hdr = false;  // the next lookup fetches the fail header of B (no byte consumed)
     // shadow fail (A.s2_lo < A.s2_hi): r1 = root-row entry of the last consumed byte (0 = none), s2 = entry of the
     // depth<=2 state of the last two consumed bytes.  A miss in a state whose base lies in [s2_lo, s2_hi) continues
     // in s2's state in the same trip: no header trip, no far header load.
@@ -300,8 +252,6 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
             nb_rel = (nb < pb + kV2Piece) ? (uint32_t)(nb - pb) : ~0u;
             B = root;
             fr = 0;
-            E = C_FAILROOT;
-            hdr = false;
             r1 = slot_t{};
             s2 = slot_t{};
             hm = 0xFFu;
@@ -319,8 +269,6 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
         if (!__any(act)) break;
         bool ev = false;
         uint32_t en_keep = 0;
-        [[maybe_unused]] unsigned long long dt0 = 0, dt1 = 0, dt2 = 0, dt3 = 0, dt4 = 0, dt5 = 0;
-        [[maybe_unused]] bool dg_anyfar = false;
         if (act) {
           // Partial prefix: the trip with few mask operations.  A header trip is a probe with label 0 (the
           // header slot is slot[B ^ 0] and carries label 0), so one compare serves goto and header alike;
@@ -328,20 +276,9 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
           // the byte comes from a register: the next one was loaded during the previous trip (nearly every trip
           // consumes), which takes the LDS round trip of the byte out of the dependent chain
           const uint32_t b = bcur;
-          if constexpr (DG == kDgStamp) AHA_STAMP(dt0);
           const uint32_t bnext = inl[rel + 1];                    // rows are padded: rel + 1 <= piece + 3
           const uint32_t c = b & hm;
-          if constexpr (kLeanPack) B = (uint32_t)S_::base((slot_t)E);
-          uint32_t idx = B ^ c;
-          // timing-only variants redirect PROBE trips only: a header trip (hm == 0) that never finds its header would
-          // repeat forever
-          if constexpr (DG == kDgNoFar || DG == kDgNoFarNoStore) idx = (idx < T || hm == 0) ? idx : (idx & 16383u);
-          if constexpr (DG == kDgFarHalf)
-            idx = (idx >= T && hm != 0 && ((idx * 0x9E3779B1u) >> 31)) ? (idx & 16383u) : idx;
-          if constexpr (DG == kDgFar40)
-            idx = (idx >= T && hm != 0 && ((idx * 0x9E3779B1u) >> 24) < 102u) ? (idx & 16383u) : idx;
-          if constexpr (DG == kDgFarL1) idx = (idx < T || hm == 0) ? idx : T + (idx & 2047u);
-          if constexpr (DG == kDgStamp) dg_anyfar = __any(idx >= T);
+          const uint32_t idx = B ^ c;
           const slot_t e0 = lt[root ^ b];                         // root row: always LDS resident
           const slot_t e2 = lt[S_::base(r1) ^ b];                 // depth-1 rows: always LDS resident
           const slot_t sx = B < A.s2_lo ? r1 : s2;                // shadow fail target of B (if B has one)
@@ -349,43 +286,20 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
           const bool near3 = i3 < T;
           const slot_t e3 = lt[near3 ? i3 : 0u];                  // sx's row (depth <= 2: mostly LDS resident)
           slot_t en;
-          if constexpr (DG == kDgSplit || DG == kDgFarNt || DG == kDgFarSc1 || DG == kDgFarWide) {
-            en = lt[idx < T ? idx : 0u];
-            if (idx >= T) {
-              if constexpr (DG == kDgFarNt) {  // hipcc drops __builtin_nontemporal_* on gfx950: buffer load with aux = nt
-                en = __builtin_amdgcn_raw_buffer_load_b32(
-                    __builtin_amdgcn_make_buffer_rsrc(const_cast<slot_t *>(gt), 0, (int)(A.n_slots * 4u), 0x00020000),
-                    (int)(idx * 4u), 0, 2);
-              } else if constexpr (DG == kDgFarSc1) {
-                en = __hip_atomic_load(gt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              } else if constexpr (DG == kDgFarWide) {
-                const uint2 w2 = *reinterpret_cast<const uint2 *>(gt + (idx & ~1u));
-                en = (idx & 1u) ? w2.y : w2.x;
-              } else {
-                en = gt[idx];
-              }
-            }
-          } else if constexpr (kLeanSplit) {
-            en = lt[min(idx, T)];                                 // slot[T] is the first input row: readable, never used
-            if (idx >= T) en = gt[idx];
-          } else if constexpr (ALL_LDS) {
+          if constexpr (ALL_LDS) {
             en = lt[idx];                                         // the whole image is in LDS: no far path
           } else {
+            // (one flat load over both apertures; ds_read + exec-masked global_load, sc1 / nt / 8-byte far loads were
+            // measured in round 3: profiles/r03_trip_anatomy.txt)
             if (idx < T)
               en = lt[idx];
             else
               en = gt[idx];
           }
-          if constexpr (DG == kDgAddFar) {
-            if (idx >= T) dg_dummy ^= (uint32_t)gt[(idx * 2654435761u) >> dg_shift];
-          }
-          if constexpr (DG == kDgAddLds) dg_dummy ^= (uint32_t)lt[(idx ^ 0x1555u) & 16383u];
-          if constexpr (DG == kDgStamp) AHA_STAMP(dt1);           // the LDS reads are back (the stamp waits lgkmcnt(0))
-          const bool nz = kLeanNoNul ? true : b != 0;
+          const bool nz = b != 0;
           const bool probe = hm != 0;
           const bool bzp = !nz && probe;                          // NUL contract: state := root, byte consumed
-          bool atroot = B == root || fr != 0 || bzp;              // fails[nid] = root: probe the root row now
-          if constexpr (kLeanPack) atroot = (E & C_FAILROOT) != 0;
+          const bool atroot = B == root || fr != 0 || bzp;        // fails[nid] = root: probe the root row now
           const bool mr = nz && S_::match(e0, b);                 // b has a depth-1 state
           // fails[nid] of a state in [s1_lo, s2_hi) follows from the last bytes: sx = r1 (depth-2 state) or s2.
           // Its row, the row of ITS fail target (r1: e2) and the root row (e0) are probed in this same trip, so
@@ -398,36 +312,14 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
           const slot_t r1n = mr ? e0 : slot_t{};
           const slot_t s2n = m2 ? e2 : r1n;
           const bool shadow = !atroot && (B - A.s1_lo) < (A.s2_hi - A.s1_lo);
-          if constexpr (DG == kDgAddValu) {
-            asm volatile("v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
-                         "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
-                         "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
-                         "v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\n"
-                         : "+v"(dg_dummy)
-                         : "v"(b));
-          }
-          if constexpr (DG == kDgStamp) {
-            AHA_STAMP(dt2);                                       // everything that does not need the probe is done
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(en)::"memory");
-            AHA_STAMP(dt3);                                       // the probe (and the previous trip's event store) is back
-          }
           const bool t = S_::match(en, c) && !bzp;                // goto (cedar.cr:441-447), or the header itself
           const bool sgo = !t && shadow;
           const bool sres = sgo && near3;
-          slot_t ex = t ? en : (sgo ? (near3 ? chain : sx) : (mr ? e0 : slot_t{}));
-          if constexpr (kLeanPack) {  // "no state" is the root's entry: base 0, fails to the root
-            const slot_t re = (slot_t)C_FAILROOT;
-            const slot_t chain_r = m3 ? e3 : (m2 ? e2 : (mr ? e0 : re));
-            ex = t ? en : (sgo ? (near3 ? chain_r : sx) : (mr ? e0 : re));
-          }
+          const slot_t ex = t ? en : (sgo ? (near3 ? chain : sx) : (mr ? e0 : slot_t{}));
           const bool land = t || atroot || sgo;                   // else: the next trip loads fails[nid] (ac.cr:189)
           const bool consumed = (t && probe) || (!t && atroot) || sres;  // at root a miss consumes (ac.cr:188)
-          if constexpr (kLeanPack) {
-            E = land ? (uint32_t)ex : E;
-          } else {
-            B = land ? S_::base(ex) : B;
-            fr = land ? S_::failroot(ex) : fr;
-          }
+          B = land ? S_::base(ex) : B;
+          fr = land ? S_::failroot(ex) : fr;
           hm = land ? 0xFFu : 0u;
           ev = consumed && S_::end(ex) && emit_ok;                // is_end? -> fetch later (ac.cr:183-185)
           s2 = consumed ? s2n : s2;
@@ -439,7 +331,6 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
           }
           rel += consumed ? 1u : 0u;
           bcur = consumed ? bnext : bcur;
-          if constexpr (DG == kDgStamp) AHA_STAMP(dt4);
           en_keep = S_::payload(ex);
         }
         if (__any(ev)) {
@@ -450,16 +341,8 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
                 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
                 const v2u rec = {en_keep, CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel)};
                 // a plain 8-byte store: hipcc ignores __builtin_nontemporal_store on gfx950, and a real non-temporal
-                // store (buffer store, aux = nt: lab variant kDgStoreNt) is worth under 1 % (profiles/r03_trip_anatomy.txt)
-                if constexpr (DG == kDgNoStore || DG == kDgNoFarNoStore) {
-                  dg_dummy ^= rec.x ^ rec.y;
-                } else if constexpr (DG == kDgStoreNt) {
-                  __builtin_amdgcn_raw_buffer_store_b64(
-                      rec, __builtin_amdgcn_make_buffer_rsrc(M.evd, 0, -1, 0x00020000),
-                      (int)(((uint32_t)chunk * ev_stride + seq) * 8u), 0, 2);
-                } else {
-                  *reinterpret_cast<v2u *>(evreg + seq) = rec;
-                }
+                // store (buffer store, aux = nt) was worth under 1 % (profiles/r03_trip_anatomy.txt)
+                *reinterpret_cast<v2u *>(evreg + seq) = rec;
               } else {
                 M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
               }
@@ -478,16 +361,6 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
               seq++;
             }
           }
-        }
-        if constexpr (DG == kDgStamp) {
-          AHA_STAMP(dt5);
-          const int o = dg_anyfar ? 6 : 0;
-          dg_acc[o + 0] += (uint32_t)(dt1 - dt0);  // A: addresses, issue of the probe and the four LDS reads, LDS round trip
-          dg_acc[o + 1] += (uint32_t)(dt2 - dt1);  // B: selects that need no probe result
-          dg_acc[o + 2] += (uint32_t)(dt3 - dt2);  // C: rest of the wait for the probe (vmcnt(0): previous event store too)
-          dg_acc[o + 3] += (uint32_t)(dt4 - dt3);  // D: selects on the probe result
-          dg_acc[o + 4] += (uint32_t)(dt5 - dt4);  // E: event store
-          dg_acc[o + 5] += 1u;
         }
       }
         if (!__any(rel < lim)) break;
@@ -508,15 +381,6 @@ __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse
     }
   }
   if (slab_id != ~0ull && lane == 0) M.slab_used[slab_id] = slab_used_n;
-#ifdef AHA_DIAG
-  if constexpr (DG == kDgStamp) {
-    if (lane == 0)
-      for (int k = 0; k < 12; k++) g_diag_stamps[(blockIdx.x * (kV2Threads / 64) + wave) * 16 + k] = dg_acc[k];
-  }
-  if constexpr (DG != kDgNone && DG != kDgStamp) {
-    if (dg_dummy == 0x9E3779B9u) M.cursor[15] = dg_dummy;  // never true in practice: keeps the lab's extra work alive
-  }
-#endif
 }
 
 // ---------------------------------------------------------------- scans
@@ -1005,56 +869,12 @@ int v2_prepare(bool compact, size_t lds_bytes) {
   return rc;
 }
 
-#ifdef AHA_DIAG
-// Lab build only (make diag): which variant of the headline kernel the next launches run, and the stamp sums.
-int g_diag_knob = 0;
-template <int DG>
-static void diag_launch_one(const DevAut &A, const V2Args &M, uint32_t grid, size_t lds, hipStream_t s) {
-  (void)hipFuncSetAttribute((const void *)k2_traverse<true, false, false, DG>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k2_traverse<true, false, false, DG>), dim3(grid), dim3(kV2Threads), lds, s, A, M);
-}
-static void diag_launch(const DevAut &A, const V2Args &M, uint32_t grid, size_t lds, hipStream_t s) {
-  switch (g_diag_knob) {
-    case 1: diag_launch_one<1>(A, M, grid, lds, s); break;
-    case 2: diag_launch_one<2>(A, M, grid, lds, s); break;
-    case 3: diag_launch_one<3>(A, M, grid, lds, s); break;
-    case 4: diag_launch_one<4>(A, M, grid, lds, s); break;
-    case 5: diag_launch_one<5>(A, M, grid, lds, s); break;
-    case 6: diag_launch_one<6>(A, M, grid, lds, s); break;
-    case 7: diag_launch_one<7>(A, M, grid, lds, s); break;
-    case 8: diag_launch_one<8>(A, M, grid, lds, s); break;
-    case 9: diag_launch_one<9>(A, M, grid, lds, s); break;
-    case 10: diag_launch_one<10>(A, M, grid, lds, s); break;
-    case 11: diag_launch_one<11>(A, M, grid, lds, s); break;
-    case 12: diag_launch_one<12>(A, M, grid, lds, s); break;
-    case 13: diag_launch_one<13>(A, M, grid, lds, s); break;
-    case 14: diag_launch_one<14>(A, M, grid, lds, s); break;
-    case 15: diag_launch_one<15>(A, M, grid, lds, s); break;
-    case 16: diag_launch_one<16>(A, M, grid, lds, s); break;
-    case 17: diag_launch_one<17>(A, M, grid, lds, s); break;
-    case 18: diag_launch_one<18>(A, M, grid, lds, s); break;
-    case 19: diag_launch_one<19>(A, M, grid, lds, s); break;
-    default: break;
-  }
-}
-extern "C" __attribute__((visibility("default"))) void aha_diag_set(int knob) { g_diag_knob = knob; }
-extern "C" __attribute__((visibility("default"))) int aha_diag_read_stamps(uint32_t *dst, uint64_t n_words) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_diag_stamps), n_words * 4, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
 void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = v2_lds_bytes(M.lds_slots, A.compact != 0);
   {
     const bool all = M.lds_slots >= A.n_slots;  // the whole image is in LDS
-#ifdef AHA_DIAG
-    if (g_diag_knob != kDgNone && A.compact && !M.chars && !all) {
-      diag_launch(A, M, grid, lds, s);
-      return;
-    }
-#endif
 #define AHA_LAUNCH_K2(C, H, L) \
   hipLaunchKernelGGL((k2_traverse<C, H, L>), dim3(grid), dim3(kV2Threads), lds, s, A, M)
     if (A.compact) {

@@ -302,7 +302,7 @@ def test_compile_time_of_the_headline_key_set():
     dt = time.time() - t0
     info = ac.info
     assert info["unit_enabled"] == 1 and info["unit_slots"] <= 1 << 20
-    assert dt < 2.0, dt
+    assert dt < (10.0 if "asan" in os.environ.get("AHA_HIP_LIB", "") else 2.0), dt  # (the sanitizer build is -O1)
 
 
 def test_replicate_needs_a_device_and_a_handle():

@@ -53,11 +53,84 @@ lib LibAhaHip
     longest : Int32 # 0 = #match, 1 = #match_longest(intersectable: false), 2 = #match_longest(intersectable: true)
   end
 
+  # aha_ac_info_t (ABI 6)
+  struct Info
+    struct_size : UInt32
+    n_keys : UInt32
+    n_states : UInt64
+    n_slots : UInt64
+    image_bytes : UInt64
+    max_key_len : UInt32
+    slot_bytes : UInt32
+    lds_slots : UInt32
+    device : Int32
+    fail_s1_lo : UInt32
+    fail_s2_lo : UInt32
+    fail_hdr_lo : UInt32
+    reserved : UInt32
+    unit_enabled : UInt32
+    unit_slots : UInt32
+    unit_syms : UInt32
+    unit_multi_permille : UInt32
+    unit_big_lo : UInt32
+    unit_big_block : UInt32
+    unit_n_low : UInt32
+    unit_n_big : UInt32
+    unit_base_bits : UInt32
+    reserved2 : UInt32
+  end
+
+  # aha_timing (ABI 6): filled when profiling is on
+  struct Timing
+    struct_size : UInt32
+    n_kernels : UInt32
+    ms_total : Float32
+    ms_count : Float32
+    ms_scan : Float32
+    ms_write : Float32
+    ms_aux : Float32
+    n_chunks : UInt64
+    n_hits : UInt64
+    engine : UInt32      # 4 = character-level traversal, 2 = single-traversal engine, 1 = two-pass engine
+    chunk_bytes : UInt32
+    repeats : UInt32     # passes thrown away: 1 = a region overflowed and the match ran again with full-size regions
+    reserved : UInt32
+  end
+
+  struct StreamSeg
+    word_offset : UInt64
+    n_hits : UInt64
+    out_offset : UInt64
+  end
+
+  struct GroupTiming
+    struct_size : UInt32
+    n_devices : UInt32
+    ms_match : Float32
+    ms_match_max_shard : Float32
+    ms_exchange : Float32
+    ms_download : Float32
+    n_hits : UInt64
+    exchange : UInt32
+    packed : UInt32
+    wire_bytes : UInt64
+  end
+
+  fun aha_abi_version : UInt32
+  fun aha_device_count : Int32
   fun aha_strerror(code : Int32) : UInt8*
   fun aha_last_error(ac : Ac) : UInt8*
   fun aha_ac_compile(key_bytes : UInt8*, key_offsets : UInt64*, n_keys : UInt32,
                      opts : Options*, out : Ac*, err_key : UInt32*) : Int32
   fun aha_ac_free(ac : Ac) : Void
+  # a second handle for the same keys on another device: nothing is compiled again (what aha_group_compile does)
+  fun aha_ac_replicate(ac : Ac, device : Int32, out : Ac*) : Int32
+  fun aha_ac_info(ac : Ac, info : Info*) : Int32
+  fun aha_ac_set_profiling(ac : Ac, enabled : Int32) : Int32
+  fun aha_ac_last_timing(ac : Ac, t : Timing*) : Int32
+  fun aha_ac_release_scratch(ac : Ac) : Int32
+  fun aha_ac_scratch_bytes(ac : Ac) : Int64
+  fun aha_ac_export(ac : Ac, which : Int32, buf : Void*, cap_bytes : UInt64) : Int64
   fun aha_ac_key(ac : Ac, id : Int32, buf : UInt8*, cap : Int32) : Int32
   fun aha_ac_id(ac : Ac, key : UInt8*, len : Int32) : Int32
   fun aha_ac_save(ac : Ac, buf : Void*, cap_bytes : UInt64) : Int64
@@ -68,7 +141,21 @@ lib LibAhaHip
                          params : MatchParams*, out : Hit*, cap : UInt64,
                          doc_hit_offsets : UInt64*, n_hits : UInt64*) : Int32
 
+  # host corpus in, hits left on the device (d_hits: device memory of the handle's device)
+  fun aha_ac_match_batch_keep(ac : Ac, corpus : UInt8*, doc_offsets : UInt64*, n_docs : UInt64,
+                              params : MatchParams*, d_hits : Hit*, cap : UInt64,
+                              doc_hit_offsets : UInt64*, n_hits : UInt64*) : Int32
+  # exchange formats of the hit lists (all on device memory, asynchronous on `stream`)
   fun aha_ac_stream_format(ac : Ac, step_bits : UInt32*, len_bits : UInt32*) : Int32
+  fun aha_ac_hits_pack_device(ac : Ac, d_hits : Hit*, n : UInt64, d_pairs : Int32*, stream : Void*) : Int32
+  fun aha_ac_hits_unpack_device(ac : Ac, d_pairs : Int32*, n : UInt64, char_offsets : Int32, d_hits : Hit*,
+                                stream : Void*) : Int32
+  fun aha_ac_hits_pack4_device(ac : Ac, d_hits : Hit*, n : UInt64, d_words : UInt32*, cap_words : UInt64,
+                               d_n_words : UInt64*, stream : Void*) : Int32
+  fun aha_ac_hits_unpack4_device(ac : Ac, d_words : UInt32*, n : UInt64, char_offsets : Int32, d_hits : Hit*,
+                                 stream : Void*) : Int32
+  fun aha_ac_hits_unpack4_segs_device(ac : Ac, d_words : UInt32*, segs : StreamSeg*, n_segs : UInt32,
+                                      char_offsets : Int32, d_hits : Hit*, stream : Void*) : Int32
   # device-resident batches: upload a corpus once, match it many times, keep the hits in HBM until they are wanted
   fun aha_ac_match_batch_device(ac : Ac, d_corpus : UInt8*, d_doc_offsets : UInt64*, n_docs : UInt64, n_bytes : UInt64,
                                 params : MatchParams*, d_out : Hit*, cap : UInt64, d_doc_hit_offsets : UInt64*,
@@ -91,6 +178,11 @@ lib LibAhaHip
                         devices : Int32*, n_devices : Int32, flags : UInt32,
                         out : Group*, err_key : UInt32*) : Int32
   fun aha_group_free(g : Group) : Void
+  fun aha_group_size(g : Group) : Int32
+  fun aha_group_last_error(g : Group) : UInt8*
+  fun aha_group_partition(doc_offsets : UInt64*, n_docs : UInt64, n_parts : Int32, bounds : UInt64*) : Int32
+  fun aha_group_download_shard(g : Group, shard : Int32, out : Hit*, cap : UInt64, n_hits : UInt64*) : Int32
+  fun aha_group_last_timing(g : Group, t : GroupTiming*) : Int32
   fun aha_group_match_batch(g : Group, corpus : UInt8*, doc_offsets : UInt64*, n_docs : UInt64,
                             params : MatchParams*, out : Hit*, cap : UInt64,
                             doc_hit_offsets : UInt64*, n_hits : UInt64*) : Int32
@@ -231,8 +323,9 @@ module Aha
       run(seq.to_slice, true, sep) { |hit| yield hit }
     end
 
-    # ACX#match_longest src/aha/ac.cr:297-319 (stale END flags of Cedar slots, cedar.cr:642-648, are not reproduced:
-    # see aha_amd/csrc/kernels.hip)
+    # ACX#match_longest src/aha/ac.cr:297-319.  Cedar's stale END flags (cedar.cr:642-648) ARE reproduced: the library
+    # replays Cedar's inserts from the keys on the first match_longest call of a handle (aha_amd/csrc/cedar_replay.cpp);
+    # NUL bytes in the text behave as in the reference (value nodes, kernels.hip)
     def match_longest(seq : Bytes | Array(UInt8), intersectable = false, &block)
       bytes = seq.is_a?(Bytes) ? seq : Slice.new(seq.to_unsafe, seq.size)
       run(bytes, false, nil, intersectable ? 2 : 1) { |hit| yield hit }

@@ -22,8 +22,11 @@
  * capacity allows for plus 1/64 of the chunk, i.e. 16 bytes per hit of capacity + N/8.  Slab pipeline (capacity
  * below 16 hits per chunk, or a separator filter): 41 bytes per hit of capacity + 80 MB.  One event per input byte
  * (8 N bytes, bounded at 48 GiB) only when `cap` announces more than one hit per 4 input bytes or a chunk
- * overflowed its region.  Plus ~24 bytes per chunk and 4 bytes per document.  A device corpus that is not 16-byte
- * aligned is first copied into scratch (N bytes).
+ * overflowed its region (aha_timing.repeats then says that the call ran twice).  Plus ~24 bytes per chunk and 4 bytes per
+ * document.  A device corpus that is not 16-byte aligned is first copied into scratch (N bytes).
+ * Character-level engine (aha_ac_info_t.unit_enabled; aha_timing.engine = 4): its records are 12 bytes and go straight to
+ * the expansion -- 24 bytes per hit of capacity + 3N/16 with the fused expansion (output chains of at most 15 keys; 7 with
+ * 23-bit bases), + the 8-byte regions above with the general post passes.
  */
 #ifndef AHA_HIP_H
 #define AHA_HIP_H
@@ -233,9 +236,10 @@ int32_t aha_ac_hits_unpack_device(aha_ac *ac, const int32_t *d_pairs, uint64_t n
  * every 1024, for a document change and for a gap of 2^step_bits - 1 or more:
  *   d_words = words[n] . first_exception[ceil(n/1024)] . exception_end[...]
  * The widths follow from the automaton (aha_ac_stream_format; every rank holds the same one): key ids take
- * bit_width(n_keys - 1) bits, lengths bit_width(longest key in bytes); with at least 6 bits left the step gets what is
+ * bit_width(n_keys - 1) bits, lengths bit_width(longest key in bytes); with at least 10 bits left the step gets what is
  * left (at most 12) and the receiver rebuilds Hit#start without a table lookup; else len_bits = 0, step_bits = 12
- * (key ids below 2^20) and the length is looked up on arrival.
+ * (key ids below 2^20) and the length is looked up on arrival (a narrower step would turn every gap of a few hundred
+ * bytes into an exception, 4 more bytes on the link).
  * pack4 needs cap_words >= 2 n + ceil(n/1024) (the worst case) and writes the real length -- what has to travel --
  * into *d_n_words (device memory); unpack4 takes the stream and n.  Asynchronous on `stream`. */
 int32_t aha_ac_stream_format(const aha_ac *ac, uint32_t *step_bits, uint32_t *len_bits);

@@ -50,6 +50,7 @@ while time.time() < t_end:
            "AHA_SHADOW_FAIL": rng.choice([None, None, None, "0"]),
            "AHA_ENGINE": rng.choice([None, None, "unit", "unit", "v2", "v1"]),
            "AHA_UNIT_POST": rng.choice([None, None, "regroup"]),
+           "AHA_UNIT_WALKS": rng.choice([None, None, "2"]),
            "AHA_DIRECT": rng.choice([None, None, "0"])}
     for k, v in env.items():
         if v is None:

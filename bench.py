@@ -388,10 +388,10 @@ def main():
     engine = ac.last_timing()["engine"]
     A = info["image_bytes"]
     if engine == 4:
-        # ku_traverse (character-level image): corpus + doc offsets + the unit image in (8-byte slots, the side array of
-        # fail words, the root table and the decode tables); its event records are scratch
+        # ku_traverse (character-level image): corpus + doc offsets + the unit image in (8-byte slots -- the fail headers
+        # are among them since round 4 --, the root table and the decode tables); its event records are scratch
         dom, dom_ms = "ku_traverse", avg["ms_count"]
-        A = info["unit_slots"] * 12 + info["unit_syms"] * 4 + 11264
+        A = info["unit_slots"] * 8 + info["unit_syms"] * 4 + 11264
         alg_bytes = n_bytes + 8 * (D + 1) + A
     elif engine == 2:
         # k2_traverse: corpus + doc offsets + automaton image in; its event records are scratch

@@ -89,3 +89,19 @@ def test_fewer_steps_than_bytes(monkeypatch):
     text = "".join(rng.choice(CHARS[6:12]) for _ in range(3000)).encode()
     assert sim.match(text) == as_list(orc.AC.compile(keys).match(text))
     assert sim.trips < len(text) * 0.9  # 3000 characters, a tiny alphabet: many retries from fail states, a header trip for most
+
+
+def test_image_with_23_bit_bases_matches_the_oracle(monkeypatch):
+    """BASELINE cfg 5's million keys: 3.9 M unit states do not fit 22-bit bases, the image takes 23 (six filter bits, unit.hpp
+    BASE WIDTH).  The CPU twin walks it over 64 KiB of cfg 5's own hit-dense text against the oracle."""
+    from aha_amd import synth
+    monkeypatch.delenv("AHA_ENGINE", raising=False)  # the library's own choice
+    blob, offs, nf = synth.keys(5)
+    corpus, doc = synth.corpus(5, blob, offs, nf, n_bytes=1 << 16, doc_bytes=1 << 16)
+    ac = AC.compile_packed(blob, offs, host_only=True)
+    info = ac.info
+    assert info["unit_enabled"] == 1 and info["unit_base_bits"] == 23 and info["unit_slots"] > 1 << 22
+    text = corpus[:int(doc[1])].tobytes()
+    o = orc.AC.compile_packed(blob, offs)
+    oh, _ = o.match_batch(corpus[:int(doc[1])], np.array([0, int(doc[1])], dtype=np.uint64))
+    assert UnitSim(ac).match(text) == [tuple(int(x) for x in h) for h in oh]

@@ -12,9 +12,10 @@ def audit(isa):
     bad, seen = [], 0
     i = 0
     while i < len(lines):
-        if "#ASMSTART" in lines[i] and i + 1 < len(lines) and "global_load_dwordx2" in lines[i + 1]:
-            m = re.search(r"global_load_dwordx2\s+v\[(\d+):(\d+)\]", lines[i + 1])
-            regs = {f"v{r}" for r in range(int(m.group(1)), int(m.group(2)) + 1)}
+        if "#ASMSTART" in lines[i] and i + 1 < len(lines) and "global_load_dword" in lines[i + 1]:
+            m = re.search(r"global_load_dword(?:x\d)?\s+v(?:\[(\d+):(\d+)\]|(\d+))", lines[i + 1])
+            lo_, hi_ = (int(m.group(1)), int(m.group(2))) if m.group(1) else (int(m.group(3)), int(m.group(3)))
+            regs = {f"v{r}" for r in range(lo_, hi_ + 1)}
             pat = re.compile(r"\b(" + "|".join(regs) + r")\b|v\[(\d+):(\d+)\]")
             seen += 1
             j = i + 3  # behind ASMEND
@@ -38,7 +39,6 @@ def audit(isa):
                 j += 1
             if not ok:
                 bad.append((i + 2, "no hand-written wait behind this load"))
-            i = j
         i += 1
     return seen, bad
 
@@ -47,7 +47,7 @@ def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "scan_unit.s")
-        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", *sys.argv[1:], "-I", os.path.join(ROOT, "include"),
                                "-I", os.path.join(ROOT, "aha_amd", "csrc"), "-S", "--cuda-device-only", "-w", "-o", out,
                                os.path.join(ROOT, "aha_amd", "csrc", "scan_unit.hip")])
         seen, bad = audit(open(out).read())

@@ -379,7 +379,7 @@ void v2_setup(aha_ac *ac) {
     uint32_t max_cnt = 0;
     for (uint32_t k = 0; k < a.n_keys; k++) max_cnt = std::max(max_cnt, a.key_cnt[k]);
     const char *upost = getenv("AHA_UNIT_POST");  // "regroup": the general post passes (tests)
-    const bool fused = !ac->key_info.empty() && max_cnt <= u_max_c4(ac->unit.base_bits) && a.max_key_len < 65536 &&
+    const bool fused = !ac->key_info.empty() && max_cnt <= kUFusedMaxChain && a.max_key_len < 65536 &&
                        !(upost && strcmp(upost, "regroup") == 0);
     std::vector<uint2> uend, uendc;
     if (fused) {

@@ -112,7 +112,7 @@ struct V2Args {
   uint32_t ev_stride;        // events a chunk may store (S / 4); more -> overflow flag, slab pipeline instead
   uint2 *evd;                // [n_chunks * ev_stride] {state base (compact) or key id, end offset in the document}
   uint32_t *evg;             // [n_chunks * ev_stride * 3] character-level traversal: the events of 64 chunks (a wave) together,
-                             // in the order of the wave's trips: {END state base | lane << 22 | min(hits, 15) << 28, end offset
+                             // in the order of the wave's trips: {END state base | lane | min(hits, 255) (unit.hpp u_rec_x / u_rec_z), end offset
                              // in the document, hits of the chunk before the event}
   uint32_t *doc_hit_rank;    // [D+1] character-level traversal: hits of the chunk before the document start (exact when no
                              // event stands for more than 15 hits: the record carries the count in bits 28..31 then)

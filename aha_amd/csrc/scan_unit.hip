@@ -346,12 +346,13 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const bool ev = evc != 0u;
             const uint32_t my = wfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(evm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)evm, 0u));
             // {END state | lane | hits it stands for, end offset in the document, hits of the chunk before it}
-            const uint32_t rx = u_child(E, BB) | (uint32_t)lane << BB | evc << (BB + 6), ry = CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel);
+            const uint32_t rx = u_rec_x(u_child(E, BB), (uint32_t)lane, evc, BB), rz = u_rec_z(hits, evc, BB);
+            const uint32_t ry = CHARS ? ((lc << 1) | lc_exact) : (uint32_t)(docrel + (int32_t)rel);
             if (ev && my < 64u) {
               uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + __umul24(my, 12u)));
               d[0] = rx;
               d[1] = ry;
-              d[2] = hits;
+              d[2] = rz;
             }
             const uint32_t kp = __popcll(evm);
             if (wfill + kp >= 64u) {
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
                 uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + __umul24(my - 64u, 12u)));
                 d[0] = rx;
                 d[1] = ry;
-                d[2] = hits;
+                d[2] = rz;
               }
             }
             wfill = (wfill + kp) & 63u;
@@ -647,12 +648,12 @@ __global__ __launch_bounds__(kV2Threads) void ku2_traverse(UnitDev U, V2Args M) 
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(evm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)evm, 0u));
       const uint32_t kp = __popcll(evm);
       // {END state | lane | hits it stands for, end offset in the document, hits of the chunk before it}
-      const uint32_t rx = u_child(X.E) | (uint32_t)lane << 22 | evc << 28;
+      const uint32_t rx = u_rec_x(u_child(X.E), (uint32_t)lane, evc, 22u), rz = u_rec_z(X.hits, evc, 22u);
       const uint32_t ry = CHARS ? ((X.lc << 1) | X.lc_exact) : (uint32_t)(X.docrel + (int32_t)X.x);
       if (T.wfill + kp > CAP) flush(T);
       if (kp > CAP) {  // (hit-dense text: more events in one trip than the buffer holds)
         if (ev && T.wout + rank < T.wcap) {
-          const v3u r = {rx, ry, X.hits};
+          const v3u r = {rx, ry, rz};
           *reinterpret_cast<v3u *>(T.wreg + (size_t)(T.wout + rank) * 3) = r;
         }
         T.wout += kp;
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(kV2Threads) void ku2_traverse(UnitDev U, V2Args M) 
           uint32_t *d = reinterpret_cast<uint32_t *>(smem + (T.wbo + __umul24(T.wfill + rank, 12u)));
           d[0] = rx;
           d[1] = ry;
-          d[2] = X.hits;
+          d[2] = rz;
         }
         T.wfill += kp;
       }
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
   }
 }
 
-// The expansion in one pass over the wave-ordered events (key sets whose output chains hold at most 15 keys: the
+// The expansion in one pass over the wave-ordered events (key sets whose output chains hold at most 15 keys -- kUFusedMaxChain --: the
 // traversal then knows the hits of every chunk and of every event's predecessors in its chunk -- the record's third
 // word -- so the bases are scanned before this kernel and every record knows where its hits go: nothing has to be put
 // back into order).  Only the stores want order: a wave's 64 records belong to 64 chunks, and a 12-byte store per
@@ -941,7 +942,7 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
         rec[q] = nxt[q];
         nxt[q] = i + kXgBlock < total ? *reinterpret_cast<const v3u *>(src + (size_t)(i + kXgBlock) * 3) : v3u{0, 0, 0};
         ue[q] = live[q] ? uend[rec[q].x & bmask] : make_uint2(0, 0);
-        if (live[q]) atomicAdd(&s_tot[par][(rec[q].x >> bb) & 63u], rec[q].x >> (bb + 6u));
+        if (live[q]) atomicAdd(&s_tot[par][(rec[q].x >> bb) & 63u], u_rec_n(rec[q].x, rec[q].z, bb));
       }
       __syncthreads();
       if (wv == 0) {
@@ -957,8 +958,8 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
 #pragma unroll
         for (int q = 0; q < kXgPer; q++) {
           if (live[q]) {
-            const uint32_t l = (rec[q].x >> bb) & 63u, n = rec[q].x >> (bb + 6u);
-            const uint32_t pos = s_start[l] + (rec[q].z - s_run[l]);
+            const uint32_t l = (rec[q].x >> bb) & 63u, n = u_rec_n(rec[q].x, rec[q].z, bb);
+            const uint32_t pos = s_start[l] + (u_rec_before(rec[q].z) - s_run[l]);
             const uint32_t end = CHARS ? (rec[q].y >> 1) + ((rec[q].y & 1u) ? 0u : s_adj[l]) : rec[q].y, co = ue[q].y & 0xFFFFFFu;
             // Hit(idx - len + 1, idx + 1, value) ac.cr:271-273: the state's own key, then its output chain (ac.cr:265-278)
             uint32_t len = (ue[q].x >> 24) | (ue[q].y >> 24) << 8, key = ue[q].x & 0xFFFFFFu;

@@ -410,9 +410,8 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
     return base[st] | ((flt << base_bits) & u_all_filter(base_bits)) | (f1 ? (1u << 29) : 0u) | (nfr ? (1u << 30) : 0u) |
            (a.key_of[st] >= 0 ? 0x80000000u : 0u);
   };
-  const uint32_t c4_max = u_max_c4(base_bits);
-  auto u_c4_of = [c4_max](const Automaton &au, uint32_t st) -> uint32_t {  // hits an event in this state stands for, capped
-    return au.key_of[st] >= 0 ? std::min<uint32_t>(au.key_cnt[au.key_of[st]], c4_max) : 0u;
+  auto u_c4_of = [](const Automaton &au, uint32_t st) -> uint32_t {  // hits an event in this state stands for, capped
+    return au.key_of[st] >= 0 ? std::min<uint32_t>(au.key_cnt[au.key_of[st]], kUMaxC4) : 0u;
   };
   u.n_slots = n_slots;
   u.n_shared = n_shared;

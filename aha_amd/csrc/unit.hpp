@@ -40,7 +40,7 @@
 // IMAGE: an XOR double array with unique bases over the symbols, 8-byte slots, at most 2^22 of them.  A state is
 // carried around as ONE word -- the low word of the entry that led to it:
 //   transition  lo = child base (22 bits) | filter of the child (7 bits) << 22 | F1 << 29 | NFR << 30 | END << 31
-//               hi = symbol (16 bits) | min(hits an event in the child stands for, 15) << 16  (0 unless the child is END)
+//               hi = symbol (16 bits) | min(hits an event in the child stands for, 255) << 16  (0 unless the child is END)
 //   root[symbol]     the same word for the root's transitions (in LDS); 0 = the root itself (base 0, owns no slot)
 // `filter` is a 7-bit Bloom filter over the symbols the child has transitions on (bit symbol & 7; symbols with
 // symbol & 7 = 7 always probe): most characters that follow a character do not continue a key, and a clear bit
@@ -92,15 +92,27 @@ constexpr uint32_t kUT0a = 0, kUT0b = 1024, kUA1 = 1536, kUA2 = 2304, kUTabWords
 // decoding of a state word / an entry (device code and the CPU twin in tests/ use the same arithmetic)
 // BASE WIDTH.  An image of at most 2^22 slots has 22-bit bases and a 7-bit filter (classes symbol & 7: 0..6 stored, 7
 // always probes); a larger one (cfg 5: 1 M keys) 23-bit bases and a 6-bit filter (classes 0..5 stored, 6 and 7 always
-// probe), and an event record leaves 3 instead of 4 bits for the hits it stands for.  The flags stay at bits 29..31.
+// probe).  The flags stay at bits 29..31.
 AHA_HD inline uint32_t u_child(uint32_t lo, uint32_t bb = 22u) { return lo & ((1u << bb) - 1u); }
 AHA_HD inline uint32_t u_all_filter(uint32_t bb) { return ((1u << (29u - bb)) - 1u) << bb; }
-AHA_HD inline uint32_t u_max_c4(uint32_t bb) { return (1u << (26u - bb)) - 1u; }  // hits an event record can stand for
+// hits an event record can stand for: the count's low 26 - bb bits ride in the record's first word behind base and lane,
+// the rest in the top five bits of its third word (hits of the chunk before the event: below 2^27)
+constexpr uint32_t kUMaxC4 = 255u;
+// ... but the fused expansion (ku_expand_groups) is built for events of a hit or two: with chains of 16 -- cfg 5 -- it takes
+// 11.7 ms where the general post passes take 0.86 + 4.38 (its threads walk a chain serially through the staging
+// windows), so key sets with longer chains keep the general passes
+constexpr uint32_t kUFusedMaxChain = 15u;
+AHA_HD inline uint32_t u_rec_x(uint32_t base, uint32_t lane, uint32_t n, uint32_t bb) {
+  return base | lane << bb | (n & ((1u << (26u - bb)) - 1u)) << (bb + 6u);
+}
+AHA_HD inline uint32_t u_rec_z(uint32_t hits_before, uint32_t n, uint32_t bb) { return hits_before | (n >> (26u - bb)) << 27; }
+AHA_HD inline uint32_t u_rec_n(uint32_t x, uint32_t z, uint32_t bb) { return (x >> (bb + 6u)) | (z >> 27) << (26u - bb); }
+AHA_HD inline uint32_t u_rec_before(uint32_t z) { return z & 0x7FFFFFFu; }
 AHA_HD inline bool u_f1(uint32_t lo) { return ((lo >> 29) & 1u) != 0; }
 AHA_HD inline bool u_nfr(uint32_t lo) { return ((lo >> 30) & 1u) != 0; }
 AHA_HD inline bool u_end(uint32_t lo) { return (lo >> 31) != 0; }
 AHA_HD inline uint32_t u_sym(uint32_t hi) { return hi & 0xFFFFu; }
-AHA_HD inline uint32_t u_c4(uint32_t hi) { return (hi >> 16) & 15u; }
+AHA_HD inline uint32_t u_c4(uint32_t hi) { return (hi >> 16) & 255u; }
 AHA_HD inline bool u_hdr_pending(uint32_t lo) { return ((lo >> 29) & 3u) == 1u; }  // F1 without NFR: fetch the header next
 
 struct UnitImage {

@@ -25,8 +25,7 @@
  * overflowed its region (aha_timing.repeats then says that the call ran twice).  Plus ~24 bytes per chunk and 4 bytes per
  * document.  A device corpus that is not 16-byte aligned is first copied into scratch (N bytes).
  * Character-level engine (aha_ac_info_t.unit_enabled; aha_timing.engine = 4): its records are 12 bytes and go straight to
- * the expansion -- 24 bytes per hit of capacity + 3N/16 with the fused expansion (output chains of at most 15 keys; 7 with
- * 23-bit bases), + the 8-byte regions above with the general post passes.
+ * the expansion -- 24 bytes per hit of capacity + 3N/16 with the fused expansion (output chains of at most 15 keys), + the 8-byte regions above with the general post passes.
  */
 #ifndef AHA_HIP_H
 #define AHA_HIP_H
@@ -267,7 +266,7 @@ enum {
   AHA_IMG_KEY_CNT = 3, /* uint32[K] */
   AHA_IMG_KEY_KC = 4,  /* uint32[K] */
   AHA_IMG_UNIT_SLOTS = 6,     /* uint64[unit_slots]: a transition is lo = child base (22 bits) | filter (7) << 22 | F1 << 29 |
-                                 NFR << 30 | END << 31, hi = symbol (16 bits) | min(hits, 15) << 16; slots[base] of a state with
+                                 NFR << 30 | END << 31, hi = symbol (16 bits) | min(hits, 255) << 16; slots[base] of a state with
                                  NFR and without F1 is its header {word of the fail state, 0}; group records and child runs of
                                  the big states: aha_amd/csrc/unit.hpp, IMAGE and BIG STATES */
   AHA_IMG_UNIT_ROOT = 7,      /* uint32[unit_syms]: the root's transitions by symbol */

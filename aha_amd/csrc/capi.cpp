@@ -556,7 +556,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
       v2_launch_hit_scan(M, s);
       if (M.chars) v2_launch_lead_scan(M, s);  // characters before every chunk (the traversal counted them per chunk)
       if (prof) HIPCHK(ac, hipEventRecord(sc->ev[3], s));
-      unit_launch_expand(M.chars ? ac->d_unit_end_chars : ac->d_unit_end, post, M, s);
+      unit_launch_expand(M.chars ? ac->d_unit_end_chars : ac->d_unit_end, post, M, 2u * ac->v2_grid, s);
     } else {
       if (unit) unit_launch_regroup(post, M, s);  // the wave-ordered events back into the chunks' regions, counted
       v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr, unit);

@@ -147,7 +147,7 @@ void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void
 void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream);  // evg -> evd + chunk_hits (replaces k2d_count)
 // evg + hit_base -> out, doc_hit_off: the whole expansion in one pass over the wave-ordered events.  uend[base] of an END
 // state = {key | (key length & 255) << 24, offset of its flattened output chain | (key length >> 8) << 24}
-void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, void *stream);
+void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, uint32_t workgroups, void *stream);
 void v2_launch_hit_scan(const V2Args &M, void *stream);   // chunk_hits -> hit_base, totals[0]
 void v2_launch_lead_scan(const V2Args &M, void *stream);  // lead_cnt -> lead_base, totals[1] (char offsets)
 

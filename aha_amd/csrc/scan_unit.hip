@@ -28,6 +28,12 @@
 #ifndef AHA_LAB_PROBE_INDEX
 #define AHA_LAB_PROBE_INDEX(i) (i)
 #endif
+#ifndef AHA_LAB_XG_GATHER_INDEX
+#define AHA_LAB_XG_GATHER_INDEX(i) (i)
+#endif
+#ifndef AHA_LAB_XG_SHAPE
+#define AHA_LAB_XG_SHAPE 1024, 1, 1536
+#endif
 
 namespace aha {
 
@@ -46,7 +52,13 @@ constexpr int kUWave = 64 * kURow;
 __device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t g, int64_t N) {
   uint4 v = make_uint4(0, 0, 0, 0);
   if (g >= 0 && g + 16 <= N) {
+#ifdef AHA_LAB_NT_TEXT
+    typedef uint32_t v4u_ __attribute__((ext_vector_type(4)));
+    const v4u_ t_ = __builtin_nontemporal_load(reinterpret_cast<const v4u_ *>(text + g));
+    v = make_uint4(t_.x, t_.y, t_.z, t_.w);
+#else
     v = *reinterpret_cast<const uint4 *>(text + g);
+#endif
   } else if (g >= 0 && g < N) {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // (rare: the text's last bytes; kept as a loop)
 #pragma unroll 1
@@ -358,7 +370,11 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             if (wfill + kp >= 64u) {
               const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (wbo + __umul24((uint32_t)lane, 12u)));
               const v3u r = {q[0], q[1], q[2]};
+#ifdef AHA_LAB_NT_EV
+              if (wout + 64u <= wcap) __builtin_nontemporal_store(r, reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3));
+#else
               if (wout + 64u <= wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
+#endif
               wout += 64u;
               if (ev && my >= 64u) {
                 uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + __umul24(my - 64u, 12u)));
@@ -892,7 +908,14 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
 // output chain (the second and later hits of an event -- rare -- read the chain).
 // CHARS: uend carries the key's length in characters, the record's second word the character count (see ku_traverse):
 // hits are char offsets, Hit(char_of_byte[start], char_of_byte[end - 1] + 1) (matcher.cr:34-39).
-constexpr int kXgThreads = 256, kXgPer = 4, kXgBlock = kXgThreads * kXgPer, kXgStage = 1536;
+#ifdef AHA_LAB_XG_PLAIN_LOADS
+#define AHA_XG_LOAD(p) (*(p))
+#else
+#define AHA_XG_LOAD(p) __builtin_nontemporal_load(p)  // the records are read once: they should not push uend lines out of L1 / L2
+#endif
+constexpr int kXgShape[3] = {AHA_LAB_XG_SHAPE};  // threads, records per thread, staged hits
+constexpr int kXgThreads = kXgShape[0], kXgPer = kXgShape[1], kXgBlock = kXgThreads * kXgPer, kXgStage = kXgShape[2];
+constexpr int kXgCacheBits = 11;
 template <bool CHARS>
 __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend, DevAut A, V2Args M) {
   __shared__ uint32_t s_hs[kXgStage], s_he[kXgStage], s_hk[kXgStage];  // staged hits: start, end, key
@@ -900,11 +923,17 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
   __shared__ uint32_t s_tot[2][64], s_start[64], s_run[64], s_all;
   __shared__ uint64_t s_base[64];  // the chunk's place in the output
   __shared__ uint32_t s_adj[64];   // CHARS: characters between the start of the document that contains the chunk start and it
+  // uend entries this workgroup has seen, direct-mapped by a hash of the base: {base + 1, first word}.  Hits pile up on few
+  // END states (cfg 3: 28 M of 30 M events end one of 676 two-letter keys), but those states' bases -- and with them their
+  // uend lines -- lie all over the image: 676 lines do not stay in a 32 KiB L1, 676 entries do in 16 KiB of LDS.  Only states
+  // that stand for one hit of a key shorter than 256 are kept (the first word is all the expansion needs of them).
+  __shared__ unsigned long long s_cache[1 << kXgCacheBits];
   if (M.cursor[1]) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
   const uint32_t stride = M.ev_stride;
   const uint32_t bb = M.unit_bb, bmask = (1u << bb) - 1u;  // the image's base width (unit.hpp, BASE WIDTH)
+  for (uint32_t i = threadIdx.x; i < (1u << kXgCacheBits); i += kXgThreads) s_cache[i] = 0ull;
   for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     __syncthreads();
     const uint64_t c = g * 64 + lane;
@@ -927,22 +956,37 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
 #pragma unroll
     for (int q = 0; q < kXgPer; q++) {
       const uint32_t i = q * kXgThreads + threadIdx.x;
-      nxt[q] = i < total ? *reinterpret_cast<const v3u *>(src + (size_t)i * 3) : v3u{0, 0, 0};
+      nxt[q] = i < total ? AHA_XG_LOAD(reinterpret_cast<const v3u *>(src + (size_t)i * 3)) : v3u{0, 0, 0};
     }
     __syncthreads();
     uint32_t par = 0;
     for (uint32_t i0 = 0; i0 < total; i0 += kXgBlock, par ^= 1u) {
       v3u rec[kXgPer];
       uint2 ue[kXgPer];
-      bool live[kXgPer];
+      bool live[kXgPer], keep[kXgPer];
+      uint32_t cs[kXgPer];
 #pragma unroll
       for (int q = 0; q < kXgPer; q++) {
         const uint32_t i = i0 + q * kXgThreads + threadIdx.x;
         live[q] = i < total;
         rec[q] = nxt[q];
-        nxt[q] = i + kXgBlock < total ? *reinterpret_cast<const v3u *>(src + (size_t)(i + kXgBlock) * 3) : v3u{0, 0, 0};
-        ue[q] = live[q] ? uend[rec[q].x & bmask] : make_uint2(0, 0);
-        if (live[q]) atomicAdd(&s_tot[par][(rec[q].x >> bb) & 63u], u_rec_n(rec[q].x, rec[q].z, bb));
+        nxt[q] = i + kXgBlock < total ? AHA_XG_LOAD(reinterpret_cast<const v3u *>(src + (size_t)(i + kXgBlock) * 3)) : v3u{0, 0, 0};
+        const uint32_t b = rec[q].x & bmask, n = u_rec_n(rec[q].x, rec[q].z, bb);
+        cs[q] = (b * 0x9E3779B1u) >> (32 - kXgCacheBits);
+        const unsigned long long ce = s_cache[cs[q]];
+#ifdef AHA_LAB_XG_NO_CACHE
+        const bool cached = false;
+#else
+        const bool cached = live[q] & n == 1u & (uint32_t)ce == b + 1u;
+#endif
+#ifdef AHA_LAB_XG_NO_GATHER
+        ue[q] = make_uint2(1u << 24 | (rec[q].x & 0xFFFFu), 0u);
+#else
+        ue[q] = make_uint2((uint32_t)(ce >> 32), 0u);
+        if (live[q] && !cached) ue[q] = uend[AHA_LAB_XG_GATHER_INDEX(b)];
+#endif
+        keep[q] = live[q] & !cached & n == 1u;
+        if (live[q]) atomicAdd(&s_tot[par][(rec[q].x >> bb) & 63u], n);
       }
       __syncthreads();
       if (wv == 0) {
@@ -954,6 +998,10 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
       }
       __syncthreads();
       const uint32_t T = s_all;
+#pragma unroll
+      for (int q = 0; q < kXgPer; q++)  // (between two barriers after every lookup of this block, before the next block's)
+        if (keep[q] && (ue[q].y >> 24) == 0u)
+          atomicExch(&s_cache[cs[q]], (unsigned long long)ue[q].x << 32 | ((rec[q].x & bmask) + 1u));
       for (uint32_t w0 = 0; w0 < T; w0 += kXgStage) {  // one window unless events stand for many hits
 #pragma unroll
         for (int q = 0; q < kXgPer; q++) {
@@ -983,7 +1031,11 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
         for (uint32_t j = threadIdx.x; j < nh; j += kXgThreads) {
           const uint32_t l = s_hl[j];
           const uint64_t idx = s_base[l] + s_run[l] + (w0 + j - s_start[l]);
+#ifdef AHA_LAB_XG_NO_STORE
+          if (idx < M.cap && s_hk[j] == 0xFFFFFFF0u) {
+#else
           if (idx < M.cap) {
+#endif
             aha_hit hit;
             hit.start = (int32_t)s_hs[j];
             hit.end = (int32_t)s_he[j];
@@ -1051,9 +1103,13 @@ void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream) {
                      (hipStream_t)stream, A, M);
 }
 
-void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, void *stream) {
+void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, uint32_t workgroups, void *stream) {
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
-  const dim3 grid((uint32_t)std::min<uint64_t>(n_groups, 1u << 16));
+  // persistent workgroups (two of 1024 threads fit a CU): each keeps its LDS cache of uend entries over its groups
+#ifdef AHA_LAB_XG_GRID
+  workgroups = AHA_LAB_XG_GRID;
+#endif
+  const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_groups, workgroups)));
   if (M.chars)
     hipLaunchKernelGGL(ku_expand_groups<true>, grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
   else

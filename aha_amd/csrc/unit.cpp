@@ -449,6 +449,12 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
 }
 
 void build_unit(const Automaton &a, UnitImage &u, bool force) {
+  // AHA_UNIT_BASE_BITS=23 (tests, the fuzzer): the wide format for every image, so that its kernels meet small random automata
+  const char *bw = getenv("AHA_UNIT_BASE_BITS");
+  if (bw && strcmp(bw, "23") == 0) {
+    build_unit_bits(a, u, force, 23u);
+    return;
+  }
   build_unit_bits(a, u, force, 22u);
   // (only the size of the image asks for wider bases: every other refusal holds for them too)
   if (!u.ok && strstr(u.why, "bases address")) build_unit_bits(a, u, force, 23u);

@@ -17,7 +17,7 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u2", "auto"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u2", "u23", "auto"], autouse=True)
 def engine(request, monkeypatch):
     """Every parity test runs on the single-traversal engine (scan_v2.hip, byte level), on the two-pass engine
     (kernels.hip: the fallback for tiny capacities and very long keys), on the single-traversal engine with its LDS
@@ -26,17 +26,23 @@ def engine(request, monkeypatch):
     unit image for every eligible key set, also the mostly-ASCII ones that would not get one by default; byte-offset
     calls through the event regions then run it, everything else the single-traversal engine; its post pass is the fused
     expansion wherever the output chains are short enough, "ur" -- AHA_UNIT_POST=regroup -- keeps it to the general
-    regroup + count + expand passes; "u2" -- AHA_UNIT_WALKS=2 -- walks two chunks per lane, ku2_traverse).  "auto" sets
+    regroup + count + expand passes; "u2" -- AHA_UNIT_WALKS=2 -- walks two chunks per lane, ku2_traverse; "u23" --
+    AHA_UNIT_BASE_BITS=23 -- builds every image in the wide format of images beyond 2^22 slots: 23-bit bases, 6-bit filter,
+    3-bit hit count in the event record).  "auto" sets
     no variable: the library decides per key set, which is what a caller and bench.py get.  The variables are read when a
     handle is compiled."""
     if request.param == "auto":
         monkeypatch.delenv("AHA_ENGINE", raising=False)
     else:
-        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u2": "unit"}.get(request.param, "v2"))
+        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u2": "unit", "u23": "unit"}.get(request.param, "v2"))
     if request.param == "u2":
         monkeypatch.setenv("AHA_UNIT_WALKS", "2")
     else:
         monkeypatch.delenv("AHA_UNIT_WALKS", raising=False)
+    if request.param == "u23":
+        monkeypatch.setenv("AHA_UNIT_BASE_BITS", "23")
+    else:
+        monkeypatch.delenv("AHA_UNIT_BASE_BITS", raising=False)
     if request.param == "ur":
         monkeypatch.setenv("AHA_UNIT_POST", "regroup")
     else:
@@ -471,7 +477,7 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
             t0 = time.perf_counter()
             assert g.match_batch_device(view, dd, out) == n
             best = min(best, time.perf_counter() - t0)
-        assert g.last_timing()["engine"] == (4 if engine in ("u", "u2") else 2)
+        assert g.last_timing()["engine"] == (4 if engine in ("u", "u2", "u23") else 2)
         res[shift] = (best, out[:n].cpu().numpy().tobytes())
     assert res[0][1] == res[1][1]
     assert res[0][0] / res[1][0] >= 0.8, (res[0][0], res[1][0])
@@ -483,12 +489,12 @@ def test_engine_selected(engine, monkeypatch):
     ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u2", "auto") else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u2", "u23", "auto") else (2,))
     ac = AC.compile(["ab", "ba"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"ab ba " * 60))[:3] == [(0, 2, 0), (3, 5, 1), (6, 8, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u2", "auto") else (2,))
-    if engine in ("u", "ur", "u2"):
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u2", "u23", "auto") else (2,))
+    if engine in ("u", "ur", "u2", "u23"):
         # the library's own choice (no AHA_ENGINE): keys of multi-byte characters get the character-level traversal for
         # byte- and char-offset batches, ASCII keys keep the byte-level one
         monkeypatch.delenv("AHA_ENGINE", raising=False)
@@ -510,7 +516,7 @@ def test_engine_selected(engine, monkeypatch):
         assert asc.info["unit_enabled"] == 0 and asc.last_timing()["engine"] == 2
     # char offsets run on the character-level engine too, the separator filter on the byte-level engines only
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u2", "auto") else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u2", "u23", "auto") else (2,))
     sep = BitArray(256)
     sep[ord(" ")] = True
     assert [tuple(h) for h in ac.match("ab ba", sep)] == [(0, 2, 0), (3, 5, 1)]

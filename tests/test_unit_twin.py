@@ -105,3 +105,39 @@ def test_image_with_23_bit_bases_matches_the_oracle(monkeypatch):
     o = orc.AC.compile_packed(blob, offs)
     oh, _ = o.match_batch(corpus[:int(doc[1])], np.array([0, int(doc[1])], dtype=np.uint64))
     assert UnitSim(ac).match(text) == [tuple(int(x) for x in h) for h in oh]
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("bits", [22, 23])
+def test_big_states_in_both_base_widths(seed, bits, monkeypatch):
+    """Hub characters that most keys start with: states with hundreds of transitions over a wide alphabet (the image's big
+    states: direct row, group records, child runs), in the 22-bit format and -- AHA_UNIT_BASE_BITS=23 -- in the wide one."""
+    rng = random.Random(7000 + seed)
+    cps = rng.sample(range(0x4E00, 0x9FA5), rng.choice([60, 300, 1500])) + list(range(0x61, 0x7B)) + \
+        rng.sample(range(0x430, 0x450), 8)
+    units = [chr(c).encode() for c in cps]
+    hubs = rng.sample(units, rng.randint(1, 4))
+    keys = sorted({(rng.choice(hubs) if rng.random() < 0.7 else b"") + b"".join(rng.choice(units) for _ in range(rng.randint(1, 4)))
+                   for _ in range(rng.choice([2000, 8000]))})
+    if bits == 23:
+        monkeypatch.setenv("AHA_UNIT_BASE_BITS", "23")
+    else:
+        monkeypatch.delenv("AHA_UNIT_BASE_BITS", raising=False)
+    ac = compile_unit(keys, monkeypatch)
+    info = ac.info
+    assert info["unit_enabled"] == 1 and info["unit_base_bits"] == bits and info["unit_n_big"] >= 1
+    sim = UnitSim(ac)
+    o = orc.AC.compile(keys)
+    filler = b"".join(units[:40]) + b"\xe4\xb8\xf0 "
+    for _ in range(3):
+        parts = []
+        while sum(map(len, parts)) < 3000:
+            r = rng.random()
+            if r < 0.4:
+                parts.append(rng.choice(keys))
+            elif r < 0.7:
+                parts.append(rng.choice(hubs) + rng.choice(units))
+            else:
+                parts.append(bytes(rng.choice(filler) for _ in range(rng.randint(1, 9))))
+        text = b"".join(parts)
+        assert sim.match(text) == as_list(o.match(text))

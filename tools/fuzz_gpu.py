@@ -26,7 +26,22 @@ while time.time() < t_end:
     lo, hi = rng.choice([(1, 3), (1, 8), (2, 12), (1, 24)])
     keys, seen = [], set()
     tries = 0
-    if rng.random() < 0.3:  # whole UTF-8 characters as the alphabet (eligible for the character-level engine); the
+    big = rng.random() < 0.2
+    if big:  # a wide alphabet of whole characters and a few hub characters that most keys start with: states with hundreds
+        # of transitions (the unit image's big states: direct row, group records, child runs) beside ordinary ones
+        cps = rng.sample(range(0x4E00, 0x9FA5), rng.choice([60, 300, 1500])) + list(range(0x61, 0x7B)) + \
+            rng.sample(range(0x430, 0x450), 8)
+        units = [chr(c).encode() for c in cps]
+        hubs = rng.sample(units, rng.randint(1, 4))
+        nk = rng.choice([200, 2000, 20000])
+        while len(keys) < nk and tries < nk * 20:
+            tries += 1
+            k = (rng.choice(hubs) if rng.random() < 0.7 else b"") + b"".join(rng.choice(units) for _ in range(rng.randint(1, 4)))
+            if k not in seen:
+                seen.add(k)
+                keys.append(k)
+        alpha = b"".join(rng.sample(units, min(len(units), 40)) + hubs * 6) + b"\xe4\xb8\xf0 "
+    elif rng.random() < 0.3:  # whole UTF-8 characters as the alphabet (eligible for the character-level engine); the
         # text below is still cut anywhere and mixed with malformed sequences
         units = [c.encode() for c in rng.sample("abcéжя中国人我是々 ", rng.randint(2, 8))]
         while len(keys) < nk and tries < nk * 20:
@@ -51,6 +66,7 @@ while time.time() < t_end:
            "AHA_ENGINE": rng.choice([None, None, "unit", "unit", "v2", "v1"]),
            "AHA_UNIT_POST": rng.choice([None, None, "regroup"]),
            "AHA_UNIT_WALKS": rng.choice([None, None, "2"]),
+           "AHA_UNIT_BASE_BITS": rng.choice([None, None, "23"]),
            "AHA_DIRECT": rng.choice([None, None, "0"])}
     for k, v in env.items():
         if v is None:
@@ -67,6 +83,8 @@ while time.time() < t_end:
             r = rng.random()
             if r < 0.4 and keys:
                 parts.append(rng.choice(keys))
+            elif big and r < 0.7:  # characters (not bytes) of the wide alphabet: hub + any
+                parts.append(rng.choice(hubs) + rng.choice(units))
             elif r < 0.45:
                 parts.append(b"\x00")
             else:

@@ -28,12 +28,6 @@
 #ifndef AHA_LAB_PROBE_INDEX
 #define AHA_LAB_PROBE_INDEX(i) (i)
 #endif
-#ifndef AHA_LAB_XG_GATHER_INDEX
-#define AHA_LAB_XG_GATHER_INDEX(i) (i)
-#endif
-#ifndef AHA_LAB_XG_SHAPE
-#define AHA_LAB_XG_SHAPE 1024, 1, 1536
-#endif
 
 namespace aha {
 
@@ -52,13 +46,7 @@ constexpr int kUWave = 64 * kURow;
 __device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t g, int64_t N) {
   uint4 v = make_uint4(0, 0, 0, 0);
   if (g >= 0 && g + 16 <= N) {
-#ifdef AHA_LAB_NT_TEXT
-    typedef uint32_t v4u_ __attribute__((ext_vector_type(4)));
-    const v4u_ t_ = __builtin_nontemporal_load(reinterpret_cast<const v4u_ *>(text + g));
-    v = make_uint4(t_.x, t_.y, t_.z, t_.w);
-#else
     v = *reinterpret_cast<const uint4 *>(text + g);
-#endif
   } else if (g >= 0 && g < N) {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // (rare: the text's last bytes; kept as a loop)
 #pragma unroll 1
@@ -370,11 +358,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             if (wfill + kp >= 64u) {
               const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (wbo + __umul24((uint32_t)lane, 12u)));
               const v3u r = {q[0], q[1], q[2]};
-#ifdef AHA_LAB_NT_EV
-              if (wout + 64u <= wcap) __builtin_nontemporal_store(r, reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3));
-#else
               if (wout + 64u <= wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
-#endif
               wout += 64u;
               if (ev && my >= 64u) {
                 uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + __umul24(my - 64u, 12u)));
@@ -904,17 +888,13 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
 // record is a memory request per record.  So a block of 1024 records stages its hits in LDS chunk by chunk -- the
 // place is the chunk's start in the block (an exclusive sum over the chunks' hit counts, LDS atomics) + the hits of
 // the chunk before the event - the hits of the chunk before the block -- and consecutive threads write consecutive hits.
-// One gather per event: uend[base of the END state] = its key, the key's length and the offset of its flattened
-// output chain (the second and later hits of an event -- rare -- read the chain).
+// One lookup per event: uend[base of the END state] = its key, the key's length and the offset of its flattened
+// output chain (the second and later hits of an event -- rare -- read the chain); the workgroups are persistent (two per
+// CU) and keep the entries they have fetched in an LDS cache (below), so most lookups are a ds_read.
 // CHARS: uend carries the key's length in characters, the record's second word the character count (see ku_traverse):
 // hits are char offsets, Hit(char_of_byte[start], char_of_byte[end - 1] + 1) (matcher.cr:34-39).
-#ifdef AHA_LAB_XG_PLAIN_LOADS
-#define AHA_XG_LOAD(p) (*(p))
-#else
-#define AHA_XG_LOAD(p) __builtin_nontemporal_load(p)  // the records are read once: they should not push uend lines out of L1 / L2
-#endif
-constexpr int kXgShape[3] = {AHA_LAB_XG_SHAPE};  // threads, records per thread, staged hits
-constexpr int kXgThreads = kXgShape[0], kXgPer = kXgShape[1], kXgBlock = kXgThreads * kXgPer, kXgStage = kXgShape[2];
+// (shape, gather and stores measured apart: profiles/r04_expansion_lab.txt -- 1024 threads x 1 record beat 256 x 4 by 20 %)
+constexpr int kXgThreads = 1024, kXgPer = 1, kXgBlock = kXgThreads * kXgPer, kXgStage = 1536;
 constexpr int kXgCacheBits = 11;
 template <bool CHARS>
 __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend, DevAut A, V2Args M) {
@@ -956,7 +936,8 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
 #pragma unroll
     for (int q = 0; q < kXgPer; q++) {
       const uint32_t i = q * kXgThreads + threadIdx.x;
-      nxt[q] = i < total ? AHA_XG_LOAD(reinterpret_cast<const v3u *>(src + (size_t)i * 3)) : v3u{0, 0, 0};
+      // (non-temporal: the records are read once, they should not push uend lines out of L1 / L2)
+      nxt[q] = i < total ? __builtin_nontemporal_load(reinterpret_cast<const v3u *>(src + (size_t)i * 3)) : v3u{0, 0, 0};
     }
     __syncthreads();
     uint32_t par = 0;
@@ -970,21 +951,13 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
         const uint32_t i = i0 + q * kXgThreads + threadIdx.x;
         live[q] = i < total;
         rec[q] = nxt[q];
-        nxt[q] = i + kXgBlock < total ? AHA_XG_LOAD(reinterpret_cast<const v3u *>(src + (size_t)(i + kXgBlock) * 3)) : v3u{0, 0, 0};
+        nxt[q] = i + kXgBlock < total ? __builtin_nontemporal_load(reinterpret_cast<const v3u *>(src + (size_t)(i + kXgBlock) * 3)) : v3u{0, 0, 0};
         const uint32_t b = rec[q].x & bmask, n = u_rec_n(rec[q].x, rec[q].z, bb);
         cs[q] = (b * 0x9E3779B1u) >> (32 - kXgCacheBits);
         const unsigned long long ce = s_cache[cs[q]];
-#ifdef AHA_LAB_XG_NO_CACHE
-        const bool cached = false;
-#else
         const bool cached = live[q] & n == 1u & (uint32_t)ce == b + 1u;
-#endif
-#ifdef AHA_LAB_XG_NO_GATHER
-        ue[q] = make_uint2(1u << 24 | (rec[q].x & 0xFFFFu), 0u);
-#else
         ue[q] = make_uint2((uint32_t)(ce >> 32), 0u);
-        if (live[q] && !cached) ue[q] = uend[AHA_LAB_XG_GATHER_INDEX(b)];
-#endif
+        if (live[q] && !cached) ue[q] = uend[b];
         keep[q] = live[q] & !cached & n == 1u;
         if (live[q]) atomicAdd(&s_tot[par][(rec[q].x >> bb) & 63u], n);
       }
@@ -1031,11 +1004,7 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
         for (uint32_t j = threadIdx.x; j < nh; j += kXgThreads) {
           const uint32_t l = s_hl[j];
           const uint64_t idx = s_base[l] + s_run[l] + (w0 + j - s_start[l]);
-#ifdef AHA_LAB_XG_NO_STORE
-          if (idx < M.cap && s_hk[j] == 0xFFFFFFF0u) {
-#else
           if (idx < M.cap) {
-#endif
             aha_hit hit;
             hit.start = (int32_t)s_hs[j];
             hit.end = (int32_t)s_he[j];
@@ -1106,9 +1075,6 @@ void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream) {
 void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, uint32_t workgroups, void *stream) {
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
   // persistent workgroups (two of 1024 threads fit a CU): each keeps its LDS cache of uend entries over its groups
-#ifdef AHA_LAB_XG_GRID
-  workgroups = AHA_LAB_XG_GRID;
-#endif
   const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_groups, workgroups)));
   if (M.chars)
     hipLaunchKernelGGL(ku_expand_groups<true>, grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);

@@ -747,19 +747,38 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
           const uint32_t ph = out16 ? (uint32_t)((first * 3) & 3u) : 0u;
           if (by_hit) {
             __syncthreads();
-            for (uint32_t h = h0 + lane; h < h0 + nh; h += 64) {
+            // the lane's hits of the window (lane, lane + 64, ...) in three sweeps -- all searches, all gathers, all LDS
+            // writes -- so that the window costs one LDS search depth and one gather latency, not one per hit
+            constexpr int kPer = (int)(kWaveStage / 64);
+            uint32_t at[kPer], en[kPer];
+            uint2 ce[kPer];
+            uint32_t kc[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+              const uint32_t h = h0 + (uint32_t)lane + 64u * (uint32_t)k;  // (beyond the window: searched, never loaded)
               uint32_t e = 0;
 #pragma unroll
               for (uint32_t step = 32; step; step >>= 1)
                 if (s_excl[e + step] <= h) e += step;
-              const uint32_t at = s_co[e] + (h - s_excl[e]);
-              const uint2 ce = A.chain[at];
-              const uint32_t end = s_end[e];
-              const uint32_t w = ph + (h - h0) * 3;
-              // Hit(idx-len+1, idx+1, value) ac.cr:271-273; chars: Hit(char_of_byte[start], char_of_byte[end-1]+1)
-              hbuf[w] = CHARS ? end - A.chain_kc[at] : end - ce.x;
-              hbuf[w + 1] = end;
-              hbuf[w + 2] = ce.y;
+              at[k] = s_co[e] + (h - s_excl[e]);
+              en[k] = s_end[e];
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+              const bool in = (uint32_t)lane + 64u * (uint32_t)k < nh;
+              ce[k] = in ? A.chain[at[k]] : make_uint2(0, 0);
+              kc[k] = (CHARS && in) ? A.chain_kc[at[k]] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+              const uint32_t j = (uint32_t)lane + 64u * (uint32_t)k;
+              if (j < nh) {
+                const uint32_t w = ph + j * 3;
+                // Hit(idx-len+1, idx+1, value) ac.cr:271-273; chars: Hit(char_of_byte[start], char_of_byte[end-1]+1)
+                hbuf[w] = CHARS ? en[k] - kc[k] : en[k] - ce[k].x;
+                hbuf[w + 1] = en[k];
+                hbuf[w + 2] = ce[k].y;
+              }
             }
           } else if (live && A.chain) {
             // fetch (ac.cr:265-278): own key, then the output chain -- from the flattened copy: consecutive loads

@@ -918,11 +918,7 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
     __syncthreads();
     const uint64_t c = g * 64 + lane;
     if (wv == 0) {
-      if (CHARS && c < M.n_chunks) {
-        const uint32_t d0 = M.chunk_doc0[c];
-        const uint64_t dchunk = M.doc_off[d0] / M.S;
-        s_adj[lane] = (uint32_t)(M.lead_base[c] - (M.lead_base[dchunk] + M.doc_lead_rank[d0]));
-      }
+      if (CHARS && c < M.n_chunks) s_adj[lane] = M.lead_cnt[c];  // (ku_chunk_adj has put the adjustment there)
       s_base[lane] = c < M.n_chunks ? M.hit_base[c] : 0ull;
       s_run[lane] = 0;
       s_tot[0][lane] = 0;
@@ -1019,6 +1015,18 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
   }
 }
 
+// CHARS: the characters between the start of the document that contains a chunk's start and the chunk, for every chunk: three
+// dependent loads that a persistent expansion workgroup would wait for at the head of every group.  Written over lead_cnt
+// (the scan has consumed it).
+__global__ __launch_bounds__(256) void ku_chunk_adj(V2Args M) {
+  if (M.cursor[1]) return;
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= M.n_chunks) return;
+  const uint32_t d0 = M.chunk_doc0[c];
+  const uint64_t dchunk = M.doc_off[d0] / M.S;
+  M.lead_cnt[c] = (uint32_t)(M.lead_base[c] - (M.lead_base[dchunk] + M.doc_lead_rank[d0]));
+}
+
 // doc_hit_off[d] = hits before the document's first event: the chunk's hit base + the hits of the chunk before the
 // document start, which the traversal noted at the boundary
 __global__ __launch_bounds__(256) void ku_doc_offsets(V2Args M) {
@@ -1076,10 +1084,12 @@ void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, uin
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
   // persistent workgroups (two of 1024 threads fit a CU): each keeps its LDS cache of uend entries over its groups
   const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_groups, workgroups)));
-  if (M.chars)
+  if (M.chars) {
+    hipLaunchKernelGGL(ku_chunk_adj, dim3((uint32_t)((M.n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M);
     hipLaunchKernelGGL(ku_expand_groups<true>, grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
-  else
+  } else {
     hipLaunchKernelGGL(ku_expand_groups<false>, grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
+  }
   if (M.doc_hit_off)
     hipLaunchKernelGGL(ku_doc_offsets, dim3((uint32_t)((M.n_docs + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M);
 }

@@ -220,10 +220,10 @@ int32_t upload_image(aha_ac *ac, const Image &img) {
   for (uint32_t k = 0; k < a.n_keys; k++) total += a.key_cnt[k];
   d.key_info = nullptr;
   d.chain = nullptr;
-  d.chain_kc = nullptr;
+  d.chain_chars = nullptr;
   std::vector<uint32_t> kinfo;
   if (a.n_keys && total < (1ull << 24)) {
-    std::vector<uint32_t> kc;
+    std::vector<uint2> kc;  // the same chains for char offsets: {characters of the key, key}
     std::vector<uint2> &ch = ac->chain_host;
     ch.clear();
     kinfo.resize(a.n_keys);
@@ -233,13 +233,13 @@ int32_t upload_image(aha_ac *ac, const Image &img) {
       kinfo[k] = (uint32_t)ch.size() | (std::min<uint32_t>(a.key_cnt[k], 255u) << 24);
       for (int32_t j = (int32_t)k; j >= 0; j = a.key_next[j]) {
         ch.push_back(uint2{a.key_len[j], (uint32_t)j});
-        kc.push_back(a.key_kc[j] + 1u);
+        kc.push_back(uint2{a.key_kc[j] + 1u, (uint32_t)j});
       }
     }
     ac->key_info = kinfo;
     if ((rc = upload(ac, kinfo, &d.key_info))) return rc;
     if ((rc = upload(ac, ch, &d.chain))) return rc;
-    if ((rc = upload(ac, kc, &d.chain_kc))) return rc;
+    if ((rc = upload(ac, kc, &d.chain_chars))) return rc;
   }
   if (img.compact) {
     const uint32_t *p = nullptr;

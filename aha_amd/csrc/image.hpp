@@ -22,7 +22,8 @@ struct DevAut {
   // id (k2d_count takes it from end_info / key_info with the one gather it makes anyway); chains need 24-bit offsets.
   const uint32_t *key_info;   // [K] chain_off[k] | min(key_cnt[k], 255) << 24 (wide format: gathered by the count pass)
   const uint2 *chain;         // {len, key}
-  const uint32_t *chain_kc;   // lead bytes in key[1..len) + 1, same index (char offsets)
+  const uint2 *chain_chars;   // {lead bytes in key[1..len) + 1 = the key's length in characters, key}, same index (char
+                              // offsets: one gather per hit like the byte offsets, not a second one for the length)
   uint32_t root;
   uint32_t n_slots;
   uint32_t max_len;

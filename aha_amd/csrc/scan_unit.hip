@@ -989,8 +989,8 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
                 s_hl[j] = (uint8_t)l;
               }
               if (++k >= n) break;
-              const uint2 ce = A.chain[co + k];
-              len = CHARS ? A.chain_kc[co + k] : ce.x;
+              const uint2 ce = (CHARS ? A.chain_chars : A.chain)[co + k];
+              len = ce.x;
               key = ce.y;
             }
           }

@@ -752,7 +752,6 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
             constexpr int kPer = (int)(kWaveStage / 64);
             uint32_t at[kPer], en[kPer];
             uint2 ce[kPer];
-            uint32_t kc[kPer];
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
               const uint32_t h = h0 + (uint32_t)lane + 64u * (uint32_t)k;  // (beyond the window: searched, never loaded)
@@ -766,8 +765,7 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
               const bool in = (uint32_t)lane + 64u * (uint32_t)k < nh;
-              ce[k] = in ? A.chain[at[k]] : make_uint2(0, 0);
-              kc[k] = (CHARS && in) ? A.chain_kc[at[k]] : 0u;
+              ce[k] = in ? (CHARS ? A.chain_chars : A.chain)[at[k]] : make_uint2(0, 0);
             }
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
@@ -775,7 +773,7 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
               if (j < nh) {
                 const uint32_t w = ph + j * 3;
                 // Hit(idx-len+1, idx+1, value) ac.cr:271-273; chars: Hit(char_of_byte[start], char_of_byte[end-1]+1)
-                hbuf[w] = CHARS ? en[k] - kc[k] : en[k] - ce[k].x;
+                hbuf[w] = en[k] - ce[k].x;
                 hbuf[w + 1] = en[k];
                 hbuf[w + 2] = ce[k].y;
               }
@@ -785,8 +783,8 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
             uint32_t w = ph + off * 3;
             const uint32_t co = rec.x;
             for (uint32_t j = 0; j < cnt; j++) {
-              const uint2 e = A.chain[co + j];
-              hbuf[w] = CHARS ? rec.y - A.chain_kc[co + j] : rec.y - e.x;
+              const uint2 e = (CHARS ? A.chain_chars : A.chain)[co + j];
+              hbuf[w] = rec.y - e.x;
               hbuf[w + 1] = rec.y;
               hbuf[w + 2] = e.y;
               w += 3;

@@ -4,7 +4,7 @@ import collections, csv, glob, json, os, re, shutil, sys
 tag, rnd = sys.argv[1], sys.argv[2]  # e.g. prof_b r01b
 src = os.path.join("gpurun_out", tag)
 note = ("rocprofv3 --pmc, separate passes with --kernel-trace only, over `python3 bench.py --steps 2 --warmup 1 "
-        "--no-cpu-baseline` (cfg3: 100k keys, 1 GiB); median over the FULL-SIZE launches of each kernel (largest grid). FETCH_SIZE/WRITE_SIZE raw units are KB; "
+        "--no-cpu-baseline` (cfg3: 100k keys, 1 GiB); median over the FULL-SIZE launches of each kernel (largest grid, at least half the longest duration). FETCH_SIZE/WRITE_SIZE raw units are KB; "
         "gfx950 FETCH_SIZE can under-report wide coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM) -- "
         "per-lane 16 B strided loads are uncalibrated, so raw values are quoted. SQ_* cycle counters are quad-cycles.")
 sys.path.insert(0, os.getcwd())
@@ -28,14 +28,22 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
     # the bench process launches a kernel at several sizes (the timed 1 GiB steps, the 64 MiB ranges of the end-to-end leg,
     # capacity probes): only the FULL-SIZE dispatches -- the largest grid of each kernel -- are averaged
     rows = [r for r in csv.DictReader(open(f)) if "aha::" in r["Kernel_Name"] and short(r["Kernel_Name"])]
+    # (a kernel with persistent workgroups has that grid at every size: of the largest-grid dispatches only those that ran
+    # at least half as long as the longest one)
     top = collections.defaultdict(int)
+    longest = collections.defaultdict(int)
+    dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     for r in rows:
         k = short(r["Kernel_Name"])
         top[k] = max(top[k], int(r["Grid_Size"]))
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         k = short(r["Kernel_Name"])
         if int(r["Grid_Size"]) == top[k]:
+            longest[k] = max(longest[k], dur(r))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        if int(r["Grid_Size"]) == top[k] and 2 * dur(r) >= longest[k]:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in agg.items():
         for c, v in cs.items():

@@ -204,6 +204,31 @@ int32_t upload(aha_ac *ac, const std::vector<T> &v, const T **out) {
   return AHA_OK;
 }
 
+// upload() for tables that appear after compile (the first match_longest call), possibly while other threads match on the
+// handle: the copy goes over a private non-blocking stream (no call of the library touches the NULL stream), the handle's
+// allocation list is touched under the pool mutex.
+template <class T>
+int32_t upload_late(aha_ac *ac, const std::vector<T> &v, const T **out) {
+  void *d = nullptr;
+  const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+  HIPCHK(ac, hipMalloc(&d, bytes));
+  {
+    std::lock_guard<std::mutex> lk(ac->pool_mu);
+    ac->dev_allocs.push_back(d);
+    ac->image_bytes += v.size() * sizeof(T);
+  }
+  if (!v.empty()) {
+    hipStream_t st = nullptr;
+    HIPCHK(ac, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipError_t e = hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    HIPCHK(ac, e);
+  }
+  *out = reinterpret_cast<const T *>(d);
+  return AHA_OK;
+}
+
 int32_t upload_image(aha_ac *ac, const Image &img) {
   const Automaton &a = ac->aut;
   DevAut &d = ac->dev;
@@ -630,11 +655,11 @@ int32_t ensure_stale(aha_ac *ac) {
         term[ac->state_base[s] >> 5] |= 1u << (ac->state_base[s] & 31);
         any_term = true;
       }
-    if (any_term && (ac->stale_rc = upload(ac, term, &ac->dev_longest.term_bits))) return;
+    if (any_term && (ac->stale_rc = upload_late(ac, term, &ac->dev_longest.term_bits))) return;
     if (ac->stale_states.empty()) return;
     std::vector<uint32_t> bits(((size_t)ac->n_slots + 31) / 32, 0u);
     for (uint32_t s : ac->stale_states) bits[ac->state_base[s] >> 5] |= 1u << (ac->state_base[s] & 31);
-    ac->stale_rc = upload(ac, bits, &ac->dev_longest.stale_bits);
+    ac->stale_rc = upload_late(ac, bits, &ac->dev_longest.stale_bits);
    } catch (...) {  // bad_alloc of the replay or of a bitmap: no exception crosses the C boundary
     ac->stale_rc = AHA_E_NOMEM;
    }

@@ -563,6 +563,9 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
 
   const bool prof = ac->profiling.load() && sc->ev_ready;
   HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
+  // device-resident offsets nobody has looked at yet: validated here, in front of the traversal; a bad verdict lands in
+  // cursor[1], where the traversal and every post pass look first (no read-back before the launch: -30 us per call)
+  if (M1.check_docs) launch_check_docs(M.doc_off, M.n_docs, N, nullptr, M.cursor + 1, s);
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[0], s));
   const uint64_t n_tiles = (M.n_chunks + kV2Threads - 1) / kV2Threads;
   DevAut post = ac->dev;
@@ -597,6 +600,15 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   HIPCHK(ac, hipGetLastError());
   HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(ac, hipStreamSynchronize(s));
+  if (sc->h_v2[1] >= 16) {  // the offsets are not what the call says (k_check_docs): nothing was indexed with them
+    if (sc->h_v2[1] & 1) {
+      tls_err = "doc offsets: need doc_offsets[0] = 0, ascending, doc_offsets[n_docs] = n_bytes";
+      return AHA_E_INVALID;
+    }
+    tls_err = aha_strerror(AHA_E_TOO_LONG);
+    return AHA_E_TOO_LONG;
+  }
+  M1.check_docs = 0;  // (looked at: a repeated pass or the two-pass engine need not look again)
   if (sc->h_v2[1] == 2) return 2;  // a chunk's event region overflowed: the caller repeats with full-size regions
   if (sc->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = sc->h_v2[2];
@@ -1189,13 +1201,14 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
   if (rc) return rc;
   if ((rc = ready_events(ac, sc))) return rc;
   *n_hits = 0;
-  if (!offsets_checked) {
+  auto check_now = [&]() -> int32_t {
     // the offsets live in HBM: one small kernel and an 4-byte read-back before anything indexes with them
-    if ((rc = v2_reserve(ac, sc, 9, 16 * 8))) return rc;
+    int32_t rc2;
+    if ((rc2 = v2_reserve(ac, sc, 9, 16 * 8))) return rc2;
     if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
     uint32_t *flag = (uint32_t *)sc->v2buf[9].p + 30;
     HIPCHK(ac, hipMemsetAsync(flag, 0, 4, s));
-    launch_check_docs(d_doc_offsets, n_docs, n_bytes, flag, s);
+    launch_check_docs(d_doc_offsets, n_docs, n_bytes, flag, nullptr, s);
     HIPCHK(ac, hipMemcpyAsync(sc->h_v2, flag, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ac, hipStreamSynchronize(s));
     const uint32_t bad = (uint32_t)sc->h_v2[0];
@@ -1207,7 +1220,13 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
       tls_err = aha_strerror(AHA_E_TOO_LONG);
       return AHA_E_TOO_LONG;
     }
-  }
+    return AHA_OK;
+  };
+  // The single-traversal pipelines validate on the device in front of their traversal (match_v2); every other path -- an
+  // empty batch, match_longest, the two-pass engine -- reads the verdict back first.
+  const bool defer_check = !offsets_checked && ac->v2_ok && !longest && n_bytes != 0;
+  if (!offsets_checked && !defer_check && (rc = check_now())) return rc;
+  M.check_docs = defer_check ? 1 : 0;
   if (n_bytes == 0) {
     if (d_doc_hit_offsets)
       HIPCHK(ac, hipMemsetAsync(d_doc_hit_offsets, 0, (n_docs + 1) * sizeof(uint64_t), s));
@@ -1306,6 +1325,7 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
     }
     *n_hits = 0;  // rc == 1: fall through to the two-pass engine
     repeats++;
+    if (M.check_docs && (rc = check_now())) return rc;  // (no single-traversal pass has looked at the offsets)
   }
   M.chunk = ac->chunk;
   // warm-up is Lmax-1 bytes per chunk: keep it a small fraction of the chunk

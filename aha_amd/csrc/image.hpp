@@ -51,6 +51,8 @@ struct MatchArgs {
   int32_t sep;               // 1: match(seq, sep) (ac.cr:321-340)
   uint32_t sep_block[8];     // bit c set <=> (c < sep.size && !sep[c])
   int32_t has_nul;           // match_longest, chunked form: the batch holds NUL bytes (the warm-ups look for them)
+  int32_t check_docs;        // host side: the device-resident doc offsets have not been validated yet -- the single-traversal
+                             // pipelines do it on the device, in front of the traversal, without a round trip to the host
   // scratch
   uint32_t *counts;          // [n_chunks] hits per chunk
   uint32_t *leads;           // [n_chunks] UTF-8 lead bytes per chunk (chars mode)
@@ -181,7 +183,8 @@ void launch_hits_unpack4_segs(const DevAut &A, const uint32_t *land, const uint6
                               const uint64_t *out_off, uint32_t n_segs, int chars, int32_t *hits, StreamFmt F, void *stream);
 
 // flag[0] |= 1: not the offsets of n_docs documents over n_bytes; |= 2: a document of 2^31 bytes or more
-void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_bytes, uint32_t *flag, void *stream);
+void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_bytes, uint32_t *flag, unsigned long long *abort_word,
+                       void *stream);
 
 // launchers (kernels.hip)
 void launch_count(const DevAut &A, const MatchArgs &M, void *stream);

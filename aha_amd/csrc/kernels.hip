@@ -781,8 +781,11 @@ void launch_hits_unpack4(const DevAut &A, const uint32_t *stream_words, uint64_t
 // -------------------------------------------------- device-resident doc offsets
 // The device entry point cannot read its doc offsets on the host: flag[0] |= 1 when they are not the offsets of
 // n_docs documents over exactly n_bytes (doc_off[0] = 0, ascending, doc_off[D] = n_bytes), |= 2 when a document
-// is 2^31 bytes or longer (Int32 offsets, src/aha/matcher.cr:3-5).
-__global__ __launch_bounds__(256) void k_check_docs(const uint64_t *doc_off, uint64_t D, uint64_t N, uint32_t *flag) {
+// is 2^31 bytes or longer (Int32 offsets, src/aha/matcher.cr:3-5).  abort_word (the single-traversal pipelines' cursor[1]): the
+// same verdict | 16 where the traversal and every post pass look before they index anything with the offsets -- the
+// call then needs no round trip to the host in front of the traversal (the host reads the word with the totals).
+__global__ __launch_bounds__(256) void k_check_docs(const uint64_t *doc_off, uint64_t D, uint64_t N, uint32_t *flag,
+                                                    unsigned long long *abort_word) {
   uint32_t bad = 0;
   for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d <= D; d += (uint64_t)gridDim.x * 256) {
     const uint64_t q = doc_off[d];
@@ -794,12 +797,14 @@ __global__ __launch_bounds__(256) void k_check_docs(const uint64_t *doc_off, uin
       else if (q1 - q >= 0x7FFFFFFFull) bad |= 2u;
     }
   }
-  if (bad) atomicOr(flag, bad);
+  if (bad && flag) atomicOr(flag, bad);
+  if (bad && abort_word) atomicOr(abort_word, (unsigned long long)(16u | bad));
 }
 
-void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_bytes, uint32_t *flag, void *stream) {
+void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_bytes, uint32_t *flag, unsigned long long *abort_word,
+                       void *stream) {
   const uint32_t g = (uint32_t)std::min<uint64_t>((n_docs + 256) / 256, 1024);
-  hipLaunchKernelGGL(k_check_docs, dim3(g), dim3(256), 0, (hipStream_t)stream, doc_off, n_docs, n_bytes, flag);
+  hipLaunchKernelGGL(k_check_docs, dim3(g), dim3(256), 0, (hipStream_t)stream, doc_off, n_docs, n_bytes, flag, abort_word);
 }
 
 // ---------------------------------------------------------------- launchers

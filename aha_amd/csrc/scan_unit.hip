@@ -81,6 +81,7 @@ __host__ __device__ inline size_t u_lds(uint32_t n_syms) {
 template <bool CHARS, int BB>
 __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (M.cursor[1] >= 16ull) return;  // the doc offsets are not what the call says (k_check_docs ran in front): index nothing
   // LDS: decode tables (16-byte aligned), the root's transitions (state words, unit.hpp: base | filter << BB | F1 | NFR | END), input rows
   uint32_t *tabw = reinterpret_cast<uint32_t *>(smem);
   uint32_t *rlw = tabw + kUTabWords;
@@ -460,6 +461,7 @@ struct UTrip {  // what a walk's trip has in flight
 template <bool CHARS>
 __global__ __launch_bounds__(kV2Threads) void ku2_traverse(UnitDev U, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (M.cursor[1] >= 16ull) return;  // (bad doc offsets: see ku_traverse)
   uint32_t *tabw = reinterpret_cast<uint32_t *>(smem);
   uint32_t *rlw = tabw + kUTabWords;
   const uint32_t n_root = (U.n_syms + 3u) & ~3u;

@@ -81,6 +81,9 @@ constexpr int kWaveIn2 = 64 * kInStride;
 template <bool COMPACT, bool CHARS, bool ALL_LDS>
 __global__ __launch_bounds__(kV2Threads, AHA_V2_WAVES_PER_SIMD) void k2_traverse(DevAut A, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // device-resident doc offsets are validated by a small kernel in front of this one (k_check_docs, capi.cpp match_v2): a bad
+  // verdict stands in cursor[1] and nothing is indexed with them
+  if (M.cursor[1] >= 16ull) return;
   using S_ = Slot<COMPACT>;
   using slot_t = typename S_::type;
   slot_t *lt = reinterpret_cast<slot_t *>(smem);

@@ -37,7 +37,7 @@ void launch_hits_unpack4_segs(const DevAut &, const uint32_t *, const uint64_t *
                               int, int32_t *, StreamFmt, void *) {
   no_gpu("launch_hits_unpack4_segs");
 }
-void launch_check_docs(const uint64_t *, uint64_t, uint64_t, uint32_t *, void *) { no_gpu("launch_check_docs"); }
+void launch_check_docs(const uint64_t *, uint64_t, uint64_t, uint32_t *, unsigned long long *, void *) { no_gpu("launch_check_docs"); }
 void launch_count(const DevAut &, const MatchArgs &, void *) { no_gpu("launch_count"); }
 void launch_scan_blocks(const MatchArgs &, uint64_t, void *) { no_gpu("launch_scan_blocks"); }
 void launch_docg(const MatchArgs &, void *) { no_gpu("launch_docg"); }

@@ -1173,6 +1173,19 @@ def test_device_entry_validates_its_offsets():
         with pytest.raises(AhaError) as e:
             ac.match_batch_device(t, torch.tensor(bad, dtype=torch.int64).cuda(), out)
         assert e.value.code == N.AHA_E_INVALID
+        # the verdict of a refused call does not outlive it, and nothing was written through the bad offsets
+        assert ac.match_batch_device(t, torch.tensor([0, 100, 256], dtype=torch.int64).cuda(), out) == 128
+    # a larger batch (the single-traversal pipelines validate on the device, in front of the traversal, without a read-back):
+    # offsets that point far outside the text must not be followed
+    big = torch.from_numpy(np.frombuffer(b"abab" * (1 << 18), dtype=np.uint8).copy()).cuda()
+    out2 = torch.zeros((1 << 19, 3), dtype=torch.int32, device="cuda")
+    good = torch.tensor([0, 1 << 19, 1 << 20], dtype=torch.int64).cuda()
+    assert ac.match_batch_device(big, good, out2) == 1 << 19
+    for bad in ([0, 1 << 40, 1 << 20], [0, (1 << 20) + 64, 1 << 20], [1 << 62, 1 << 19, 1 << 20]):
+        with pytest.raises(AhaError) as e:
+            ac.match_batch_device(big, torch.tensor(bad, dtype=torch.int64).cuda(), out2)
+        assert e.value.code == N.AHA_E_INVALID
+    assert ac.match_batch_device(big, good, out2) == 1 << 19
 
 
 def test_sequence_longer_than_int32_is_rejected():

@@ -211,7 +211,9 @@ int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *do
  * hipStream_t (NULL = default stream).  Blocks until the hits are final.
  * On AHA_E_CAPACITY the first `cap` hits and all offsets are still valid.
  * d_doc_offsets must hold n_docs + 1 ascending offsets with [0] = 0 and [n_docs] = n_bytes, every document shorter
- * than 2^31 bytes: checked on the device before anything is indexed with them (AHA_E_INVALID / AHA_E_TOO_LONG). */
+ * than 2^31 bytes: checked on the device before anything is indexed with them (AHA_E_INVALID / AHA_E_TOO_LONG) -- by a
+ * small kernel in front of the traversal whose verdict every later kernel of the call looks at first, so a valid call
+ * pays no read-back for it (match_longest and the two-pass engine read the verdict back before they start). */
 int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
                                   const uint64_t *d_doc_offsets, uint64_t n_docs,
                                   uint64_t n_bytes, const aha_match_params *params,

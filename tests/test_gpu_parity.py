@@ -449,7 +449,8 @@ def test_config5_at_full_key_count(engine):
 
 def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
     """A device corpus that is not 16-byte aligned (a slice of a larger buffer) must not fall to the two-pass engine:
-    same hits, same engine, at least 80 % of the aligned rate (one device-to-device copy in front of the match)."""
+    same hits, same engine, at least 70 % of the aligned rate (one device-to-device copy in front of the match: ~0.18 ms
+    for these 256 MiB against ~0.7 ms for the match)."""
     if engine not in ("v2", "u"):
         pytest.skip("on the byte-level and on the character-level engine")
     import torch
@@ -480,7 +481,7 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
         assert g.last_timing()["engine"] == (4 if engine in ("u", "u2", "u23") else 2)
         res[shift] = (best, out[:n].cpu().numpy().tobytes())
     assert res[0][1] == res[1][1]
-    assert res[0][0] / res[1][0] >= 0.8, (res[0][0], res[1][0])
+    assert res[0][0] / res[1][0] >= 0.7, (res[0][0], res[1][0])
     g.release_scratch()
     assert g.match_batch_device(big[1:1 + corpus.size], dd, out) == n  # scratch grows back
 

@@ -579,7 +579,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   }
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[1], s));
   if (direct) {
-    if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));
+    // (no event between the traversal and the post passes of this pipeline: a record costs ~5 us of stream time, and ev[1]
+    // stands for ev[2] in the timing below)
     if (unit && ac->unit_fused) {  // the traversal counted the hits: bases, then the expansion straight from the wave-ordered events
       v2_launch_hit_scan(M, s);
       if (M.chars) v2_launch_lead_scan(M, s);  // characters before every chunk (the traversal counted them per chunk)
@@ -621,8 +622,12 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     t.n_kernels = 9;
     (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
     (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], sc->ev[1]);
-    (void)hipEventElapsedTime(&t.ms_scan, sc->ev[1], sc->ev[2]);
-    (void)hipEventElapsedTime(&t.ms_aux, sc->ev[2], sc->ev[3]);
+    if (direct) {
+      (void)hipEventElapsedTime(&t.ms_aux, sc->ev[1], sc->ev[3]);
+    } else {
+      (void)hipEventElapsedTime(&t.ms_scan, sc->ev[1], sc->ev[2]);
+      (void)hipEventElapsedTime(&t.ms_aux, sc->ev[2], sc->ev[3]);
+    }
     (void)hipEventElapsedTime(&t.ms_write, sc->ev[3], sc->ev[4]);
     t.n_chunks = M.n_chunks;
     t.n_hits = *n_hits;

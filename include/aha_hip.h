@@ -141,7 +141,7 @@ typedef struct {
   uint32_t n_kernels;
   float ms_total;           /* first launch -> hits and offsets final in HBM */
   float ms_count;           /* engine 2: the traversal kernel; engine 1: traversal pass 1 */
-  float ms_scan;            /* scans of per-chunk counts */
+  float ms_scan;            /* scans of per-chunk counts (slab pipeline; the region pipelines have them in ms_aux: no event in between) */
   float ms_write;           /* engine 2: chain expansion + doc offsets; engine 1: traversal pass 2 */
   float ms_aux;             /* engine 2: hits per chunk + scan (regions) or event sort (slabs); engine 1: char-offset prefix pass */
   uint64_t n_chunks;

@@ -703,6 +703,7 @@ template <uint32_t kWaveStage, bool CHARS>
 __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
   __shared__ __attribute__((aligned(16))) uint32_t hbuf[kWaveStage * 3 + 4];
   __shared__ uint32_t s_excl[64], s_co[64], s_end[64];
+  __shared__ __attribute__((aligned(16))) uint8_t s_mark[kWaveStage];  // by hit index: 1 where an event's first hit stands
   const bool out16 = (reinterpret_cast<uintptr_t>(M.out) & 15u) == 0;
   if (M.cursor[1]) return;
   const int lane = threadIdx.x;
@@ -757,19 +758,29 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
           const uint32_t ph = out16 ? (uint32_t)((first * 3) & 3u) : 0u;
           if (by_hit) {
             __syncthreads();
-            // the lane's hits of the window (lane, lane + 64, ...) in three sweeps -- all searches, all gathers, all LDS
-            // writes -- so that the window costs one LDS search depth and one gather latency, not one per hit
+            // the lane's hits of the window (lane, lane + 64, ...) in three sweeps -- all event lookups, all gathers, all LDS
+            // writes -- so that the window costs one LDS depth and one gather latency, not one per hit.
+            // Which event a hit belongs to: the events that start inside the window mark their first hit in s_mark; a hit's event
+            // is then (events that start before its sweep) + (marks at or below its place in the sweep: a ballot and a count)
+            // - 1 -- two dependent LDS reads per hit instead of the seven of a binary search over the events' hit counts.
             constexpr int kPer = (int)(kWaveStage / 64);
             uint32_t at[kPer], en[kPer];
             uint2 ce[kPer];
 #pragma unroll
-            for (int k = 0; k < kPer; k++) {
-              const uint32_t h = h0 + (uint32_t)lane + 64u * (uint32_t)k;  // (beyond the window: searched, never loaded)
-              uint32_t e = 0;
+            for (int k = 0; k < kPer / 4; k++) reinterpret_cast<uint32_t *>(s_mark)[lane + 64 * k] = 0u;
+            __syncthreads();
+            if (live && off - h0 < nh) s_mark[off - h0] = 1;  // (off < h0 wraps around to a large number)
+            uint32_t before = (uint32_t)__popcll(__ballot(live && off < h0));
+            __syncthreads();
 #pragma unroll
-              for (uint32_t step = 32; step; step >>= 1)
-                if (s_excl[e + step] <= h) e += step;
-              at[k] = s_co[e] + (h - s_excl[e]);
+            for (int k = 0; k < kPer; k++) {
+              const uint32_t j = (uint32_t)lane + 64u * (uint32_t)k;
+              const bool mk = j < nh && s_mark[j] != 0;
+              const uint64_t marks = __ballot(mk);
+              const uint32_t e = min(before + __builtin_amdgcn_mbcnt_hi((uint32_t)(marks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)marks, 0u)) +
+                                         (mk ? 1u : 0u) - 1u, 63u);  // (beyond the window: some event, never loaded)
+              before += (uint32_t)__popcll(marks);
+              at[k] = s_co[e] + (h0 + j - s_excl[e]);
               en[k] = s_end[e];
             }
 #pragma unroll

@@ -1423,9 +1423,11 @@ bool host_streams(Scratch *sc) {
 // The host entry: upload, match and download pipelined over ranges of whole documents.  d_keep != null: the hits stay
 // on the device, in the caller's buffer d_keep[0 .. cap) (aha_ac_match_batch_keep: what the shards of a group call), and
 // only the per-document offsets come back to the host.
+// (d_keep AND out: both -- the hits stay on the device and the ranges' hits also go to out[0 .. host_cap) while they fit;
+// what a shard of a group calls when its place in the caller's buffer is known before it starts)
 static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
                                 const aha_match_params *params, aha_hit *out, aha_hit *d_keep, uint64_t cap,
-                                uint64_t *doc_hit_offsets, uint64_t *n_hits);
+                                uint64_t *doc_hit_offsets, uint64_t *n_hits, uint64_t host_cap = ~0ull);
 
 int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets,
                            uint64_t n_docs, const aha_match_params *params, aha_hit *out,
@@ -1443,9 +1445,20 @@ int32_t aha_ac_match_batch_keep(aha_ac *ac, const uint8_t *corpus, const uint64_
                           n_hits);
 }
 
+// library-internal (group.cpp): aha_ac_match_batch_keep that also copies the hits to host memory, range by range, as long as
+// they fit host_cap hits -- the copy never makes the call fail (a group reports AHA_E_CAPACITY from its total)
+int32_t aha_internal_match_batch_keep_copy(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                                           const aha_match_params *params, aha_hit *d_hits, uint64_t cap, aha_hit *host_out,
+                                           uint64_t host_cap, uint64_t *doc_hit_offsets, uint64_t *n_hits) {
+  if (cap && !d_hits) return AHA_E_INVALID;
+  static aha_hit none;
+  return match_batch_host(ac, corpus, doc_offsets, n_docs, params, host_out, d_hits ? d_hits : &none, cap, doc_hit_offsets,
+                          n_hits, host_out ? host_cap : 0);
+}
+
 static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
                                 const aha_match_params *params, aha_hit *out, aha_hit *d_keep, uint64_t cap,
-                                uint64_t *doc_hit_offsets, uint64_t *n_hits) {
+                                uint64_t *doc_hit_offsets, uint64_t *n_hits, uint64_t host_cap) {
   if (!ac || !doc_offsets || !n_hits) return AHA_E_INVALID;
   if (ac->device < 0) {
     tls_err = aha_strerror(AHA_E_NO_DEVICE);
@@ -1545,8 +1558,8 @@ static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_
         if (P.failed) return;
       }
       const uint64_t D = bounds[k + 1] - bounds[k];
-      if (got[k] && !d_keep && hipMemcpyAsync(out + base[k], d_out + base[k], got[k] * sizeof(aha_hit), hipMemcpyDeviceToHost,
-                                              s_down) != hipSuccess)
+      if (got[k] && out && (!d_keep || base[k] + got[k] <= host_cap) &&
+          hipMemcpyAsync(out + base[k], d_out + base[k], got[k] * sizeof(aha_hit), hipMemcpyDeviceToHost, s_down) != hipSuccess)
         return P.fail(AHA_E_HIP, "download of the hits failed");
       if (doc_hit_offsets) {
         try {

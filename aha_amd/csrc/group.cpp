@@ -28,6 +28,12 @@
 
 #include "../../include/aha_hip.h"
 
+// library-internal (capi.cpp): aha_ac_match_batch_keep that also copies the ranges' hits to host memory while they fit
+extern "C" int32_t aha_internal_match_batch_keep_copy(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets,
+                                                      uint64_t n_docs, const aha_match_params *params, aha_hit *d_hits,
+                                                      uint64_t cap, aha_hit *host_out, uint64_t host_cap,
+                                                      uint64_t *doc_hit_offsets, uint64_t *n_hits);
+
 namespace {
 
 // the few RCCL entry points used (rccl.h declares them; resolved at run time)
@@ -100,6 +106,8 @@ struct Shard {
   std::vector<uint64_t> h_dho;
   int32_t rc = AHA_OK;
   double ms_match = 0;
+  aha_hit *host_out = nullptr;  // shards one after the other on a shared device: this shard's place in the caller's buffer,
+  uint64_t host_cap = 0;        // and the room there
 };
 
 double ms_since(std::chrono::steady_clock::time_point t0) {
@@ -223,6 +231,18 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   T.struct_size = sizeof(T);
   T.n_devices = (uint32_t)n;
 
+  enum Transport { kCopies = 0, kRccl = 1, kSelfRccl = 2 };
+  const Transport via = (g->distinct && n > 1) ? kRccl : (g->self_rccl ? kSelfRccl : kCopies);
+  // What travels: the 4-byte stream of include/aha_hip.h (aha_ac_hits_pack4_device) when the key ids fit 20 bits,
+  // else the 12-byte triples.  Same code for every transport, so the packed path runs on a one-GPU box too.
+  aha_ac_info_t info{};
+  info.struct_size = sizeof(info);
+  (void)aha_ac_info(g->shards[0].ac, &info);
+  // (the 4-byte stream's own condition, aha_ac_hits_pack4_device: ids beyond 2^20 need the length in the word)
+  uint32_t sf_step = 0, sf_len = 0;
+  const bool fits = aha_ac_stream_format(g->shards[0].ac, &sf_step, &sf_len) == AHA_OK && (sf_len != 0 || info.n_keys <= (1u << 20));
+  const bool words = (n > 1 || via == kSelfRccl) && fits;
+
   // ---- every shard: upload its range, match on its device (one host thread per shard: the calls block)
   const auto t_all = std::chrono::steady_clock::now();
   std::vector<std::thread> th;
@@ -254,8 +274,10 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     const auto t0 = std::chrono::steady_clock::now();
     for (int attempt = 0; attempt < 2; attempt++) {
       uint64_t nh = 0;
-      s.rc = aha_ac_match_batch_keep(s.ac, corpus + b0, rel.data(), D, params, (aha_hit *)s.out.p,
-                                     s.out.bytes / sizeof(aha_hit), s.h_dho.data(), &nh);
+      // (s.host_out: shards that run one after the other know their place in the caller's buffer -- the hits of a range
+      // go there from inside the shard's own pipeline, beside the upload of the next range)
+      s.rc = aha_internal_match_batch_keep_copy(s.ac, corpus + b0, rel.data(), D, params, (aha_hit *)s.out.p,
+                                                s.out.bytes / sizeof(aha_hit), s.host_out, s.host_cap, s.h_dho.data(), &nh);
       s.n_hits = nh;
       if (s.rc != AHA_E_CAPACITY) break;
       if (!s.out.reserve(nh * sizeof(aha_hit))) {  // the call told the exact count: once more with room
@@ -265,7 +287,21 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
       }
     }
     s.ms_match = ms_since(t0);
-    if (s.rc != AHA_OK) s.err = aha_last_error(s.ac);  // the text is the calling thread's: take it along
+    if (s.rc != AHA_OK) {
+      s.err = aha_last_error(s.ac);  // the text is the calling thread's: take it along
+      return;
+    }
+    if (words) {  // the shard's exchange stream, launched behind its match (it does not wait for the other shards)
+      const uint64_t capw = 2 * s.n_hits + (s.n_hits + 1023) / 1024 + 16;
+      if (!s.pk.reserve(capw * 4) || !s.nw.reserve(8)) {
+        s.rc = AHA_E_HIP;
+        s.err = "hipMalloc failed for the packed stream";
+        return;
+      }
+      s.rc = aha_ac_hits_pack4_device(s.ac, (const aha_hit *)s.out.p, s.n_hits, (uint32_t *)s.pk.p, capw, (uint64_t *)s.nw.p,
+                                      s.stream);
+      if (s.rc != AHA_OK) s.err = std::string("pack: ") + aha_last_error(s.ac);
+    }
   };
   for (size_t r = 0; r < n; r++) {
     Shard &s = g->shards[r];
@@ -274,21 +310,74 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     s.rc = AHA_E_NOMEM;
     s.err = "worker thread not started";
   }
-  for (size_t r = 0; r < n; r++) {
+  // the caller's copy of a shard's hits (a private stream per shard, a thread per copy: the source is pageable memory's peer)
+  std::vector<std::thread> dl;
+  std::vector<int> dl_rc(n, 0);
+  std::vector<char> dl_started(n, 0);
+  struct JoinAll {
+    std::vector<std::thread> &t;
+    ~JoinAll() {
+      for (auto &x : t)
+        if (x.joinable()) x.join();
+    }
+  } join_dl{dl};
+  auto t_d = std::chrono::steady_clock::now();
+  auto start_download = [&](size_t r, uint64_t at) {
+    if (!out || !g->shards[r].n_hits) return;
+    if (dl.empty()) t_d = std::chrono::steady_clock::now();
+    dl_started[r] = 1;
     try {
-      th.emplace_back([&, r]() {
-        try {
-          work(r);
-        } catch (...) {  // bad_alloc of a host vector: no exception crosses the C boundary (or a thread's top frame)
-          g->shards[r].rc = AHA_E_NOMEM;
-          g->shards[r].err = "out of host memory";
-        }
+      dl.emplace_back([&, r, at]() {
+        Shard &s = g->shards[r];
+        if (hipSetDevice(s.device) != hipSuccess ||
+            (!s.dstream && hipStreamCreateWithFlags(&s.dstream, hipStreamNonBlocking) != hipSuccess) ||
+            hipMemcpyAsync(out + at, s.out.p, s.n_hits * sizeof(aha_hit), hipMemcpyDeviceToHost, s.dstream) != hipSuccess ||
+            hipStreamSynchronize(s.dstream) != hipSuccess)
+          dl_rc[r] = 1;
       });
     } catch (...) {
-      break;  // thread creation failed: the shards started so far are joined below, the rest keep AHA_E_NOMEM
+      dl_rc[r] = 1;
+    }
+  };
+  if (g->distinct || n == 1) {
+    for (size_t r = 0; r < n; r++) {
+      try {
+        th.emplace_back([&, r]() {
+          try {
+            work(r);
+          } catch (...) {  // bad_alloc of a host vector: no exception crosses the C boundary (or a thread's top frame)
+            g->shards[r].rc = AHA_E_NOMEM;
+            g->shards[r].err = "out of host memory";
+          }
+        });
+      } catch (...) {
+        break;  // thread creation failed: the shards started so far are joined below, the rest keep AHA_E_NOMEM
+      }
+    }
+    for (auto &t : th) t.join();
+  } else {
+    // Shards that share a device share its PCIe link: side by side they would only take turns on it, and every shard's
+    // place in the caller's buffer would be known when all of them have counted -- the hits' way back would follow the whole
+    // match phase.  One after the other, a shard's place is known when it is done, and its hits go to the host beside the
+    // next shard's upload (the link is full duplex), as in the single handle's pipeline.
+    uint64_t at = 0;
+    for (size_t r = 0; r < n; r++) {
+      Shard &s = g->shards[r];
+      s.host_out = (out && at < cap) ? out + at : nullptr;
+      s.host_cap = s.host_out ? cap - at : 0;
+      try {
+        work(r);
+      } catch (...) {
+        s.rc = AHA_E_NOMEM;
+        s.err = "out of host memory";
+      }
+      s.host_out = nullptr;
+      if (s.rc != AHA_OK) break;
+      // (a shard whose hits did not all fit the rest of the caller's buffer: AHA_E_CAPACITY below, nothing is written beyond cap)
+      dl_started[r] = 1;
+      at += s.n_hits;
     }
   }
-  for (auto &t : th) t.join();
   T.ms_match = (float)ms_since(t_all);
   uint64_t total = 0;
   std::vector<uint64_t> base(n + 1, 0);
@@ -313,33 +402,10 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
   if (total > cap) return fail(AHA_E_CAPACITY, "output buffer too small");
 
   // ---- the caller's copy: every device sends ITS hits to the host over its own PCIe link (a private stream per shard),
-  // beside the exchange between the devices -- not one device the whole gathered stream behind it
-  const auto t_d = std::chrono::steady_clock::now();
-  std::vector<std::thread> dl;
-  std::vector<int> dl_rc(n, 0);
-  struct JoinAll {
-    std::vector<std::thread> &t;
-    ~JoinAll() {
-      for (auto &x : t)
-        if (x.joinable()) x.join();
-    }
-  } join_dl{dl};
-  if (out)
-    for (size_t r = 0; r < n; r++) {
-      if (!g->shards[r].n_hits) continue;
-      try {
-        dl.emplace_back([&, r]() {
-          Shard &s = g->shards[r];
-          if (hipSetDevice(s.device) != hipSuccess ||
-              (!s.dstream && hipStreamCreateWithFlags(&s.dstream, hipStreamNonBlocking) != hipSuccess) ||
-              hipMemcpyAsync(out + base[r], s.out.p, s.n_hits * sizeof(aha_hit), hipMemcpyDeviceToHost, s.dstream) != hipSuccess ||
-              hipStreamSynchronize(s.dstream) != hipSuccess)
-            dl_rc[r] = 1;
-        });
-      } catch (...) {
-        dl_rc[r] = 1;
-      }
-    }
+  // beside the exchange between the devices -- not one device the whole gathered stream behind it.  (Shards on one device:
+  // started above, behind each shard's match.)
+  for (size_t r = 0; r < n; r++)
+    if (!dl_started[r]) start_download(r, base[r]);
 
   // ---- all-gatherv of the hit buffers: every device gets the whole ordered stream
   const auto t_x = std::chrono::steady_clock::now();
@@ -348,29 +414,9 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     if (hipSetDevice(s.device) != hipSuccess || !s.all.reserve(std::max<uint64_t>(total, 1) * sizeof(aha_hit)))
       return fail(AHA_E_HIP, "hipMalloc failed for the gathered hits");
   }
-  enum Transport { kCopies = 0, kRccl = 1, kSelfRccl = 2 };
-  const Transport via = (g->distinct && n > 1) ? kRccl : (g->self_rccl ? kSelfRccl : kCopies);
-  // What travels: the 4-byte stream of include/aha_hip.h (aha_ac_hits_pack4_device) when the key ids fit 20 bits,
-  // else the 12-byte triples.  Same code for every transport, so the packed path runs on a one-GPU box too.
-  aha_ac_info_t info{};
-  info.struct_size = sizeof(info);
-  (void)aha_ac_info(g->shards[0].ac, &info);
-  // (the 4-byte stream's own condition, aha_ac_hits_pack4_device: ids beyond 2^20 need the length in the word)
-  uint32_t sf_step = 0, sf_len = 0;
-  const bool fits = aha_ac_stream_format(g->shards[0].ac, &sf_step, &sf_len) == AHA_OK && (sf_len != 0 || info.n_keys <= (1u << 20));
-  const bool words = (n > 1 || via == kSelfRccl) && fits;
   const int chars = (params && params->char_offsets) ? 1 : 0;
   std::vector<uint64_t> ebase(n + 1, 0);  // in 32-bit elements
-  if (words) {
-    for (size_t r = 0; r < n; r++) {
-      Shard &s = g->shards[r];
-      const uint64_t capw = 2 * s.n_hits + (s.n_hits + 1023) / 1024 + 16;
-      if (hipSetDevice(s.device) != hipSuccess || !s.pk.reserve(capw * 4) || !s.nw.reserve(8))
-        return fail(AHA_E_HIP, "hipMalloc failed for the packed stream");
-      int32_t rc = aha_ac_hits_pack4_device(s.ac, (const aha_hit *)s.out.p, s.n_hits, (uint32_t *)s.pk.p, capw,
-                                            (uint64_t *)s.nw.p, s.stream);
-      if (rc != AHA_OK) return fail(rc, std::string("pack: ") + aha_last_error(s.ac));
-    }
+  if (words) {  // (every shard has packed its hits behind its match: work() above)
     for (size_t r = 0; r < n; r++) {
       Shard &s = g->shards[r];
       if (hipSetDevice(s.device) != hipSuccess ||

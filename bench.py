@@ -497,8 +497,9 @@ def main():
                       "note": "host_entry = aha_ac_match_batch on pageable host buffers (upload, match and download "
                               "pipelined over document ranges); with_download = device-resident match + D2H of the "
                               "hits; pcie_h2d = one blocking upload of the same corpus; group_host_entry = aha_group_match_batch over "
-                              "three shards on this one device (upload and match pipelined per shard, hits gathered on the "
-                              "device and downloaded); best of 3; never `value`"}
+                              "three shards on this one device (shards that share a device run one after the other: upload, "
+                              "match and the copy of each shard's hits to its place in the caller's buffer pipelined per shard; "
+                              "the gathered list is also built on the device); best of 3; never `value`"}
         log(f"end to end: {end_to_end}")
 
     # ---- parity gate: no throughput figure without a bit-exact comparison on this run's hits.

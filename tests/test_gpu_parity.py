@@ -1046,6 +1046,40 @@ def test_group_of_shards_on_one_device(engine, transport, monkeypatch):
         assert np.array_equal(gd, od) and gh.tobytes() == oh.tobytes()
 
 
+def test_group_shards_in_turn_copy_their_hits_from_inside_their_pipelines(engine):
+    """Shards that share a device run one after the other and copy the hits of every ~64 MiB range to their place in the
+    caller's buffer from inside their own pipeline (group.cpp): two shards of two ranges each against the single handle,
+    with a buffer that fits exactly, and with one that is a hit short -- AHA_E_CAPACITY, the count, nothing beyond cap."""
+    if engine != "auto":
+        pytest.skip("once, on the library's own choice")
+    import ctypes as C
+    from aha_amd import ACGroup
+
+    blob, offs, nf = synth.keys(3, K=20_000)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=200 << 20, doc_bytes=1 << 20)
+    D = doc.size - 1
+    doc_u64 = doc.astype(np.uint64)
+    one = AC.compile_packed(blob, offs)
+    want, want_dho = one.match_batch(corpus, doc, cap=corpus.size // 8)
+    n = len(want)
+    grp = ACGroup.compile_packed(blob, offs, [0, 0])
+    hit_t = np.dtype([("start", "<i4"), ("end", "<i4"), ("value", "<i4")])
+    out = np.full(n + 8, -7, dtype=np.int32).repeat(3).view(hit_t)  # guard hits behind the capacity
+    dho = np.zeros(D + 1, dtype=np.uint64)
+    got = C.c_uint64(0)
+    rc = N.lib().aha_group_match_batch(grp._h, corpus.ctypes.data, doc_u64.ctypes.data, D, None, out.ctypes.data, n,
+                                       dho.ctypes.data, C.byref(got))
+    assert rc == 0 and got.value == n
+    assert out[:n].tobytes() == np.asarray(want).tobytes() and np.array_equal(dho, np.asarray(want_dho, dtype=np.uint64))
+    assert (out[n:]["start"] == -7).all()
+    assert grp.last_timing()["n_devices"] == 2
+    out2 = np.full(n + 8, -7, dtype=np.int32).repeat(3).view(hit_t)
+    rc = N.lib().aha_group_match_batch(grp._h, corpus.ctypes.data, doc_u64.ctypes.data, D, None, out2.ctypes.data, n - 1,
+                                       dho.ctypes.data, C.byref(got))
+    assert rc == N.AHA_E_CAPACITY and got.value == n
+    assert (out2[n - 1:]["start"] == -7).all()  # nothing was written at or beyond cap
+
+
 def test_concurrent_calls_on_one_handle():
     """The handle is immutable after compile; concurrent #match calls must be safe (SURVEY.md 8 b, threading)."""
     import threading

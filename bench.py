@@ -423,6 +423,8 @@ def main():
         "whole_path_frac": round((n_bytes + 12 * n_hits + 16 * (D + 1) + A) / (avg["ms_total"] * 1e-3) / 1e9
                                  / HBM_PEAK_GBS, 4),
         "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
+        # SURVEY.md section 8 d: "also report against the 6.29 TB/s measured-copy ceiling" (MI355X_MICROARCH.md: float4 copy)
+        "frac_of_measured_copy": round(achieved / 6290.0, 4),
     }
 
     # ---- end to end, outside the timed region (SURVEY.md section 8 d: "incl. PCIe upload and incl. D2H of hits as

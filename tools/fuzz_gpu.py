@@ -9,7 +9,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np
 import pyoracle as orc
-from aha_amd import AC
+from aha_amd import AC, ACGroup
 from pymodel import ModelAC
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -17,7 +17,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
 ALPHABETS = [b"ab", b"abc", b"abcd", b"ab\xe4\xb8\x80", b"abcdefgh", b"xyz\xd0\xb0\xd1\x8f\xe4\xb8\xad\xe5\x9b\xbd",
              bytes(range(0x61, 0x7b)), bytes(range(1, 256))]
-n_cases = n_hits = n_long = 0
+n_cases = n_hits = n_long = n_group = 0
 seed = seed0
 while time.time() < t_end:
     rng = random.Random(seed)
@@ -76,6 +76,13 @@ while time.time() < t_end:
     wide = rng.random() < 0.25
     ac = AC.compile(keys, force_wide=wide)
     o = orc.AC.compile(keys)
+    grp, n_shards = None, 0
+    if not wide and rng.random() < 0.3:  # (the group compiles with the library's own slot format)
+        n_shards = rng.choice([2, 3, 4])
+        os.environ["AHA_GROUP_RCCL"] = rng.choice(["", "self"])
+        if not os.environ["AHA_GROUP_RCCL"]:
+            del os.environ["AHA_GROUP_RCCL"]
+        grp = ACGroup.compile(keys, [0] * n_shards)
     for _ in range(rng.randint(1, 3)):
         n = rng.choice([0, 1, 17, 1000, 20000, 300000])
         parts = []
@@ -105,6 +112,19 @@ while time.time() < t_end:
             sys.exit(1)
         n_cases += 1
         n_hits += len(gh)
+        if grp is not None and text.size <= 300000:
+            # the group API over shards on this one device: partition, shards in turn through the pipelined host entry, the
+            # 4-byte exchange stream (or triples), the rebuild -- the caller's copy and every shard's gathered copy
+            gg, gdo = grp.match_batch(text, doc, chars=chars)
+            ok = len(gg) == len(oh) and np.asarray(gg).tobytes() == np.asarray(gh).tobytes() and \
+                np.array_equal(np.asarray(gdo, dtype=np.uint64), np.asarray(od, dtype=np.uint64))
+            for shard in range(n_shards):
+                ok = ok and grp.download_shard(shard).tobytes() == np.asarray(gh).tobytes()
+            if not ok:
+                print("GROUP MISMATCH seed", seed, "keys", len(keys), "env", env, "shards", n_shards, "n", text.size,
+                      "docs", doc.size - 1, "chars", chars, flush=True)
+                sys.exit(1)
+            n_group += 1
         if text.size <= 20000 and len(keys) <= 2000 and rng.random() < 0.5:
             # match_longest against the oracle (Cedar's stale END flags included) and against the independent restatement
             # (tests/pymodel.py) given the oracle's stale paths; first document of the batch
@@ -122,4 +142,4 @@ while time.time() < t_end:
     seed += 1
     if seed % 5 == 0:
         print(f"[fuzz] {seed - seed0} automata, {n_cases} batches, {n_hits} hits ok", flush=True)
-print(f"fuzz ok: {n_long} match_longest documents, {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")
+print(f"fuzz ok: {n_group} group batches, {n_long} match_longest documents, {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")

@@ -428,6 +428,11 @@ class AC:
         return {f: getattr(t, f) for f, _ in t._fields_ if f != "struct_size"}
 
 
+# Aha::ACBig = ACX(Int64) (src/aha/ac.cr:9): node ids of 64 bits, the same Hit with an Int32 value (ac.cr:273) -- the
+# library's numbering has no such limit below 2^31 keys, so one class answers for both names.
+ACBig = AC
+
+
 class DeviceBuffer:
     """HBM obtained through the C ABI (aha_buffer_alloc): what a caller without a GPU framework uses."""
 

@@ -391,6 +391,11 @@ module Aha
     end
   end
 
+  # `Aha::ACBig = ACX(Int64)` (src/aha/ac.cr:9) differs from `Aha::AC` only in the width of its node ids: what `#match` yields
+  # is the same `Hit` with an Int32 value (`val.to_i32`, ac.cr:273).  The library's own numbering has no such limit below
+  # 2^31 keys, so one class answers for both names.
+  alias ACBig = AC
+
   # Several GPUs of one node behind one object: the batch is cut into contiguous, byte-balanced document ranges (one
   # per device), every device matches its range, the hit buffers are exchanged with an all-gatherv (RCCL over xGMI
   # between distinct devices) and come back in document order -- the same hits as AC#match_batch.

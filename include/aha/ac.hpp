@@ -257,4 +257,7 @@ class AC {
   aha_ac *h_;
 };
 
+// Aha::ACBig = ACX(Int64) (src/aha/ac.cr:9): wider node ids, the same Hit with an Int32 value (ac.cr:273)
+using ACBig = AC;
+
 }  // namespace aha

@@ -340,3 +340,12 @@ def test_crystal_binding_declares_every_symbol_of_the_header():
     declared = set(re.findall(r"\b(aha_[a-z_0-9]+)\s*\(", hdr))
     bound = set(re.findall(r"fun (aha_[a-z_0-9]+)", cr))
     assert declared - bound == set(), sorted(declared - bound)
+
+
+def test_acbig_is_an_alias():
+    """Aha::ACBig = ACX(Int64) (ac.cr:9) yields the same Hit (value.to_i32, ac.cr:273): every mirror answers for both names."""
+    import aha_amd
+    assert aha_amd.ACBig is aha_amd.AC
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert "alias ACBig = AC" in open(os.path.join(root, "bindings", "crystal", "aha_hip.cr")).read()
+    assert "using ACBig = AC;" in open(os.path.join(root, "include", "aha", "ac.hpp")).read()

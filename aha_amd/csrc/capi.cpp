@@ -1423,11 +1423,17 @@ bool host_streams(Scratch *sc) {
 // The host entry: upload, match and download pipelined over ranges of whole documents.  d_keep != null: the hits stay
 // on the device, in the caller's buffer d_keep[0 .. cap) (aha_ac_match_batch_keep: what the shards of a group call), and
 // only the per-document offsets come back to the host.
-// (d_keep AND out: both -- the hits stay on the device and the ranges' hits also go to out[0 .. host_cap) while they fit;
-// what a shard of a group calls when its place in the caller's buffer is known before it starts)
+// (d_keep AND a host copy: both -- the hits stay on the device and the ranges' hits also go to hc->out[0 .. hc->cap) while
+// they fit; what a shard of a group calls.  The place may become known while the call runs: the copies wait for hc->ready.)
+struct aha_internal_host_copy {
+  aha_hit *out;                // where this call's hits go in host memory (null: nowhere)
+  uint64_t cap;                // room there, in hits
+  volatile int ready;          // set (release) by the caller once out / cap are final
+  volatile int uploads_done;   // set by the call once its text is on the device (or the call is over)
+};
 static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
                                 const aha_match_params *params, aha_hit *out, aha_hit *d_keep, uint64_t cap,
-                                uint64_t *doc_hit_offsets, uint64_t *n_hits, uint64_t host_cap = ~0ull);
+                                uint64_t *doc_hit_offsets, uint64_t *n_hits, aha_internal_host_copy *hc = nullptr);
 
 int32_t aha_ac_match_batch(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets,
                            uint64_t n_docs, const aha_match_params *params, aha_hit *out,
@@ -1448,17 +1454,23 @@ int32_t aha_ac_match_batch_keep(aha_ac *ac, const uint8_t *corpus, const uint64_
 // library-internal (group.cpp): aha_ac_match_batch_keep that also copies the hits to host memory, range by range, as long as
 // they fit host_cap hits -- the copy never makes the call fail (a group reports AHA_E_CAPACITY from its total)
 int32_t aha_internal_match_batch_keep_copy(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
-                                           const aha_match_params *params, aha_hit *d_hits, uint64_t cap, aha_hit *host_out,
-                                           uint64_t host_cap, uint64_t *doc_hit_offsets, uint64_t *n_hits) {
+                                           const aha_match_params *params, aha_hit *d_hits, uint64_t cap,
+                                           aha_internal_host_copy *hc, uint64_t *doc_hit_offsets, uint64_t *n_hits) {
+  struct Done {  // whatever way the call ends, whoever waits for its uploads goes on
+    aha_internal_host_copy *hc;
+    ~Done() {
+      if (hc) __atomic_store_n(&hc->uploads_done, 1, __ATOMIC_RELEASE);
+    }
+  } done{hc};
   if (cap && !d_hits) return AHA_E_INVALID;
   static aha_hit none;
-  return match_batch_host(ac, corpus, doc_offsets, n_docs, params, host_out, d_hits ? d_hits : &none, cap, doc_hit_offsets,
-                          n_hits, host_out ? host_cap : 0);
+  return match_batch_host(ac, corpus, doc_offsets, n_docs, params, nullptr, d_hits ? d_hits : &none, cap, doc_hit_offsets,
+                          n_hits, hc);
 }
 
 static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
                                 const aha_match_params *params, aha_hit *out, aha_hit *d_keep, uint64_t cap,
-                                uint64_t *doc_hit_offsets, uint64_t *n_hits, uint64_t host_cap) {
+                                uint64_t *doc_hit_offsets, uint64_t *n_hits, aha_internal_host_copy *hc) {
   if (!ac || !doc_offsets || !n_hits) return AHA_E_INVALID;
   if (ac->device < 0) {
     tls_err = aha_strerror(AHA_E_NO_DEVICE);
@@ -1547,6 +1559,7 @@ static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_
       P.uploaded = k + 1;
       P.cv.notify_all();
     }
+    if (hc) __atomic_store_n(&hc->uploads_done, 1, __ATOMIC_RELEASE);  // (a group starts its next shard's uploads now)
   };
   auto downloader = [&]() {
     if (hipSetDevice(device) != hipSuccess) return P.fail(AHA_E_HIP, "hipSetDevice failed");
@@ -1558,8 +1571,16 @@ static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_
         if (P.failed) return;
       }
       const uint64_t D = bounds[k + 1] - bounds[k];
-      if (got[k] && out && (!d_keep || base[k] + got[k] <= host_cap) &&
-          hipMemcpyAsync(out + base[k], d_out + base[k], got[k] * sizeof(aha_hit), hipMemcpyDeviceToHost, s_down) != hipSuccess)
+      aha_hit *to = out;
+      if (d_keep) {  // the keep form: a copy only where the caller of the library-internal entry has said where to
+        to = nullptr;
+        if (hc && got[k]) {
+          while (!__atomic_load_n(&hc->ready, __ATOMIC_ACQUIRE)) std::this_thread::yield();  // (set when the shards before have counted)
+          if (hc->out && base[k] + got[k] <= hc->cap) to = hc->out;
+        }
+      }
+      if (got[k] && to &&
+          hipMemcpyAsync(to + base[k], d_out + base[k], got[k] * sizeof(aha_hit), hipMemcpyDeviceToHost, s_down) != hipSuccess)
         return P.fail(AHA_E_HIP, "download of the hits failed");
       if (doc_hit_offsets) {
         try {

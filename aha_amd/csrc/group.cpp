@@ -28,11 +28,18 @@
 
 #include "../../include/aha_hip.h"
 
-// library-internal (capi.cpp): aha_ac_match_batch_keep that also copies the ranges' hits to host memory while they fit
+// library-internal (capi.cpp): aha_ac_match_batch_keep that also copies the ranges' hits to host memory while they fit; the
+// place may become known while the call runs (ready), and the call says when its text is on the device (uploads_done)
+struct aha_internal_host_copy {
+  aha_hit *out;
+  uint64_t cap;
+  volatile int ready;
+  volatile int uploads_done;
+};
 extern "C" int32_t aha_internal_match_batch_keep_copy(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets,
                                                       uint64_t n_docs, const aha_match_params *params, aha_hit *d_hits,
-                                                      uint64_t cap, aha_hit *host_out, uint64_t host_cap,
-                                                      uint64_t *doc_hit_offsets, uint64_t *n_hits);
+                                                      uint64_t cap, aha_internal_host_copy *hc, uint64_t *doc_hit_offsets,
+                                                      uint64_t *n_hits);
 
 namespace {
 
@@ -106,8 +113,7 @@ struct Shard {
   std::vector<uint64_t> h_dho;
   int32_t rc = AHA_OK;
   double ms_match = 0;
-  aha_hit *host_out = nullptr;  // shards one after the other on a shared device: this shard's place in the caller's buffer,
-  uint64_t host_cap = 0;        // and the room there
+  aha_internal_host_copy *hc = nullptr;  // shards in turn on a shared device: this shard's place in the caller's buffer
 };
 
 double ms_since(std::chrono::steady_clock::time_point t0) {
@@ -277,7 +283,7 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
       // (s.host_out: shards that run one after the other know their place in the caller's buffer -- the hits of a range
       // go there from inside the shard's own pipeline, beside the upload of the next range)
       s.rc = aha_internal_match_batch_keep_copy(s.ac, corpus + b0, rel.data(), D, params, (aha_hit *)s.out.p,
-                                                s.out.bytes / sizeof(aha_hit), s.host_out, s.host_cap, s.h_dho.data(), &nh);
+                                                s.out.bytes / sizeof(aha_hit), s.hc, s.h_dho.data(), &nh);
       s.n_hits = nh;
       if (s.rc != AHA_E_CAPACITY) break;
       if (!s.out.reserve(nh * sizeof(aha_hit))) {  // the call told the exact count: once more with room
@@ -360,23 +366,48 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     // place in the caller's buffer would be known when all of them have counted -- the hits' way back would follow the whole
     // match phase.  One after the other, a shard's place is known when it is done, and its hits go to the host beside the
     // next shard's upload (the link is full duplex), as in the single handle's pipeline.
-    uint64_t at = 0;
+    // A shard starts when the one before it has its text on the device (its last match and the copy of its last hits run
+    // beside the next shard's first upload); where its hits go is told when the shards before it have counted (`ready`) --
+    // its pipeline only needs that for the copies to the host, which wait for it.
+    std::vector<aha_internal_host_copy> hc(n);
     for (size_t r = 0; r < n; r++) {
-      Shard &s = g->shards[r];
-      s.host_out = (out && at < cap) ? out + at : nullptr;
-      s.host_cap = s.host_out ? cap - at : 0;
+      hc[r] = aha_internal_host_copy{nullptr, 0, 0, 0};
+      g->shards[r].hc = &hc[r];
+    }
+    for (size_t r = 0; r < n; r++) {
       try {
-        work(r);
+        th.emplace_back([&, r]() {
+          if (r)  // (set by the shard's call, however it ends, and once more below)
+            while (!__atomic_load_n(&hc[r - 1].uploads_done, __ATOMIC_ACQUIRE)) std::this_thread::yield();
+          try {
+            work(r);
+          } catch (...) {
+            g->shards[r].rc = AHA_E_NOMEM;
+            g->shards[r].err = "out of host memory";
+          }
+          __atomic_store_n(&hc[r].uploads_done, 1, __ATOMIC_RELEASE);
+        });
       } catch (...) {
-        s.rc = AHA_E_NOMEM;
-        s.err = "out of host memory";
+        for (size_t q = r; q < n; q++) __atomic_store_n(&hc[q].uploads_done, 1, __ATOMIC_RELEASE);
+        break;  // thread creation failed: the shards started so far are joined below, the rest keep AHA_E_NOMEM
       }
-      s.host_out = nullptr;
-      if (s.rc != AHA_OK) break;
+    }
+    uint64_t at = 0;
+    bool dead = false;
+    for (size_t r = 0; r < th.size(); r++) {
+      Shard &s = g->shards[r];
+      if (!dead && out && at < cap) {
+        hc[r].out = out + at;
+        hc[r].cap = cap - at;
+      }
+      __atomic_store_n(&hc[r].ready, 1, __ATOMIC_RELEASE);
+      th[r].join();
+      if (s.rc != AHA_OK) dead = true;  // (the later shards still run to their end; the call reports this one)
       // (a shard whose hits did not all fit the rest of the caller's buffer: AHA_E_CAPACITY below, nothing is written beyond cap)
       dl_started[r] = 1;
       at += s.n_hits;
     }
+    for (size_t r = 0; r < n; r++) g->shards[r].hc = nullptr;
   }
   T.ms_match = (float)ms_since(t_all);
   uint64_t total = 0;

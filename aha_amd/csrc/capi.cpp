@@ -21,6 +21,7 @@
 #include "cedar_replay.hpp"
 #include "image.hpp"
 #include "unit.hpp"
+#include "hash.hpp"
 
 using namespace aha;
 
@@ -83,6 +84,11 @@ struct aha_ac {
   const uint2 *d_unit_end = nullptr;  // fused expansion (scan_unit.hip ku_expand_groups): key, key length, chain offset per END base
   bool unit_fused = false;            // ... usable: flattened chains of at most 15 keys, key lengths below 2^16
   int unit_walks = 1;                 // chunks a lane of the character-level traversal walks (AHA_UNIT_WALKS; 2 where the LDS allows)
+  // the same automaton keyed by raw characters (hash.hpp, scan_hash.hip): the traversal of byte- and char-offset calls where
+  // the key set allows it (no one-character key, 22-bit bases, a pair filter at most half full)
+  HashImage hash;
+  bool hash_ok = false;
+  HashDev hdev{};
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
   // match_longest only (cedar_replay.cpp): the states that carry one of Cedar's stale END flags, derived on the first
   // match_longest call (it replays every insert: as long again as the rest of compile); dev_longest = dev + the bitmap
@@ -433,6 +439,21 @@ void v2_setup(aha_ac *ac) {
       ac->udev.n_syms = ac->unit.n_syms;
       ac->udev.max_len = a.max_key_len;
       ac->unit_ok = true;
+      if (ac->hash.ok && hash_lds_bytes(ac->hash.n_groups) <= kLdsPerCU && hash_prepare(ac->hash.n_groups) == 0) {
+        const HEntry *hp = nullptr, *hd = nullptr;
+        static_assert(sizeof(HEntry) == 16, "HEntry is one 16-byte load");
+        if (upload(ac, ac->hash.bloom, &ac->hdev.bloom) == AHA_OK && upload(ac, ac->hash.disp, &ac->hdev.disp) == AHA_OK &&
+            upload(ac, ac->hash.pairs, &hp) == AHA_OK && upload(ac, ac->hash.deep, &hd) == AHA_OK) {
+          ac->hdev.pairs = reinterpret_cast<const uint4 *>(hp);
+          ac->hdev.deep = reinterpret_cast<const uint4 *>(hd);
+          ac->hdev.n_groups = ac->hash.n_groups;
+          ac->hdev.pair_log2 = ac->hash.pair_log2;
+          ac->hdev.deep_log2 = ac->hash.deep_log2;
+          ac->hdev.k1 = ac->hash.k1;
+          ac->hdev.max_len = a.max_key_len;
+          ac->hash_ok = true;
+        }
+      }
       const char *uw = getenv("AHA_UNIT_WALKS");
       // (two walks per lane -- ku2_traverse -- lose to one on every box measured: profiles/r04_two_walks.txt; on request only)
       ac->unit_walks = (unit2_event_buffer(ac->unit.n_syms) >= kU2MinEventBuffer && ac->unit.base_bits == 22 && uw &&
@@ -573,7 +594,10 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     post.end_info = ac->d_unit_end_info;  // events carry bases of the unit image
     post.compact = 1;
     const uint64_t u_tiles = (M.n_chunks + (uint64_t)kV2Threads * walks - 1) / ((uint64_t)kV2Threads * walks);
-    unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, u_tiles), s, walks);
+    if (ac->hash_ok && walks == 1)
+      hash_launch_traverse(ac->hdev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, u_tiles), s);
+    else
+      unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, u_tiles), s, walks);
   } else {
     v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   }
@@ -617,7 +641,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
-    t.engine = unit ? 4 : 2;
+    t.engine = unit ? ((ac->hash_ok && walks == 1) ? 5 : 4) : 2;
     t.chunk_bytes = M.S;
     t.n_kernels = 9;
     (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
@@ -786,7 +810,13 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     // character-level image: built when the keys are UTF-8-shaped and at least 30 % of their bytes lie in multi-byte
     // characters (AHA_ENGINE=unit forces it for every eligible key set, AHA_ENGINE=v2 / v1 never build it)
     const char *eng = getenv("AHA_ENGINE");
-    if (!eng || strcmp(eng, "unit") == 0) build_unit(ac->aut, ac->unit, eng != nullptr);
+    const bool want_hash = eng && strcmp(eng, "hash") == 0;  // (opt-in while the engine is new)
+    if (!eng || strcmp(eng, "unit") == 0 || want_hash) build_unit(ac->aut, ac->unit, eng != nullptr);
+    if (ac->unit.ok && want_hash) {
+      build_hash(ac->unit, ac->hash);
+      if (getenv("AHA_DEBUG") && !ac->hash.ok) fprintf(stderr, "aha: no hash image: %s\n", ac->hash.why);
+    }
+    std::vector<UnitImage::HTrans>().swap(ac->unit.htrans);  // (only build_hash reads the list)
     if (getenv("AHA_DEBUG") && !ac->unit.ok) fprintf(stderr, "aha: no character-level image: %s\n", ac->unit.why);
   }
   if (!(flags & AHA_OPT_HOST_ONLY)) {
@@ -820,6 +850,7 @@ int32_t aha_ac_replicate(const aha_ac *src, int32_t device, aha_ac **out) {
     ac->s2_lo = src->s2_lo;
     ac->s2_hi = src->s2_hi;
     ac->unit = src->unit;
+    ac->hash = src->hash;
     ac->seg2 = src->seg2;
     ac->state_base = src->state_base;
   } catch (...) {
@@ -1413,7 +1444,7 @@ struct HostPipe {
   }
 };
 
-bool host_streams(Scratch *sc) {
+static bool host_streams(Scratch *sc) {
   for (auto &st : sc->hs)
     if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
   return true;
@@ -1654,9 +1685,9 @@ static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_
 // ---- device buffers behind the C ABI (include/aha_hip.h) ---------------------------------------------------------
 namespace {
 std::mutex g_copy_mu;
-std::vector<hipStream_t> g_copy_streams;  // one private non-blocking stream per device, created on first use
+static std::vector<hipStream_t> g_copy_streams;  // one private non-blocking stream per device, created on first use
 
-int32_t copy_stream(int device, hipStream_t *out) {
+static int32_t copy_stream(int device, hipStream_t *out) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     tls_err = aha_strerror(AHA_E_NO_DEVICE);
@@ -1676,7 +1707,7 @@ int32_t copy_stream(int device, hipStream_t *out) {
   return AHA_OK;
 }
 
-int32_t buffer_copy(int device, void *dst, const void *src, uint64_t bytes, hipMemcpyKind kind) {
+static int32_t buffer_copy(int device, void *dst, const void *src, uint64_t bytes, hipMemcpyKind kind) {
   if (bytes && (!dst || !src)) return AHA_E_INVALID;
   DeviceGuard g(device);
   hipStream_t st = nullptr;

@@ -154,6 +154,20 @@ void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, uin
 void v2_launch_hit_scan(const V2Args &M, void *stream);   // chunk_hits -> hit_base, totals[0]
 void v2_launch_lead_scan(const V2Args &M, void *stream);  // lead_cnt -> lead_base, totals[1] (char offsets)
 
+// ---- character-level engine over the hash image (scan_hash.hip, hash.hpp) --------
+struct HashDev {
+  const uint32_t *bloom;   // [1 << 14] pair filter
+  const uint8_t *disp;     // [n_groups] displacement of every group of pairs
+  const uint4 *pairs;      // [1 << pair_log2] {parent, character | hits << 24, word, child filter}
+  const uint4 *deep;       // [1 << deep_log2]
+  uint32_t n_groups, pair_log2, deep_log2;
+  uint32_t k1;             // multiplier of the character in the key hash
+  uint32_t max_len;        // longest key, bytes
+};
+size_t hash_lds_bytes(uint32_t n_groups);
+int hash_prepare(uint32_t n_groups);  // raises the dynamic-LDS limit; hipError_t as int
+void hash_launch_traverse(const HashDev &H, const V2Args &M, uint32_t grid, void *stream);
+
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
 void v2_launch_traverse(const DevAut &A, const V2Args &M, uint32_t grid, void *stream);

@@ -174,14 +174,68 @@ def cpu_baseline(blob, offs, corpus, doc, gpu_hits, gpu_dho, seconds, log):
     }, exact
 
 
+def launch_ranks(n):
+    """One child process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the same command line),
+    rendezvous on 127.0.0.1.  Rank 0's stdout (the JSON line) goes to this process's stdout.  Returns the exit code: non-zero
+    when a rank fails (the others are stopped) or prints no line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    deadline = time.time() + 3600
+    while any(p.poll() is None for p in procs):
+        failed = [p for p in procs if p.poll() not in (None, 0)]
+        if failed or time.time() > deadline:  # a rank died (or the job hangs): the rest would wait for it in a collective
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            rc = 1
+            break
+        time.sleep(0.2)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+        rc = rc or (p.returncode or 0)
+    reader.join(timeout=30)
+    out = b"".join(chunks).decode()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if not rc and not any(l.startswith("{") for l in out.splitlines()):
+        rc = 1
+    return rc
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    if world == 1 and args.gpus > 1:
+        # plain `python bench.py --gpus N` (no torchrun): this process starts the N ranks itself -- fresh children, before it
+        # has made any GPU call -- and passes rank 0's JSON line on
+        sys.exit(launch_ranks(args.gpus))
+    if os.environ.get("AHA_BENCH_LAUNCH_TEST"):  # (tests/test_host_logic.py: the launcher alone, no GPU)
+        if rank == 0:
+            print(json.dumps({"launch_test": True, "world": world, "gpus": args.gpus,
+                              "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")}), flush=True)
+        sys.exit(3 if os.environ.get("AHA_BENCH_LAUNCH_TEST") == f"fail{rank}" else 0)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     if os.environ.get("AHA_BENCH_ONE_DEVICE"):  # rehearsal of the N>1 path on a 1-GPU box (ranks share cuda:0)
         local_rank = 0

@@ -36,6 +36,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is all it exports. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define AHA_ABI_VERSION 6
 
@@ -371,6 +375,9 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
 int32_t aha_group_download_shard(aha_group *g, int32_t shard, aha_hit *out, uint64_t cap, uint64_t *n_hits);
 int32_t aha_group_last_timing(const aha_group *g, aha_group_timing *t);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

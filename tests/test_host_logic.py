@@ -28,6 +28,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/aha_hip.h but not exported"
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
     assert N.lib().aha_abi_version() == 6
+    # ... and nothing else (-fvisibility=hidden + aha_amd/csrc/exports.map): a drop-in linked into someone else's process
+    # must not bring unprefixed helpers, C++ internals or kernel stubs into its symbol space
+    import shutil, subprocess
+    if shutil.which("nm") and "asan" not in os.path.basename(N.LIB_PATH):
+        out = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+        assert exported == declared, sorted(exported ^ declared)
+    listed = set(re.findall(r"^\s+(aha_[a-z_0-9]+);", open(os.path.join(ROOT, "aha_amd", "csrc", "exports.map")).read(), re.M))
+    assert listed == declared, sorted(listed ^ declared)
 
 
 def test_compile_errors_follow_reference():
@@ -349,3 +358,20 @@ def test_acbig_is_an_alias():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert "alias ACBig = AC" in open(os.path.join(root, "bindings", "crystal", "aha_hip.cr")).read()
     assert "using ACBig = AC;" in open(os.path.join(root, "include", "aha", "ac.hpp")).read()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without torchrun: the parent starts N fresh rank processes before it touches the GPU, hands on
+    rank 0's JSON line, and fails when a rank fails (AHA_BENCH_LAUNCH_TEST stops the children in front of their first GPU call)."""
+    import json, subprocess, sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = dict(os.environ, AHA_BENCH_LAUNCH_TEST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, bench, "--gpus", "3", "--backend", "gloo"], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["launch_test"] and line["world"] == 3 and line["gpus"] == 3 and line["master"].startswith("127.0.0.1:")
+    env["AHA_BENCH_LAUNCH_TEST"] = "fail1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, timeout=300)
+    assert r.returncode != 0

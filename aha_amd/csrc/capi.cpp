@@ -1121,6 +1121,30 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
       src = ac->unit.tables.data();
       bytes = ac->unit.tables.size() * 4;
       break;
+    case AHA_IMG_HASH_BLOOM:
+      src = ac->hash.bloom.data();
+      bytes = ac->hash.ok ? ac->hash.bloom.size() * 4 : 0;
+      break;
+    case AHA_IMG_HASH_DISP:
+      src = ac->hash.disp.data();
+      bytes = ac->hash.ok ? ac->hash.disp.size() : 0;
+      break;
+    case AHA_IMG_HASH_PAIRS:
+      src = ac->hash.pairs.data();
+      bytes = ac->hash.ok ? ac->hash.pairs.size() * 16 : 0;
+      break;
+    case AHA_IMG_HASH_DEEP:
+      src = ac->hash.deep.data();
+      bytes = ac->hash.ok ? ac->hash.deep.size() * 16 : 0;
+      break;
+    case AHA_IMG_HASH_PARAMS:
+      if (ac->hash.ok) {
+        tmp = {ac->hash.k1, ac->hash.n_groups, ac->hash.pair_log2, ac->hash.deep_log2, ac->hash.n_pairs, ac->hash.n_deep,
+               ac->hash.bloom_fill_permille, 0u};
+        src = tmp.data();
+        bytes = tmp.size() * 4;
+      }
+      break;
     case AHA_IMG_STALE_ENDS: {
       // {key id, prefix length} of every state with a stale END flag: the state is that prefix of that key
       aha_ac *m = const_cast<aha_ac *>(ac);

@@ -31,7 +31,6 @@ AHA_OPT_FORCE_WIDE = 2
 AHA_IMG_SLOTS, AHA_IMG_END_KEY, AHA_IMG_KEY_LN, AHA_IMG_KEY_CNT, AHA_IMG_KEY_KC = 0, 1, 2, 3, 4
 AHA_IMG_STALE_ENDS = 5
 AHA_IMG_UNIT_SLOTS, AHA_IMG_UNIT_ROOT, AHA_IMG_UNIT_END_KEY, AHA_IMG_UNIT_TABLES = 6, 7, 8, 9
-AHA_IMG_HASH_BLOOM, AHA_IMG_HASH_DISP, AHA_IMG_HASH_PAIRS, AHA_IMG_HASH_DEEP, AHA_IMG_HASH_PARAMS = 10, 11, 12, 13, 14
 
 
 class aha_options(C.Structure):

@@ -21,7 +21,6 @@
 #include "cedar_replay.hpp"
 #include "image.hpp"
 #include "unit.hpp"
-#include "hash.hpp"
 
 using namespace aha;
 
@@ -83,12 +82,6 @@ struct aha_ac {
   const uint2 *d_unit_end_chars = nullptr;  // ... with the key's length in characters (char offsets)
   const uint2 *d_unit_end = nullptr;  // fused expansion (scan_unit.hip ku_expand_groups): key, key length, chain offset per END base
   bool unit_fused = false;            // ... usable: flattened chains of at most 15 keys, key lengths below 2^16
-  int unit_walks = 1;                 // chunks a lane of the character-level traversal walks (AHA_UNIT_WALKS; 2 where the LDS allows)
-  // the same automaton keyed by raw characters (hash.hpp, scan_hash.hip): the traversal of byte- and char-offset calls where
-  // the key set allows it (no one-character key, 22-bit bases, a pair filter at most half full)
-  HashImage hash;
-  bool hash_ok = false;
-  HashDev hdev{};
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
   // match_longest only (cedar_replay.cpp): the states that carry one of Cedar's stale END flags, derived on the first
   // match_longest call (it replays every insert: as long again as the rest of compile); dev_longest = dev + the bitmap
@@ -439,25 +432,6 @@ void v2_setup(aha_ac *ac) {
       ac->udev.n_syms = ac->unit.n_syms;
       ac->udev.max_len = a.max_key_len;
       ac->unit_ok = true;
-      if (ac->hash.ok && hash_lds_bytes(ac->hash.n_groups) <= kLdsPerCU && hash_prepare(ac->hash.n_groups) == 0) {
-        const HEntry *hp = nullptr, *hd = nullptr;
-        static_assert(sizeof(HEntry) == 16, "HEntry is one 16-byte load");
-        if (upload(ac, ac->hash.bloom, &ac->hdev.bloom) == AHA_OK && upload(ac, ac->hash.disp, &ac->hdev.disp) == AHA_OK &&
-            upload(ac, ac->hash.pairs, &hp) == AHA_OK && upload(ac, ac->hash.deep, &hd) == AHA_OK) {
-          ac->hdev.pairs = reinterpret_cast<const uint4 *>(hp);
-          ac->hdev.deep = reinterpret_cast<const uint4 *>(hd);
-          ac->hdev.n_groups = ac->hash.n_groups;
-          ac->hdev.pair_log2 = ac->hash.pair_log2;
-          ac->hdev.deep_log2 = ac->hash.deep_log2;
-          ac->hdev.k1 = ac->hash.k1;
-          ac->hdev.max_len = a.max_key_len;
-          ac->hash_ok = true;
-        }
-      }
-      const char *uw = getenv("AHA_UNIT_WALKS");
-      // (two walks per lane -- ku2_traverse -- lose to one on every box measured: profiles/r04_two_walks.txt; on request only)
-      ac->unit_walks = (unit2_event_buffer(ac->unit.n_syms) >= kU2MinEventBuffer && ac->unit.base_bits == 22 && uw &&
-                        strcmp(uw, "2") == 0) ? 2 : 1;
     }
   }
 }
@@ -490,10 +464,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   const uint32_t Lmax = ac->aut.max_key_len;
   uint64_t s_min = std::max<uint64_t>(64, ((8ull * Lmax + 63) / 64) * 64);
   if (s_min > kV2MaxS) return 1;
-  // (the character-level traversal walks two chunks per lane where its LDS allows: twice the chunks, half the size)
   const char *de = getenv("AHA_DIRECT");
-  const int walks = (ac->unit_ok && ac->unit_walks == 2 && !M1.sep && mode != kSlabs && !(de && strcmp(de, "0") == 0)) ? 2 : 1;
-  uint64_t lanes = (uint64_t)ac->v2_grid * kV2Threads * walks;
+  uint64_t lanes = (uint64_t)ac->v2_grid * kV2Threads;
   uint64_t S = ((N + lanes - 1) / lanes + 63) / 64 * 64;
   S = std::min<uint64_t>(std::max<uint64_t>(S, s_min), kV2MaxS);
   V2Args M{};
@@ -593,11 +565,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (unit) {
     post.end_info = ac->d_unit_end_info;  // events carry bases of the unit image
     post.compact = 1;
-    const uint64_t u_tiles = (M.n_chunks + (uint64_t)kV2Threads * walks - 1) / ((uint64_t)kV2Threads * walks);
-    if (ac->hash_ok && walks == 1)
-      hash_launch_traverse(ac->hdev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, u_tiles), s);
-    else
-      unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, u_tiles), s, walks);
+    unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   } else {
     v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   }
@@ -641,7 +609,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
-    t.engine = unit ? ((ac->hash_ok && walks == 1) ? 5 : 4) : 2;
+    t.engine = unit ? 4 : 2;
     t.chunk_bytes = M.S;
     t.n_kernels = 9;
     (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
@@ -810,13 +778,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     // character-level image: built when the keys are UTF-8-shaped and at least 30 % of their bytes lie in multi-byte
     // characters (AHA_ENGINE=unit forces it for every eligible key set, AHA_ENGINE=v2 / v1 never build it)
     const char *eng = getenv("AHA_ENGINE");
-    const bool want_hash = eng && strcmp(eng, "hash") == 0;  // (opt-in while the engine is new)
-    if (!eng || strcmp(eng, "unit") == 0 || want_hash) build_unit(ac->aut, ac->unit, eng != nullptr);
-    if (ac->unit.ok && want_hash) {
-      build_hash(ac->unit, ac->hash);
-      if (getenv("AHA_DEBUG") && !ac->hash.ok) fprintf(stderr, "aha: no hash image: %s\n", ac->hash.why);
-    }
-    std::vector<UnitImage::HTrans>().swap(ac->unit.htrans);  // (only build_hash reads the list)
+    if (!eng || strcmp(eng, "unit") == 0) build_unit(ac->aut, ac->unit, eng != nullptr);
     if (getenv("AHA_DEBUG") && !ac->unit.ok) fprintf(stderr, "aha: no character-level image: %s\n", ac->unit.why);
   }
   if (!(flags & AHA_OPT_HOST_ONLY)) {
@@ -850,7 +812,6 @@ int32_t aha_ac_replicate(const aha_ac *src, int32_t device, aha_ac **out) {
     ac->s2_lo = src->s2_lo;
     ac->s2_hi = src->s2_hi;
     ac->unit = src->unit;
-    ac->hash = src->hash;
     ac->seg2 = src->seg2;
     ac->state_base = src->state_base;
   } catch (...) {
@@ -1120,30 +1081,6 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
     case AHA_IMG_UNIT_TABLES:
       src = ac->unit.tables.data();
       bytes = ac->unit.tables.size() * 4;
-      break;
-    case AHA_IMG_HASH_BLOOM:
-      src = ac->hash.bloom.data();
-      bytes = ac->hash.ok ? ac->hash.bloom.size() * 4 : 0;
-      break;
-    case AHA_IMG_HASH_DISP:
-      src = ac->hash.disp.data();
-      bytes = ac->hash.ok ? ac->hash.disp.size() : 0;
-      break;
-    case AHA_IMG_HASH_PAIRS:
-      src = ac->hash.pairs.data();
-      bytes = ac->hash.ok ? ac->hash.pairs.size() * 16 : 0;
-      break;
-    case AHA_IMG_HASH_DEEP:
-      src = ac->hash.deep.data();
-      bytes = ac->hash.ok ? ac->hash.deep.size() * 16 : 0;
-      break;
-    case AHA_IMG_HASH_PARAMS:
-      if (ac->hash.ok) {
-        tmp = {ac->hash.k1, ac->hash.n_groups, ac->hash.pair_log2, ac->hash.deep_log2, ac->hash.n_pairs, ac->hash.n_deep,
-               ac->hash.bloom_fill_permille, 0u};
-        src = tmp.data();
-        bytes = tmp.size() * 4;
-      }
       break;
     case AHA_IMG_STALE_ENDS: {
       // {key id, prefix length} of every state with a stale END flag: the state is that prefix of that key

@@ -142,31 +142,13 @@ struct UnitDev {
 };
 size_t unit_lds_bytes(uint32_t n_syms);
 int unit_prepare(uint32_t n_syms);  // raises the dynamic-LDS limit; hipError_t as int
-// walks = 2: every lane walks two chunks (ku2_traverse; a tile is 2048 chunks), needs unit2_event_buffer(n_syms) >=
-// kU2MinEventBuffer records of LDS left beside the root table
-constexpr uint32_t kU2MinEventBuffer = 16;
-uint32_t unit2_event_buffer(uint32_t n_syms);
-void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream, int walks);
+void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream);
 void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream);  // evg -> evd + chunk_hits (replaces k2d_count)
 // evg + hit_base -> out, doc_hit_off: the whole expansion in one pass over the wave-ordered events.  uend[base] of an END
 // state = {key | (key length & 255) << 24, offset of its flattened output chain | (key length >> 8) << 24}
 void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, uint32_t workgroups, void *stream);
 void v2_launch_hit_scan(const V2Args &M, void *stream);   // chunk_hits -> hit_base, totals[0]
 void v2_launch_lead_scan(const V2Args &M, void *stream);  // lead_cnt -> lead_base, totals[1] (char offsets)
-
-// ---- character-level engine over the hash image (scan_hash.hip, hash.hpp) --------
-struct HashDev {
-  const uint32_t *bloom;   // [1 << 14] pair filter
-  const uint8_t *disp;     // [n_groups] displacement of every group of pairs
-  const uint4 *pairs;      // [1 << pair_log2] {parent, character | hits << 24, word, child filter}
-  const uint4 *deep;       // [1 << deep_log2]
-  uint32_t n_groups, pair_log2, deep_log2;
-  uint32_t k1;             // multiplier of the character in the key hash
-  uint32_t max_len;        // longest key, bytes
-};
-size_t hash_lds_bytes(uint32_t n_groups);
-int hash_prepare(uint32_t n_groups);  // raises the dynamic-LDS limit; hipError_t as int
-void hash_launch_traverse(const HashDev &H, const V2Args &M, uint32_t grid, void *stream);
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int

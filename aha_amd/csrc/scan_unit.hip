@@ -21,14 +21,6 @@
 #include "image.hpp"
 #include "unit.hpp"
 
-// timing-only lab variants live in tools/lab/ (make lab): the product build defines none of them
-#ifdef AHA_LAB_INCLUDE
-#include AHA_LAB_INCLUDE
-#endif
-#ifndef AHA_LAB_PROBE_INDEX
-#define AHA_LAB_PROBE_INDEX(i) (i)
-#endif
-
 namespace aha {
 
 namespace {
@@ -278,12 +270,10 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const uint32_t fc = BB == 22 ? (code & 7u) : min(code & 7u, 6u);
             const bool probe = act & good & (((E | 0x20000000u) >> ((uint32_t)BB + fc)) & 1u) != 0u & Bq != 0u;
             unsigned long long enw = 0;
-#ifndef AHA_LAB_NO_PROBE
             {
-              const uint2 *ap = slots + AHA_LAB_PROBE_INDEX(probe ? (Bq ^ se) : 0u);
+              const uint2 *ap = slots + (probe ? (Bq ^ se) : 0u);
               asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(enw) : "v"(ap) : "memory");
             }
-#endif
             if (act) {
               uint32_t n_code, n_L;
               bool n_later;
@@ -296,9 +286,7 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
               // fails to
               const uint32_t rt = rl[code];
               const uint32_t rf = rl[pc];
-#ifndef AHA_LAB_NO_PROBE
               asm volatile("s_waitcnt vmcnt(0)" : "+v"(enw) : : "memory");
-#endif
               const uint32_t enx = (uint32_t)enw, eny = (uint32_t)(enw >> 32);
               const bool symhit = probe & u_sym(eny) == se & !grp;  // (a group record's second word is a slot number)
               const bool hit = symhit & !hdr;
@@ -333,9 +321,6 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
               const int32_t last = (int32_t)rel - 1;  // row index of the unit's last byte
               // is_end? -> fetch later (ac.cr:183-185); this lane reports the end positions in [a, e)
               evc = (end & last >= a_rel & last < e_rel) ? c4 : 0u;
-#ifdef AHA_LAB_NO_EVENTS
-              evc = 0u;
-#endif
             }
             return evc;
           };
@@ -396,369 +381,6 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
         }
       }
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// TWO WALKS PER LANE (round 4).  ku_traverse is bound by latency it cannot hide: one workgroup of 1024 threads holds the
-// root's table, so a SIMD runs four waves, and each wave-trip waits for the slowest of its ~25 probes (L2 hits since the
-// image shrank: still ~0.4 ms of 2.1) and for the event path's LDS round trips while the VALU is ~60 % busy
-// (profiles/r03_unit_lab.txt, profiles/r04_unit_lab_a.txt).  More waves do not fit, so every lane walks TWO chunks: both
-// probes, both decode chains and both root reads of a trip are in flight before either walk consumes its own.
-//   * tile = 2048 chunks: lane t of the workgroup walks chunks tile * 2048 + t (walk A) and + 1024 + t (walk B); the 64
-//     chunks of (wave, walk) are one group of the event space, as before (ku_expand_groups does not know the difference)
-//   * the input of a walk is a RING of 24 bytes in LDS (three 8-byte pieces + a guard dword that repeats the first, so
-//     that the two-dword read of a unit never wraps): 28 bytes = 7 dwords per walk, odd stride.  A refill appends one
-//     piece as soon as every lane of the wave has left the oldest one (a lane runs up to 16 bytes ahead of the slowest:
-//     93 % of the lane-trips are useful on the cfg 3 mix, 96 % with the 52-byte window of ku_traverse), and a 64-byte
-//     line is still requested once: the refill that starts a line loads it into 16 registers
-//   * positions are 32-bit offsets from the chunk's start minus the warm-up rounded to whole lines (`x`); a lane is
-//     active while its unit starts before its limit / the next document boundary and all bytes the unit's first byte
-//     announces are staged
-//   * events: a buffer per (wave, walk) in LDS, flushed when the next trip's records would not fit
-constexpr int kW2Piece = 8, kW2Ring = 3 * kW2Piece, kW2Row = kW2Ring + 4;
-constexpr int kW2Walks = 2, kW2Tile = kV2Threads * kW2Walks;
-constexpr uint32_t kW2Inf = 0x7FFFFFFFu;
-
-__host__ __device__ inline size_t u2_lds_fixed(uint32_t n_syms) {  // decode tables, root table, rings
-  return (size_t)(kUTabWords + ((n_syms + 3u) & ~3u)) * 4 + (size_t)kW2Tile * kW2Row;
-}
-// records per event buffer (one per wave and walk) that fit beside the rest, at most 64
-__host__ __device__ inline uint32_t u2_ev_cap(uint32_t n_syms) {
-  const size_t fixed = u2_lds_fixed(n_syms) + 16, lds = 160 * 1024;
-  if (fixed >= lds) return 0;
-  const size_t per = (lds - fixed) / ((size_t)(kV2Threads / 64) * kW2Walks * 12);
-  return (uint32_t)(per > 64 ? 64 : per);
-}
-__host__ __device__ inline size_t u2_lds(uint32_t n_syms) {
-  return u2_lds_fixed(n_syms) + (size_t)u2_ev_cap(n_syms) * (kV2Threads / 64) * kW2Walks * 12 + 16;
-}
-
-struct UWalk {
-  uint32_t E, pc;       // the state as one word (unit.hpp), the symbol that led to it
-  uint32_t x, rp;       // position (offset from the tile origin of the chunk), its index in the ring
-  uint32_t code, L;     // the unit at x: symbol; length | bytes that must be staged << 4 | "it is a character" << 8
-  uint32_t lim, nbx;    // units that start before lim are this lane's; next document boundary (kW2Inf: beyond the window)
-  uint32_t hits, seq;   // hits / events of the chunk so far
-  uint32_t dn;          // index of the next boundary
-  int32_t docrel;       // offset in the document = docrel + x
-  uint32_t lc, lead_total, lc_exact;  // CHARS
-  uint4 q;              // the 16 input bytes whose two pieces are staged next
-  uint32_t chunk;
-};
-struct USet {  // wave-uniform, per walk
-  uint32_t st, rs;             // pieces staged, ring offset of the next piece
-  uint32_t wfill, wout, wcap;  // the event buffer: records in it, records written, capacity of the wave's part of the event space
-  uint32_t *wreg;
-  uint32_t wbo;                // byte offset of the buffer in LDS
-};
-struct UTrip {  // what a walk's trip has in flight
-  uint32_t n_code, n_L, rt, rf, se, Bq, rpn;
-  uint2 en;
-  bool act, probe, grp, hdr, good;
-};
-
-template <bool CHARS>
-__global__ __launch_bounds__(kV2Threads) void ku2_traverse(UnitDev U, V2Args M) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  if (M.cursor[1] >= 16ull) return;  // (bad doc offsets: see ku_traverse)
-  uint32_t *tabw = reinterpret_cast<uint32_t *>(smem);
-  uint32_t *rlw = tabw + kUTabWords;
-  const uint32_t n_root = (U.n_syms + 3u) & ~3u;
-  for (uint32_t i = threadIdx.x; i < kUTabWords; i += kV2Threads) tabw[i] = U.tables[i];
-  for (uint32_t i = threadIdx.x; i < n_root; i += kV2Threads) rlw[i] = i < U.n_syms ? U.root[i] : 0u;
-  __syncthreads();
-  const uint32_t *rl = rlw;
-  const uint4 *t0a = reinterpret_cast<const uint4 *>(tabw + kUT0a);
-  const uint2 *t0b = reinterpret_cast<const uint2 *>(tabw + kUT0b);
-  const uint8_t *tabb = reinterpret_cast<const uint8_t *>(tabw);
-  uint8_t *in_base = smem + (size_t)(kUTabWords + n_root) * 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t *rowA = reinterpret_cast<uint32_t *>(in_base + (size_t)threadIdx.x * kW2Row);
-  uint32_t *rowB = reinterpret_cast<uint32_t *>(in_base + (size_t)(kV2Threads + threadIdx.x) * kW2Row);
-  typedef uint32_t v3u __attribute__((ext_vector_type(3)));
-  const uint32_t CAP = u2_ev_cap(U.n_syms);
-  const uint32_t ev0 = (uint32_t)u2_lds_fixed(U.n_syms) + 16u;  // byte offset of the event buffers
-  const uint2 *slots = U.slots;
-  const int64_t N = (int64_t)M.n_bytes;
-  const uint64_t D = M.n_docs;
-  const uint32_t S = M.S;
-  const uint32_t warm = U.max_len > 1 ? U.max_len - 1 : 0;
-  const uint32_t WB = (warm + 63u) & ~63u;           // warm-up, whole lines: the tile origin of a chunk is its start - WB
-  const uint32_t p0 = (WB - warm) / kW2Piece;        // first piece staged
-  const uint32_t tot = (WB + S) / kW2Piece + 1;      // pieces: one beyond the chunk (a unit that starts in its last bytes)
-  const uint32_t ev_stride = M.ev_stride;
-
-  // The unit at ring index rp / position x (unit.hpp): table-driven decode -- the first byte tells the length the unit
-  // would have, where its second and third byte are looked up (a poison value unless they are continuation bytes) and
-  // the window of its class; the sum is the symbol when it falls into that window.
-  auto decode = [&](const uint32_t *row, uint32_t rp, uint32_t x, uint32_t dend, uint32_t &o_code, uint32_t &o_L) {
-    const uint32_t lo = row[rp >> 2], hi = row[(rp >> 2) + 1];
-    const uint32_t w4 = __builtin_amdgcn_alignbyte(hi, lo, rp & 3u);
-    const uint32_t b0 = w4 & 0xFFu;
-    const uint4 q0 = t0a[b0];
-    const uint2 q1 = t0b[b0];
-    const uint32_t s1 = *reinterpret_cast<const uint32_t *>(tabb + q0.x + ((w4 >> 6) & 0x3FCu));
-    const uint32_t s2 = *reinterpret_cast<const uint32_t *>(tabb + q0.y + ((w4 >> 14) & 0x3FCu));
-    const uint32_t sum = q0.z + s1 + s2;
-    const uint32_t want = q1.y;                  // bytes the first byte announces
-    const bool in_doc = x + want <= dend;        // else: a lead byte without its continuation bytes (bad)
-    const bool whole = in_doc & sum < kUPoison;  // a well-formed unit
-    const bool good = whole & (sum - q0.w) < q1.x;  // ... of the keys' alphabet
-    uint32_t L = (whole ? want : 1u) | (in_doc ? want << 4 : 16u);
-    if (CHARS) L |= (b0 & 0xC0u) != 0x80u ? 0x100u : 0u;  // the unit is a character (it does not start with a stray continuation byte)
-    o_L = L;
-    o_code = good ? sum - kUBias : 0u;           // symbol 0 has no transition anywhere
-  };
-  // the 16 bytes that hold pieces p & ~1 and + 1 of a walk.  Not waited for here: the refill that takes the first of the
-  // two pieces does, two refills later.  A 64-byte line is requested four times, a few microseconds apart -- the later
-  // three are L2 hits, as fast as the probes the next trip waits for anyway (vmcnt counts in order: a load in flight
-  // makes every later probe wait for it too; only the first quarter of a line costs more than they do).  Two walks
-  // leave no registers for a queue of whole lines (ku_traverse: 12).
-  auto load_quarter = [&](UWalk &X, uint32_t p) {
-    const int64_t ga = (int64_t)X.chunk * S - (int64_t)WB + (int64_t)(p >> 1) * 16;
-    const bool fast = ga >= 0 && ga + 16 <= N;
-    if (wall(fast))
-      X.q = *reinterpret_cast<const uint4 *>(M.text + ga);
-    else
-      X.q = load16(M.text, ga, N);
-  };
-  // appends piece T.st to the walk's ring and decodes the lanes' units again (a unit decoded ahead of its bytes is
-  // whatever the ring held)
-  auto refill = [&](UWalk &X, USet &T, uint32_t *row) {
-    uint32_t v0, v1;
-#ifdef AHA_LAB_W2_BLOCKQ
-    if (T.st & 1u) {
-      v0 = (uint32_t)X.q.z, v1 = (uint32_t)X.q.w;
-    } else {
-      load_quarter(X, T.st);
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      v0 = (uint32_t)X.q.x, v1 = (uint32_t)X.q.y;
-    }
-#else
-    if (T.st & 1u) {
-      v0 = (uint32_t)X.q.z, v1 = (uint32_t)X.q.w;
-      if (T.st + 1 < tot) load_quarter(X, T.st + 1);
-    } else {
-      v0 = (uint32_t)X.q.x, v1 = (uint32_t)X.q.y;
-    }
-#endif
-    row[T.rs >> 2] = v0;
-    row[(T.rs >> 2) + 1] = v1;
-    if (T.rs == 0) row[kW2Ring >> 2] = v0;  // the guard
-    T.st++;
-    T.rs = T.rs == 2 * kW2Piece ? 0u : T.rs + kW2Piece;
-    decode(row, X.rp, X.x, X.nbx, X.code, X.L);
-  };
-  // a document starts at x (ac.cr:177: the state is per sequence)
-  auto boundary = [&](UWalk &A, bool bnd, uint32_t *row) {
-    if (bnd) {
-      const int64_t here = (int64_t)A.chunk * S - (int64_t)WB + (int64_t)A.x;
-      uint64_t dn = A.dn;
-      int64_t nb;
-      do {
-        M.doc_ev_rank[dn] = A.seq;
-        M.doc_hit_rank[dn] = A.hits;
-        if (CHARS) M.doc_lead_rank[dn] = A.lead_total;
-        dn++;
-        nb = dn <= D ? (int64_t)M.doc_off[dn] : INT64_MAX;
-      } while (nb == here);
-      asm volatile("" : "+v"(nb));  // retire the load inside this block
-      A.dn = (uint32_t)dn;
-      A.nbx = nb - here <= (int64_t)S + 64 ? (uint32_t)(nb - here) + A.x : kW2Inf;
-      A.E = 0, A.pc = 0, A.lc = 0, A.lc_exact = 1;
-      A.docrel = -(int32_t)A.x;
-    }
-    decode(row, A.rp, A.x, A.nbx, A.code, A.L);  // (its document ends elsewhere now)
-  };
-  // ---- the trip, first half: everything that leaves the lane is requested
-  auto issue = [&](UWalk &X, const USet &T, const uint32_t *row, UTrip &t) {
-    const uint32_t st8 = T.st * kW2Piece;
-    t.act = X.x < min(X.lim, X.nbx) & X.x + ((X.L >> 4) & 15u) <= st8;
-    t.good = X.code != 0u;
-    const uint32_t Lb = X.L & 15u;
-    uint32_t r = X.rp + Lb;
-    r = r >= (uint32_t)kW2Ring ? r - kW2Ring : r;
-    t.rpn = r;
-    decode(row, r, X.x + Lb, X.nbx, t.n_code, t.n_L);  // the NEXT unit, while this one is probed
-    // the root's transitions (LDS) on the unit (symbol 0 has none) and on the symbol that led to the current state: the
-    // one-character state a two-character state fails to
-    t.rt = rl[X.code];
-    t.rf = rl[X.pc];
-    // the state's own transition: at most one 8-byte probe, keyed by the unit's symbol / the group of a high symbol at a
-    // big state / 0 for the header (unit.hpp, IMAGE); the state word's filter answers most misses without it
-    t.Bq = u_child(X.E);
-    t.hdr = u_hdr_pending(X.E);
-    t.grp = t.Bq >= U.big_lo & X.code >= U.n_low & !t.hdr;
-    const uint32_t s_ = t.grp ? (X.code >> 5) + U.g0 : X.code;
-    t.se = t.hdr ? 0u : s_;
-    t.probe = t.act & t.good & (((X.E | 0x20000000u) >> (22u + (X.code & 7u))) & 1u) != 0u & t.Bq != 0u;
-#ifdef AHA_LAB_NO_PROBE
-    t.en = make_uint2(0u, 0u);
-#else
-    t.en = slots[AHA_LAB_PROBE_INDEX(t.probe ? (t.Bq ^ t.se) : 0u)];
-#endif
-  };
-  // ---- second half: the new state; returns the hits the lane reports (0: none)
-  auto consume = [&](UWalk &X, const UTrip &t) -> uint32_t {
-    const uint32_t code = X.code;
-    const bool symhit = t.probe & u_sym(t.en.y) == t.se & !t.grp;  // (a group record's second word is a slot number)
-    const bool hit = symhit & !t.hdr;
-    // a big state continues on this high symbol: the next trip probes its child's slot as the state "slot ^ symbol"
-    const bool redir = t.grp & t.probe & ((t.en.x >> (code & 31u)) & 1u) != 0u;
-    const uint32_t rE = (__builtin_popcount(t.en.x & ~(~0u << (code & 31u))) + t.en.y ^ code) | u_all_filter(22u);
-    // a miss: the fail link is the root (or the unit matches nothing) -> the root's table answers in this trip; else the
-    // unit is tried again in the fail state: root[the symbol that led here] (F1), or the header, fetched by the next trip
-    const bool viaroot = !symhit & !redir & (!u_nfr(X.E) | !t.good);
-    const uint32_t ft = u_f1(X.E) ? (t.rf & 0x7FFFFFFFu) : (t.Bq | u_all_filter(22u) | 0x20000000u);
-    uint32_t nE = viaroot ? t.rt : ft;
-    nE = redir ? rE : nE;
-    nE = symhit ? t.en.x : nE;
-    X.E = t.act ? nE : X.E;
-    const bool consumed = t.act & (hit | viaroot);
-    const bool end = consumed & u_end(nE);
-    const uint32_t c4 = hit ? u_c4(t.en.y) : 1u;
-    X.pc = consumed ? code : X.pc;
-    if (CHARS) {  // characters that START in the lane's chunk
-      const uint32_t isl = (consumed & X.x >= WB) ? (X.L >> 8) : 0u;
-      X.lc += isl;
-      X.lead_total += isl;
-    }
-    X.x += consumed ? (X.L & 15u) : 0u;
-    X.rp = consumed ? t.rpn : X.rp;
-    X.code = consumed ? t.n_code : code;
-    X.L = consumed ? t.n_L : X.L;
-    // is_end? -> fetch later (ac.cr:183-185); this lane reports the end positions in its chunk
-    uint32_t evc = (end & X.x > WB & X.x <= X.lim) ? c4 : 0u;
-#ifdef AHA_LAB_NO_EVENTS
-    evc = 0u;
-#endif
-    return evc;
-  };
-  auto flush = [&](USet &T) {  // what is buffered leaves in one store
-    if ((uint32_t)lane < T.wfill && T.wout + (uint32_t)lane < T.wcap) {
-      const uint32_t *qq = reinterpret_cast<const uint32_t *>(smem + (T.wbo + __umul24((uint32_t)lane, 12u)));
-      const v3u r = {qq[0], qq[1], qq[2]};
-      *reinterpret_cast<v3u *>(T.wreg + (size_t)(T.wout + lane) * 3) = r;
-    }
-    T.wout += T.wfill;
-    T.wfill = 0;
-  };
-  auto report = [&](UWalk &X, USet &T, uint32_t evc, uint64_t evm) {
-    if (evm) {
-      const bool ev = evc != 0u;
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(evm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)evm, 0u));
-      const uint32_t kp = __popcll(evm);
-      // {END state | lane | hits it stands for, end offset in the document, hits of the chunk before it}
-      const uint32_t rx = u_rec_x(u_child(X.E), (uint32_t)lane, evc, 22u), rz = u_rec_z(X.hits, evc, 22u);
-      const uint32_t ry = CHARS ? ((X.lc << 1) | X.lc_exact) : (uint32_t)(X.docrel + (int32_t)X.x);
-      if (T.wfill + kp > CAP) flush(T);
-      if (kp > CAP) {  // (hit-dense text: more events in one trip than the buffer holds)
-        if (ev && T.wout + rank < T.wcap) {
-          const v3u r = {rx, ry, rz};
-          *reinterpret_cast<v3u *>(T.wreg + (size_t)(T.wout + rank) * 3) = r;
-        }
-        T.wout += kp;
-      } else {
-        if (ev) {
-          uint32_t *d = reinterpret_cast<uint32_t *>(smem + (T.wbo + __umul24(T.wfill + rank, 12u)));
-          d[0] = rx;
-          d[1] = ry;
-          d[2] = rz;
-        }
-        T.wfill += kp;
-      }
-      X.seq += ev ? 1u : 0u;
-      X.hits += evc;
-    }
-  };
-  auto start = [&](UWalk &A, USet &T, uint64_t tile, int w) {
-    A.chunk = (uint32_t)(tile * kW2Tile) + (uint32_t)w * kV2Threads + threadIdx.x;  // (n_chunks < 2^32: capi.cpp)
-    const bool live = A.chunk < M.n_chunks;
-    const int64_t a = (int64_t)A.chunk * S;
-    const int64_t e = live ? min(a + (int64_t)S, N) : a;
-    A.E = 0, A.pc = 0, A.code = 0, A.L = 0x11u, A.hits = 0, A.seq = 0, A.lc = 0, A.lead_total = 0, A.lc_exact = 0;
-    A.lim = live ? WB + (uint32_t)(e - a) : 0u;
-    A.x = WB, A.nbx = kW2Inf, A.dn = 0, A.docrel = 0;
-    if (live) {
-      const uint64_t dn = first_boundary(M.doc_off, D, (uint64_t)a);
-      const int64_t nb = (int64_t)M.doc_off[dn];
-      int64_t doc_start = a;
-      if (nb != a) {
-        doc_start = (int64_t)M.doc_off[dn - 1];
-        A.x = WB - (uint32_t)min<int64_t>(a - doc_start, (int64_t)warm);
-        if (CHARS) M.chunk_doc0[A.chunk] = (uint32_t)(dn - 1);
-      } else if (CHARS) {
-        M.chunk_doc0[A.chunk] = (uint32_t)dn;
-      }
-      A.dn = (uint32_t)dn;
-      A.nbx = nb - a <= (int64_t)S + 64 ? (uint32_t)(nb - a) + WB : kW2Inf;
-      A.docrel = (int32_t)(a - (int64_t)WB - doc_start);
-    }
-    A.rp = A.x % (uint32_t)kW2Ring;
-    T.st = p0;
-    T.rs = (p0 % 3u) * kW2Piece;
-    T.wfill = 0, T.wout = 0;
-    const uint64_t wchunk0 = tile * kW2Tile + (uint64_t)w * kV2Threads + (uint64_t)wave * 64;
-    T.wreg = M.evg + wchunk0 * ev_stride * 3;
-    T.wcap = (uint32_t)min<uint64_t>(64, M.n_chunks > wchunk0 ? M.n_chunks - wchunk0 : 0) * ev_stride;
-    T.wbo = ev0 + (uint32_t)(wave * kW2Walks + w) * (CAP * 12u);
-    load_quarter(A, p0);  // the first piece's
-  };
-  auto finish = [&](UWalk &X, USet &T) {
-    flush(T);
-    if (X.chunk < M.n_chunks) {
-      M.ev_cnt[X.chunk] = X.seq;
-      if (X.seq > ev_stride) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
-      if (CHARS) M.lead_cnt[X.chunk] = X.lead_total;
-      M.chunk_hits[X.chunk] = X.hits;
-      if ((int64_t)X.chunk * S + (int64_t)(X.lim - WB) == N) {  // documents that start at N (empty tail documents, and d = D)
-        uint64_t dn = X.dn;
-        while (dn <= D) {
-          M.doc_ev_rank[dn] = X.seq;
-          M.doc_hit_rank[dn] = X.hits;
-          if (CHARS) M.doc_lead_rank[dn] = X.lead_total;
-          dn++;
-        }
-      }
-    }
-  };
-
-  const uint64_t n_tiles = (M.n_chunks + kW2Tile - 1) / kW2Tile;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    UWalk A, B;
-    USet TA, TB;
-    start(A, TA, tile, 0);
-    start(B, TB, tile, 1);
-    for (;;) {
-      {
-        const bool bA = A.x == A.nbx & A.x < A.lim, bB = B.x == B.nbx & B.x < B.lim;
-        if (wany(bA | bB)) {  // rare
-          boundary(A, bA, rowA);
-          boundary(B, bB, rowB);
-        }
-      }
-      // a refill as soon as every lane has left the oldest piece (or has nothing more to do)
-      if (TA.st < tot && wall((int32_t)A.x >= (int32_t)(TA.st * kW2Piece) - 2 * kW2Piece | A.x >= A.lim)) refill(A, TA, rowA);
-      if (TB.st < tot && wall((int32_t)B.x >= (int32_t)(TB.st * kW2Piece) - 2 * kW2Piece | B.x >= B.lim)) refill(B, TB, rowB);
-      // both walks' requests are in flight before either consumes its own
-      UTrip ta, tb;
-      issue(A, TA, rowA, ta);
-      issue(B, TB, rowB, tb);
-      if (!wany(ta.act | tb.act)) {
-        if (TA.st >= tot && TB.st >= tot) break;
-        continue;
-      }
-      const uint32_t evcA = consume(A, ta);
-      const uint32_t evcB = consume(B, tb);
-      // (both votes first: hipcc would otherwise sink one walk's second half below the other walk's report, whose
-      // buffer store would then stand between that walk's probe and the wait for it)
-      const uint64_t evmA = wballot(evcA != 0u), evmB = wballot(evcB != 0u);
-      report(A, TA, evcA, evmA);
-      report(B, TB, evcB, evmB);
-    }
-    finish(A, TA);
-    finish(B, TB);
   }
 }
 
@@ -1042,7 +664,6 @@ __global__ __launch_bounds__(256) void ku_doc_offsets(V2Args M) {
 }  // namespace
 
 size_t unit_lds_bytes(uint32_t n_syms) { return u_lds(n_syms); }
-uint32_t unit2_event_buffer(uint32_t n_syms) { return u2_ev_cap(n_syms); }
 
 int unit_prepare(uint32_t n_syms) {
   const int lds = (int)unit_lds_bytes(n_syms);
@@ -1050,22 +671,10 @@ int unit_prepare(uint32_t n_syms) {
   if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<true, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<false, 23>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<true, 23>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (!e && u2_ev_cap(n_syms) >= kU2MinEventBuffer) {
-    e = (int)hipFuncSetAttribute((const void *)ku2_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)u2_lds(n_syms));
-    if (!e)
-      e = (int)hipFuncSetAttribute((const void *)ku2_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)u2_lds(n_syms));
-  }
   return e;
 }
 
-void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream, int walks) {
-  if (walks == 2 && U.base_bits == 22) {
-    if (M.chars)
-      hipLaunchKernelGGL(ku2_traverse<true>, dim3(grid), dim3(kV2Threads), u2_lds(U.n_syms), (hipStream_t)stream, U, M);
-    else
-      hipLaunchKernelGGL(ku2_traverse<false>, dim3(grid), dim3(kV2Threads), u2_lds(U.n_syms), (hipStream_t)stream, U, M);
-    return;
-  }
+void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream) {
   const size_t lds = unit_lds_bytes(U.n_syms);
 #define AHA_LAUNCH_KU(C, B) hipLaunchKernelGGL((ku_traverse<C, B>), dim3(grid), dim3(kV2Threads), lds, (hipStream_t)stream, U, M)
   if (U.base_bits == 23) {

@@ -1,6 +1,5 @@
 // unit.cpp -- see unit.hpp.
 #include "unit.hpp"
-#include "hash.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -15,7 +14,6 @@ namespace {
 struct UTrans {
   uint32_t sym;    // while collecting: class << 16 | payload; afterwards the symbol
   uint32_t child;  // byte-level state id (at a unit boundary)
-  uint32_t raw;    // the unit's bytes as a little-endian integer
 };
 
 }  // namespace
@@ -91,7 +89,7 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
       const uint32_t c1 = a.first_child[s] + j;
       const uint32_t b0 = a.in_label[c1];
       if (need[c1] == 0) {
-        tr.push_back({(1u << 16) | b0, c1, b0});
+        tr.push_back({(1u << 16) | b0, c1});
         continue;
       }
       for (uint32_t j2 = 0; j2 < a.n_child[c1]; j2++) {
@@ -101,7 +99,7 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
           const uint32_t p = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
           lo2 = std::min(lo2, p);
           hi2 = std::max(hi2, p + 1);
-          tr.push_back({(2u << 16) | p, c2, b0 | b1 << 8});
+          tr.push_back({(2u << 16) | p, c2});
           continue;
         }
         for (uint32_t j3 = 0; j3 < a.n_child[c2]; j3++) {
@@ -110,7 +108,7 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
           const uint32_t p = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
           lo3 = std::min(lo3, p);
           hi3 = std::max(hi3, p + 1);
-          tr.push_back({(3u << 16) | p, c3, b0 | b1 << 8 | b2 << 16});
+          tr.push_back({(3u << 16) | p, c3});
         }
       }
     }
@@ -445,25 +443,6 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
         rec = ((uint64_t)run << 32) | (bits | 1u << ((sym - u.n_low) & 31u));
         u.slots[run + rank] = entry;
       }
-    }
-  }
-  // ---- the same transitions keyed by raw characters (hash.hpp)
-  {
-    std::vector<uint32_t> in_raw(S, 0u);  // the character that leads from the root to a one-character state
-    for (uint32_t t = first[0]; t < first[1]; t++) in_raw[tr[t].child] = tr[t].raw;
-    auto child_filter = [&](uint32_t st) -> uint32_t {
-      uint32_t f = 0;
-      for (uint32_t q = first[st]; q < first[st + 1]; q++) f |= 1u << h_cls(tr[q].raw);
-      return f;
-    };
-    u.htrans.reserve(tr.size() + u.n_nfr);
-    for (uint32_t s : ustates) {
-      if (s == 0) continue;
-      if (udepth[s] == 1 && a.key_of[s] >= 0) u.has_len1_key = true;
-      const uint32_t par = udepth[s] == 1 ? (kHTag | in_raw[s]) : base[s];
-      if (has_header(s)) u.htrans.push_back({par, kHHdr, word(a.fail[s]) & 0x7FFFFFFFu, 0u, child_filter(a.fail[s])});
-      for (uint32_t t = first[s]; t < first[s + 1]; t++)
-        u.htrans.push_back({par, tr[t].raw, word(tr[t].child), u_c4_of(a, tr[t].child), child_filter(tr[t].child)});
     }
   }
   u.ok = true;

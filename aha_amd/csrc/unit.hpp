@@ -132,17 +132,6 @@ struct UnitImage {
   uint32_t c2lo = 0, w2 = 0, c3lo = 0, w3 = 0;
   uint32_t n_states = 0, n_trans = 0, n_nfr = 0;
   uint32_t multi_permille = 0;      // share of the key bytes that lie in two- and three-byte units
-  // The same transitions keyed by raw characters (a character = its UTF-8 bytes as a little-endian integer), for the hash
-  // image (hash.hpp): every transition out of a state of one character or more, and every header.
-  struct HTrans {
-    uint32_t parent;  // 1 << 24 | character of the one-character parent state, or the base of the parent state
-    uint32_t ch;      // character, or 0xFFFFFF: the header of `parent`
-    uint32_t word;    // the child (header: the fail state, END cleared) as one word
-    uint32_t c4;      // hits an event in the child stands for (0 unless it is END)
-    uint32_t cf;      // child filter of that state (hash.hpp h_cls)
-  };
-  std::vector<HTrans> htrans;
-  bool has_len1_key = false;        // a key of one character (the hash image's walk does not look at single characters)
 };
 
 // a: the byte-level automaton (build_automaton).  Fills u; u.ok = false + u.why when the key set is not eligible or

@@ -278,13 +278,6 @@ enum {
   AHA_IMG_UNIT_ROOT = 7,      /* uint32[unit_syms]: the root's transitions by symbol */
   AHA_IMG_UNIT_END_KEY = 8,   /* int32[unit_slots]: key id at the base of an END state, else -1 */
   AHA_IMG_UNIT_TABLES = 9,    /* uint32[2816]: the decode tables (unit.hpp, SYMBOLS) */
-  /* the same automaton keyed by raw characters (aha_amd/csrc/hash.hpp; built with AHA_ENGINE=hash where the key set allows it;
-   * empty otherwise): entries are {parent, character | hits << 24, state word, child filter} */
-  AHA_IMG_HASH_BLOOM = 10,    /* uint32[1 << 14]: blocked Bloom filter over the two-character paths */
-  AHA_IMG_HASH_DISP = 11,     /* uint8[n_groups]: displacements of the pairs' perfect hash */
-  AHA_IMG_HASH_PAIRS = 12,    /* uint32[4][1 << pair_log2] */
-  AHA_IMG_HASH_DEEP = 13,     /* uint32[4][1 << deep_log2]: cuckoo table of the deeper transitions and the headers */
-  AHA_IMG_HASH_PARAMS = 14,   /* uint32[8]: k1, n_groups, pair_log2, deep_log2, pairs, deep entries, filter fill permille, 0 */
   AHA_IMG_STALE_ENDS = 5     /* {uint32 key id, uint32 prefix length}[]: the states (a prefix of a key each) whose node in
                                  the reference's Cedar keeps a stale END flag (src/aha/cedar.cr:642-648); match_longest
                                  treats them as ends that yield nothing (src/aha/ac.cr:126-128, 249-263) */

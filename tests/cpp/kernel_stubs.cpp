@@ -16,8 +16,7 @@ namespace aha {
 size_t v2_lds_bytes(uint32_t, bool) { return 0; }
 size_t unit_lds_bytes(uint32_t) { return 0; }
 int unit_prepare(uint32_t) { return 0; }
-void unit_launch_traverse(const UnitDev &, const V2Args &, uint32_t, void *, int) { no_gpu("unit_launch_traverse"); }
-uint32_t unit2_event_buffer(uint32_t) { return 0; }
+void unit_launch_traverse(const UnitDev &, const V2Args &, uint32_t, void *) { no_gpu("unit_launch_traverse"); }
 int v2_prepare(bool, size_t) { return 0; }
 void v2_launch_traverse(const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("v2_launch_traverse"); }
 void v2_launch_chunk_scan(const V2Args &, void *) { no_gpu("v2_launch_chunk_scan"); }
@@ -25,9 +24,6 @@ void v2_launch_sort(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("
 void v2_launch_expand(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("v2_launch_expand"); }
 void v2_launch_direct_post(const DevAut &, const V2Args &, void *, void *, bool) { no_gpu("v2_launch_direct_post"); }
 void launch_has_nul(const uint8_t *, uint64_t, uint64_t *, void *) { no_gpu("launch_has_nul"); }
-size_t hash_lds_bytes(uint32_t) { return 0; }
-int hash_prepare(uint32_t) { return 0; }
-void hash_launch_traverse(const HashDev &, const V2Args &, uint32_t, void *) { no_gpu("hash_launch_traverse"); }
 void unit_launch_regroup(const DevAut &, const V2Args &, void *) { no_gpu("unit_launch_regroup"); }
 void unit_launch_expand(const uint2 *, const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("unit_launch_expand"); }
 void v2_launch_hit_scan(const V2Args &, void *) { no_gpu("v2_launch_hit_scan"); }

@@ -17,7 +17,7 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u2", "u23", "h", "hr", "auto"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u23", "auto"], autouse=True)
 def engine(request, monkeypatch):
     """Every parity test runs on the single-traversal engine (scan_v2.hip, byte level), on the two-pass engine
     (kernels.hip: the fallback for tiny capacities and very long keys), on the single-traversal engine with its LDS
@@ -26,25 +26,20 @@ def engine(request, monkeypatch):
     unit image for every eligible key set, also the mostly-ASCII ones that would not get one by default; byte-offset
     calls through the event regions then run it, everything else the single-traversal engine; its post pass is the fused
     expansion wherever the output chains are short enough, "ur" -- AHA_UNIT_POST=regroup -- keeps it to the general
-    regroup + count + expand passes; "u2" -- AHA_UNIT_WALKS=2 -- walks two chunks per lane, ku2_traverse; "u23" --
+    regroup + count + expand passes; "u23" --
     AHA_UNIT_BASE_BITS=23 -- builds every image in the wide format of images beyond 2^22 slots: 23-bit bases, 6-bit filter,
-    3-bit hit count in the event record; "h" -- AHA_ENGINE=hash -- walks the same automaton keyed by raw characters,
-    scan_hash.hip, wherever the key set allows it (no one-character key), "hr" with the general post passes).  "auto" sets
+    3-bit hit count in the event record).  "auto" sets
     no variable: the library decides per key set, which is what a caller and bench.py get.  The variables are read when a
     handle is compiled."""
     if request.param == "auto":
         monkeypatch.delenv("AHA_ENGINE", raising=False)
     else:
-        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u2": "unit", "u23": "unit", "h": "hash", "hr": "hash"}.get(request.param, "v2"))
-    if request.param == "u2":
-        monkeypatch.setenv("AHA_UNIT_WALKS", "2")
-    else:
-        monkeypatch.delenv("AHA_UNIT_WALKS", raising=False)
+        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u23": "unit"}.get(request.param, "v2"))
     if request.param == "u23":
         monkeypatch.setenv("AHA_UNIT_BASE_BITS", "23")
     else:
         monkeypatch.delenv("AHA_UNIT_BASE_BITS", raising=False)
-    if request.param in ("ur", "hr"):
+    if request.param == "ur":
         monkeypatch.setenv("AHA_UNIT_POST", "regroup")
     else:
         monkeypatch.delenv("AHA_UNIT_POST", raising=False)
@@ -452,7 +447,7 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
     """A device corpus that is not 16-byte aligned (a slice of a larger buffer) must not fall to the two-pass engine:
     same hits, same engine, at least 70 % of the aligned rate (one device-to-device copy in front of the match: ~0.18 ms
     for these 256 MiB against ~0.7 ms for the match)."""
-    if engine not in ("v2", "u", "h"):
+    if engine not in ("v2", "u"):
         pytest.skip("on the byte-level and on the character-level engine")
     import torch
 
@@ -479,7 +474,7 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
             t0 = time.perf_counter()
             assert g.match_batch_device(view, dd, out) == n
             best = min(best, time.perf_counter() - t0)
-        assert g.last_timing()["engine"] in ((4,) if engine in ("u", "u2", "u23") else (4, 5) if engine == "h" else (2,))
+        assert g.last_timing()["engine"] == (4 if engine in ("u", "u23") else 2)
         res[shift] = (best, out[:n].cpu().numpy().tobytes())
     assert res[0][1] == res[1][1]
     assert res[0][0] / res[1][0] >= 0.7, (res[0][0], res[1][0])
@@ -491,12 +486,12 @@ def test_engine_selected(engine, monkeypatch):
     ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u2", "u23", "h", "hr", "auto") else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u23", "auto") else (2,))
     ac = AC.compile(["ab", "ba"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"ab ba " * 60))[:3] == [(0, 2, 0), (3, 5, 1), (6, 8, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u2", "u23", "h", "hr", "auto") else (2,))
-    if engine in ("u", "ur", "u2", "u23"):
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u23", "auto") else (2,))
+    if engine in ("u", "ur", "u23"):
         # the library's own choice (no AHA_ENGINE): keys of multi-byte characters get the character-level traversal for
         # byte- and char-offset batches, ASCII keys keep the byte-level one
         monkeypatch.delenv("AHA_ENGINE", raising=False)
@@ -518,7 +513,7 @@ def test_engine_selected(engine, monkeypatch):
         assert asc.info["unit_enabled"] == 0 and asc.last_timing()["engine"] == 2
     # char offsets run on the character-level engine too, the separator filter on the byte-level engines only
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u2", "u23", "h", "hr", "auto") else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u23", "auto") else (2,))
     sep = BitArray(256)
     sep[ord(" ")] = True
     assert [tuple(h) for h in ac.match("ab ba", sep)] == [(0, 2, 0), (3, 5, 1)]
@@ -656,7 +651,7 @@ def test_host_entry_pipeline_and_buffer_api(engine):
     small first (count and offsets must still be exact) and with char offsets.  (2) aha_corpus_upload +
     aha_buffer_alloc / _download: the batch uploaded once through the C ABI, matched with the device entry point on
     raw pointers (no torch), hits downloaded.  The oracle checks the first documents."""
-    if engine not in ("v2", "u", "h"):
+    if engine not in ("v2", "u"):
         pytest.skip("on the byte-level and on the character-level engine")
     import torch
 
@@ -696,7 +691,7 @@ def test_full_size_properties(cfg, engine):
     properties instead of a full oracle run -- ordering, every hit spells its
     key, document independence (any split of the batch gives the same hits),
     engine agreement by checksum -- plus the oracle on a sample of documents."""
-    if engine not in ("v2", "u", "u2", "h", "auto"):
+    if engine not in ("v2", "u", "auto"):
         pytest.skip("full-size run: the byte-level and the character-level traversals, and the library's own choice")
     import hashlib
 
@@ -796,7 +791,7 @@ def test_single_large_document_vs_oracle(engine):
     """SURVEY 8d single-document variant: one 256 MiB document, so every chunk
     but the first starts in the middle of a sequence (warm-up overlap at scale).
     Full comparison with the oracle."""
-    if engine not in ("v2", "u", "u2", "h"):
+    if engine not in ("v2", "u"):
         pytest.skip("the byte-level and the character-level traversals")
     import torch
 
@@ -1009,7 +1004,7 @@ def test_group_of_shards_on_one_device(engine, transport, monkeypatch):
     buffer is rebuilt from what RCCL delivered: dlopen of librccl.so, the symbol signatures, ncclInt32,
     ncclCommInitAll and the ordering behind the pack kernels run on this one GPU (only the n > 1 topology does not).
     Same hits and offsets as the single handle and the oracle, in EVERY shard's gathered buffer."""
-    if engine not in ("v2", "u", "h"):
+    if engine not in ("v2", "u"):
         pytest.skip("on the byte-level and on the character-level engine")
     from aha_amd import ACGroup
 

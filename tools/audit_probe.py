@@ -47,7 +47,9 @@ def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "scan_unit.s")
-        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", *sys.argv[1:], "-I", os.path.join(ROOT, "include"),
+        # (the Makefile passes the build's own CXXFLAGS; without arguments: its defaults)
+        flags = sys.argv[1:] or ["-O3", "-std=c++17"]
+        subprocess.check_call([hipcc, *flags, "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
                                "-I", os.path.join(ROOT, "aha_amd", "csrc"), "-S", "--cuda-device-only", "-w", "-o", out,
                                os.path.join(ROOT, "aha_amd", "csrc", "scan_unit.hip")])
         seen, bad = audit(open(out).read())

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AHA_HIP_LIB") or os.path.join(_HERE, "libaha_hip.so")
 SYNTH_PATH = os.path.join(_HERE, "libaha_synth.so")
 
+AHA_ABI_VERSION = 7
 AHA_OK = 0
 AHA_E_INVALID = -1
 AHA_E_EMPTY_KEY = -2
@@ -111,6 +112,9 @@ SIGNATURES = {
                                      C.POINTER(_u64)]),
     "aha_group_last_timing": (_i32, [_vp, C.POINTER(aha_group_timing)]),
     "aha_group_download_shard": (_i32, [_vp, _i32, _vp, _u64, C.POINTER(_u64)]),
+    "aha_group_corpus_upload": (_i32, [_vp, _vp, _vp, _u64, C.POINTER(_vp)]),
+    "aha_group_corpus_free": (None, [_vp]),
+    "aha_group_match_batch_device": (_i32, [_vp, _vp, C.POINTER(aha_match_params), _vp, C.POINTER(_u64)]),
     "aha_buffer_alloc": (_i32, [_i32, _u64, C.POINTER(_vp)]),
     "aha_buffer_free": (_i32, [_i32, _vp]),
     "aha_buffer_upload": (_i32, [_i32, _vp, _vp, _u64]),
@@ -143,6 +147,8 @@ def lib():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
+        if L.aha_abi_version() != AHA_ABI_VERSION:  # structs and entry points below are this version's
+            raise ImportError(f"{LIB_PATH} has ABI {L.aha_abi_version()}, this binding is written for ABI {AHA_ABI_VERSION}")
         _lib = L
     return _lib
 

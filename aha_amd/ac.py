@@ -176,6 +176,7 @@ class AC:
     @property
     def info(self):
         i = N.aha_ac_info_t()
+        i.struct_size = C.sizeof(i)  # (in: the bytes this binding's struct has; the library fills no more)
         self._check(N.lib().aha_ac_info(self._h, C.byref(i)))
         return {f: getattr(i, f) for f, _ in i._fields_ if f != "struct_size"}
 
@@ -308,6 +309,33 @@ class AC:
         self._check(rc)
         return int(n.value)
 
+    def match_batch_keep(self, corpus, doc_offsets, d_hits, chars=False):
+        """aha_ac_match_batch_keep: host corpus in (uploaded range by range beside the matches), the hits stay on the device in
+        d_hits (a torch int32 [cap, 3] tensor on the handle's device); returns (n_hits, per-document offsets)."""
+        corpus = np.ascontiguousarray(corpus, dtype=np.uint8)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        D = doc_offsets.size - 1
+        p = _params(chars, None)
+        dho = np.zeros(D + 1, dtype=np.uint64)
+        n = C.c_uint64(0)
+        rc = N.lib().aha_ac_match_batch_keep(self._h, _ptr(corpus), _ptr(doc_offsets), D, C.byref(p),
+                                             C.c_void_p(d_hits.data_ptr()), d_hits.shape[0], _ptr(dho), C.byref(n))
+        if rc == N.AHA_E_CAPACITY:
+            e = AhaError(rc)
+            e.required = int(n.value)
+            raise e
+        self._check(rc)
+        return int(n.value), dho
+
+    def replicate(self, device):
+        """aha_ac_replicate: a second handle for the same keys on another device -- the host image is copied and uploaded,
+        nothing is compiled again."""
+        h = C.c_void_p()
+        rc = N.lib().aha_ac_replicate(self._h, device, C.byref(h))
+        if rc != N.AHA_OK:
+            raise AhaError(rc)
+        return AC(h)
+
     def match_corpus(self, corpus, cap=None, sep=None, chars=False, longest=0):
         """Matches a batch that already lives in HBM (DeviceCorpus: uploaded once through the C ABI, no GPU framework
         involved) and downloads the hits: -> (hits, doc_hit_offsets).  The upload is not repeated per call."""
@@ -424,6 +452,7 @@ class AC:
 
     def last_timing(self):
         t = N.aha_timing()
+        t.struct_size = C.sizeof(t)
         self._check(N.lib().aha_ac_last_timing(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in t._fields_ if f != "struct_size"}
 
@@ -559,6 +588,29 @@ class ACGroup:
                 raise AhaError(rc, N.lib().aha_group_last_error(self._h).decode() or None)
             return out[: n.value], dho
 
+    def upload_corpus(self, corpus, doc_offsets):
+        """The batch resident on the group's devices (aha_group_corpus_upload): every shard's document range on its device."""
+        if isinstance(corpus, (bytes, bytearray)):
+            corpus = np.frombuffer(bytes(corpus), dtype=np.uint8)
+        corpus = np.ascontiguousarray(corpus, dtype=np.uint8)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        rc = N.lib().aha_group_corpus_upload(self._h, _ptr(corpus), _ptr(doc_offsets), doc_offsets.size - 1, C.byref(h))
+        if rc != N.AHA_OK:
+            raise AhaError(rc, N.lib().aha_group_last_error(self._h).decode() or None)
+        return GroupCorpus(self, h, doc_offsets.size - 1)
+
+    def match_corpus(self, gcorpus, chars=False):
+        """aha_group_match_batch_device: every device matches its resident range, then the all-gatherv; the hits stay on the
+        devices (download_shard reads one device's copy of the whole stream).  Returns (n_hits, per-document offsets)."""
+        p = _params(chars, None)
+        dho = np.zeros(gcorpus.n_docs + 1, dtype=np.uint64)
+        n = C.c_uint64(0)
+        rc = N.lib().aha_group_match_batch_device(self._h, gcorpus._h, C.byref(p), _ptr(dho), C.byref(n))
+        if rc != N.AHA_OK:
+            raise AhaError(rc, N.lib().aha_group_last_error(self._h).decode() or None)
+        return int(n.value), dho
+
     def download_shard(self, shard):
         """The gathered hit stream as device `shard` holds it after the last match_batch (every device holds it all)."""
         n = C.c_uint64(0)
@@ -575,3 +627,18 @@ class ACGroup:
         if rc != N.AHA_OK:
             raise AhaError(rc)
         return {f: getattr(t, f) for f, _ in t._fields_ if f != "struct_size"}
+
+
+class GroupCorpus:
+    """A batch resident on the devices of an ACGroup (aha_group_corpus_*); keeps its group alive."""
+
+    def __init__(self, group, handle, n_docs):
+        self._g, self._h, self.n_docs = group, handle, n_docs
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                N.lib().aha_group_corpus_free(h)
+            except Exception:  # interpreter shutdown
+                pass

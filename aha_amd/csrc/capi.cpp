@@ -21,6 +21,7 @@
 #include "cedar_replay.hpp"
 #include "image.hpp"
 #include "unit.hpp"
+#include "internal.hpp"
 
 using namespace aha;
 
@@ -987,8 +988,19 @@ int32_t aha_ac_load(const void *buf, uint64_t n_bytes, const aha_options *opts, 
   return aha_ac_compile(r + head + offs_bytes, offs.data(), K, opts, out, nullptr);
 }
 
-int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
-  if (!ac || !info) return AHA_E_INVALID;
+// Output structs grow with the ABI: the caller says how many bytes its struct has (struct_size, set before the call) and gets
+// no more than that; 0 -- a caller built before the field was read -- means the size the struct had then (ABI 5).
+static void copy_sized(void *dst, const void *full, uint32_t caller_size, size_t full_size, size_t abi5_size) {
+  const size_t n = caller_size == 0 ? abi5_size : std::min<size_t>(caller_size, full_size);
+  if (n < 4) return;
+  memcpy(dst, full, n);
+  const uint32_t filled = (uint32_t)n;
+  memcpy(dst, &filled, 4);  // struct_size: the bytes that were filled
+}
+
+int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *caller_info) {
+  if (!ac || !caller_info) return AHA_E_INVALID;
+  aha_ac_info_t full, *info = &full;
   memset(info, 0, sizeof(*info));
   info->struct_size = sizeof(*info);
   info->n_keys = ac->aut.n_keys;
@@ -1012,6 +1024,7 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *info) {
   info->unit_n_low = ac->unit.n_low;
   info->unit_n_big = ac->unit.n_big;
   info->unit_base_bits = ac->unit.ok ? ac->unit.base_bits : 0;
+  copy_sized(caller_info, &full, caller_info->struct_size, sizeof(full), sizeof(full) - 24);
   return AHA_OK;
 }
 
@@ -1144,11 +1157,13 @@ int32_t aha_ac_set_profiling(aha_ac *ac, int32_t enabled) {
 
 int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t) {
   if (!ac || !t) return AHA_E_INVALID;
+  aha_timing full;
   {
     std::lock_guard<std::mutex> lk(const_cast<aha_ac *>(ac)->last_mu);
-    *t = ac->last;
+    full = ac->last;
   }
-  t->struct_size = sizeof(*t);
+  full.struct_size = sizeof(full);
+  copy_sized(t, &full, t->struct_size, sizeof(full), sizeof(full) - 8);
   return AHA_OK;
 }
 
@@ -1417,12 +1432,6 @@ static bool host_streams(Scratch *sc) {
 // only the per-document offsets come back to the host.
 // (d_keep AND a host copy: both -- the hits stay on the device and the ranges' hits also go to hc->out[0 .. hc->cap) while
 // they fit; what a shard of a group calls.  The place may become known while the call runs: the copies wait for hc->ready.)
-struct aha_internal_host_copy {
-  aha_hit *out;                // where this call's hits go in host memory (null: nowhere)
-  uint64_t cap;                // room there, in hits
-  volatile int ready;          // set (release) by the caller once out / cap are final
-  volatile int uploads_done;   // set by the call once its text is on the device (or the call is over)
-};
 static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
                                 const aha_match_params *params, aha_hit *out, aha_hit *d_keep, uint64_t cap,
                                 uint64_t *doc_hit_offsets, uint64_t *n_hits, aha_internal_host_copy *hc = nullptr);
@@ -1451,7 +1460,7 @@ int32_t aha_internal_match_batch_keep_copy(aha_ac *ac, const uint8_t *corpus, co
   struct Done {  // whatever way the call ends, whoever waits for its uploads goes on
     aha_internal_host_copy *hc;
     ~Done() {
-      if (hc) __atomic_store_n(&hc->uploads_done, 1, __ATOMIC_RELEASE);
+      if (hc) hc->set_uploads_done();
     }
   } done{hc};
   if (cap && !d_hits) return AHA_E_INVALID;
@@ -1551,7 +1560,7 @@ static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_
       P.uploaded = k + 1;
       P.cv.notify_all();
     }
-    if (hc) __atomic_store_n(&hc->uploads_done, 1, __ATOMIC_RELEASE);  // (a group starts its next shard's uploads now)
+    if (hc) hc->set_uploads_done();  // (a group starts its next shard's uploads now)
   };
   auto downloader = [&]() {
     if (hipSetDevice(device) != hipSuccess) return P.fail(AHA_E_HIP, "hipSetDevice failed");
@@ -1567,7 +1576,7 @@ static int32_t match_batch_host(aha_ac *ac, const uint8_t *corpus, const uint64_
       if (d_keep) {  // the keep form: a copy only where the caller of the library-internal entry has said where to
         to = nullptr;
         if (hc && got[k]) {
-          while (!__atomic_load_n(&hc->ready, __ATOMIC_ACQUIRE)) std::this_thread::yield();  // (set when the shards before have counted)
+          hc->wait_ready();  // (set when the shards before have counted)
           if (hc->out && base[k] + got[k] <= hc->cap) to = hc->out;
         }
       }

@@ -28,18 +28,7 @@
 
 #include "../../include/aha_hip.h"
 
-// library-internal (capi.cpp): aha_ac_match_batch_keep that also copies the ranges' hits to host memory while they fit; the
-// place may become known while the call runs (ready), and the call says when its text is on the device (uploads_done)
-struct aha_internal_host_copy {
-  aha_hit *out;
-  uint64_t cap;
-  volatile int ready;
-  volatile int uploads_done;
-};
-extern "C" int32_t aha_internal_match_batch_keep_copy(aha_ac *ac, const uint8_t *corpus, const uint64_t *doc_offsets,
-                                                      uint64_t n_docs, const aha_match_params *params, aha_hit *d_hits,
-                                                      uint64_t cap, aha_internal_host_copy *hc, uint64_t *doc_hit_offsets,
-                                                      uint64_t *n_hits);
+#include "internal.hpp"
 
 namespace {
 
@@ -133,6 +122,135 @@ struct aha_group {
   std::mutex mu;  // calls on one group are serialised
   uint64_t gathered = 0;  // hits every shard's `all` buffer holds since the last successful exchange
 };
+
+// The all-gatherv of the hit buffers (SURVEY.md section 8 e): every shard holds its own hits in `out` (and, words: their
+// 4-byte stream in `pk`, its length in `nw`, packed behind its match); afterwards every shard's `all` holds the whole ordered
+// stream.  base[r] = hits before shard r, total = all of them.  Fills T.ms_exchange / exchange / packed / wire_bytes.
+static int32_t group_exchange(aha_group *g, const aha_match_params *params, bool words, int via_i, const std::vector<uint64_t> &base,
+                              uint64_t total) {
+  enum Transport { kCopies = 0, kRccl = 1, kSelfRccl = 2 };
+  const Transport via = (Transport)via_i;
+  const size_t n = g->shards.size();
+  aha_group_timing &T = g->last;
+  auto fail = [g](int32_t rc, const std::string &what) {
+    g->err = what;
+    return rc;
+  };
+  const auto t_x = std::chrono::steady_clock::now();
+  for (size_t r = 0; r < n; r++) {
+    Shard &s = g->shards[r];
+    if (hipSetDevice(s.device) != hipSuccess || !s.all.reserve(std::max<uint64_t>(total, 1) * sizeof(aha_hit)))
+      return fail(AHA_E_HIP, "hipMalloc failed for the gathered hits");
+  }
+  const int chars = (params && params->char_offsets) ? 1 : 0;
+  std::vector<uint64_t> ebase(n + 1, 0);  // in 32-bit elements
+  if (words) {  // (every shard has packed its hits behind its match: work() above)
+    for (size_t r = 0; r < n; r++) {
+      Shard &s = g->shards[r];
+      if (hipSetDevice(s.device) != hipSuccess ||
+          hipMemcpyAsync(&s.n_words, s.nw.p, 8, hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
+          hipStreamSynchronize(s.stream) != hipSuccess)
+        return fail(AHA_E_HIP, "reading the stream length failed");
+    }
+  } else {
+    for (size_t r = 0; r < n; r++) g->shards[r].n_words = g->shards[r].n_hits * 3;
+  }
+  for (size_t r = 0; r < n; r++) ebase[r + 1] = ebase[r] + g->shards[r].n_words;
+  T.wire_bytes = 4 * ebase[n];
+  if (words)
+    for (size_t r = 0; r < n; r++) {
+      Shard &s = g->shards[r];
+      if (hipSetDevice(s.device) != hipSuccess || !s.land.reserve(std::max<uint64_t>(ebase[n], 1) * 4))
+        return fail(AHA_E_HIP, "hipMalloc failed for the landing area");
+    }
+  // payload of shard p as shard r sees it arrive: triples land in place, words in the landing area
+  auto landing = [&](Shard &s, size_t p) -> void * {
+    return words ? (void *)((uint32_t *)s.land.p + ebase[p]) : (void *)((aha_hit *)s.all.p + base[p]);
+  };
+  auto payload = [&](const Shard &q) -> const void * { return words ? q.pk.p : q.out.p; };
+  if (via != kCopies) {
+    if (g->comms.empty()) {
+      if (!g->rccl.load(g->err)) return AHA_E_HIP;
+      g->comms.assign(n, nullptr);
+      bool ok = true;
+      if (via == kRccl) {  // one communicator, rank r on devices[r]
+        std::vector<int> devs;
+        for (const Shard &s : g->shards) devs.push_back(s.device);
+        ok = g->rccl.CommInitAll(g->comms.data(), (int)n, devs.data()) == 0;
+      } else {  // rehearsal: one communicator of ONE rank per shard
+        for (size_t r = 0; r < n && ok; r++) {
+          const int dev = g->shards[r].device;
+          ok = g->rccl.CommInitAll(&g->comms[r], 1, &dev) == 0;
+        }
+      }
+      if (!ok) {
+        for (ncclComm_t c : g->comms)
+          if (c) (void)g->rccl.CommDestroy(c);
+        g->comms.clear();
+        return fail(AHA_E_HIP, "ncclCommInitAll failed");
+      }
+    }
+    bool ok = g->rccl.GroupStart() == 0;
+    for (size_t r = 0; r < n && ok; r++) {
+      Shard &s = g->shards[r];
+      ok = hipSetDevice(s.device) == hipSuccess;  // the calls of rank r are made with its device current
+      for (size_t p = 0; p < n && ok; p++) {
+        if (via == kRccl ? p == r : p != r) continue;  // real exchange: every peer; rehearsal: the own stream only
+        const int peer = via == kRccl ? (int)p : 0;
+        if (s.n_words) ok = ok && g->rccl.Send(payload(s), s.n_words, kNcclInt32, peer, g->comms[r], s.stream) == 0;
+        if (g->shards[p].n_words)
+          ok = ok && g->rccl.Recv(landing(s, p), g->shards[p].n_words, kNcclInt32, peer, g->comms[r], s.stream) == 0;
+      }
+    }
+    ok = (g->rccl.GroupEnd() == 0) && ok;
+    if (!ok) return fail(AHA_E_HIP, "RCCL send/recv failed");
+  }
+  if (via != kRccl) {  // shards on one device: the peers' payloads by device-to-device copies
+    for (size_t r = 0; r < n; r++) {
+      Shard &s = g->shards[r];
+      if (hipSetDevice(s.device) != hipSuccess) return fail(AHA_E_HIP, "hipSetDevice failed");
+      for (size_t p = 0; p < n; p++) {
+        const Shard &q = g->shards[p];
+        if (p != r && q.n_words &&
+            hipMemcpyAsync(landing(s, p), payload(q), q.n_words * 4, hipMemcpyDeviceToDevice, s.stream) != hipSuccess)
+          return fail(AHA_E_HIP, "device-to-device copy failed");
+      }
+    }
+  }
+  // the own part as it is (unless it came back through RCCL: then it is rebuilt like a peer's, so the test of the
+  // rehearsal checks the bytes RCCL delivered); all streams that arrived are rebuilt into triples by ONE launch
+  const bool own_via_rccl = via == kSelfRccl;
+  for (size_t r = 0; r < n; r++) {
+    Shard &s = g->shards[r];
+    if (hipSetDevice(s.device) != hipSuccess) return fail(AHA_E_HIP, "hipSetDevice failed");
+    if (s.n_hits && !own_via_rccl &&
+        hipMemcpyAsync((aha_hit *)s.all.p + base[r], s.out.p, s.n_hits * sizeof(aha_hit), hipMemcpyDeviceToDevice,
+                       s.stream) != hipSuccess)
+      return fail(AHA_E_HIP, "device-to-device copy failed");
+    if (!words) continue;  // triples landed in place
+    std::vector<aha_stream_seg> segs;
+    for (size_t p = 0; p < n; p++) {
+      if ((p == r && !own_via_rccl) || !g->shards[p].n_hits) continue;
+      segs.push_back(aha_stream_seg{ebase[p], g->shards[p].n_hits, base[p]});
+    }
+    for (size_t k = 0; k < segs.size(); k += 64) {
+      int32_t rc = aha_ac_hits_unpack4_segs_device(s.ac, (const uint32_t *)s.land.p, segs.data() + k,
+                                                   (uint32_t)std::min<size_t>(64, segs.size() - k), chars,
+                                                   (aha_hit *)s.all.p, s.stream);
+      if (rc != AHA_OK) return fail(rc, std::string("rebuild: ") + aha_last_error(s.ac));
+    }
+  }
+  for (size_t r = 0; r < n; r++) {
+    Shard &s = g->shards[r];
+    if (hipSetDevice(s.device) != hipSuccess || hipStreamSynchronize(s.stream) != hipSuccess)
+      return fail(AHA_E_HIP, "exchange failed");
+  }
+  T.ms_exchange = (float)ms_since(t_x);
+  T.exchange = (uint32_t)via;
+  T.packed = words ? 1u : 0u;
+  g->gathered = total;
+  return AHA_OK;
+}
 
 extern "C" {
 
@@ -370,25 +488,21 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     // beside the next shard's first upload); where its hits go is told when the shards before it have counted (`ready`) --
     // its pipeline only needs that for the copies to the host, which wait for it.
     std::vector<aha_internal_host_copy> hc(n);
-    for (size_t r = 0; r < n; r++) {
-      hc[r] = aha_internal_host_copy{nullptr, 0, 0, 0};
-      g->shards[r].hc = &hc[r];
-    }
+    for (size_t r = 0; r < n; r++) g->shards[r].hc = &hc[r];
     for (size_t r = 0; r < n; r++) {
       try {
         th.emplace_back([&, r]() {
-          if (r)  // (set by the shard's call, however it ends, and once more below)
-            while (!__atomic_load_n(&hc[r - 1].uploads_done, __ATOMIC_ACQUIRE)) std::this_thread::yield();
+          if (r) hc[r - 1].wait_uploads_done();  // (set by the shard's call, however it ends, and once more below)
           try {
             work(r);
           } catch (...) {
             g->shards[r].rc = AHA_E_NOMEM;
             g->shards[r].err = "out of host memory";
           }
-          __atomic_store_n(&hc[r].uploads_done, 1, __ATOMIC_RELEASE);
+          hc[r].set_uploads_done();
         });
       } catch (...) {
-        for (size_t q = r; q < n; q++) __atomic_store_n(&hc[q].uploads_done, 1, __ATOMIC_RELEASE);
+        for (size_t q = r; q < n; q++) hc[q].set_uploads_done();
         break;  // thread creation failed: the shards started so far are joined below, the rest keep AHA_E_NOMEM
       }
     }
@@ -396,11 +510,10 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     bool dead = false;
     for (size_t r = 0; r < th.size(); r++) {
       Shard &s = g->shards[r];
-      if (!dead && out && at < cap) {
-        hc[r].out = out + at;
-        hc[r].cap = cap - at;
-      }
-      __atomic_store_n(&hc[r].ready, 1, __ATOMIC_RELEASE);
+      if (!dead && out && at < cap)
+        hc[r].set_ready(out + at, cap - at);
+      else
+        hc[r].set_ready(nullptr, 0);
       th[r].join();
       if (s.rc != AHA_OK) dead = true;  // (the later shards still run to their end; the call reports this one)
       // (a shard whose hits did not all fit the rest of the caller's buffer: AHA_E_CAPACITY below, nothing is written beyond cap)
@@ -439,125 +552,224 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
     if (!dl_started[r]) start_download(r, base[r]);
 
   // ---- all-gatherv of the hit buffers: every device gets the whole ordered stream
-  const auto t_x = std::chrono::steady_clock::now();
-  for (size_t r = 0; r < n; r++) {
-    Shard &s = g->shards[r];
-    if (hipSetDevice(s.device) != hipSuccess || !s.all.reserve(std::max<uint64_t>(total, 1) * sizeof(aha_hit)))
-      return fail(AHA_E_HIP, "hipMalloc failed for the gathered hits");
+  {
+    const int32_t xrc = group_exchange(g, params, words, (int)via, base, total);
+    if (xrc != AHA_OK) return xrc;
   }
-  const int chars = (params && params->char_offsets) ? 1 : 0;
-  std::vector<uint64_t> ebase(n + 1, 0);  // in 32-bit elements
-  if (words) {  // (every shard has packed its hits behind its match: work() above)
-    for (size_t r = 0; r < n; r++) {
-      Shard &s = g->shards[r];
-      if (hipSetDevice(s.device) != hipSuccess ||
-          hipMemcpyAsync(&s.n_words, s.nw.p, 8, hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
-          hipStreamSynchronize(s.stream) != hipSuccess)
-        return fail(AHA_E_HIP, "reading the stream length failed");
-    }
-  } else {
-    for (size_t r = 0; r < n; r++) g->shards[r].n_words = g->shards[r].n_hits * 3;
-  }
-  for (size_t r = 0; r < n; r++) ebase[r + 1] = ebase[r] + g->shards[r].n_words;
-  T.wire_bytes = 4 * ebase[n];
-  if (words)
-    for (size_t r = 0; r < n; r++) {
-      Shard &s = g->shards[r];
-      if (hipSetDevice(s.device) != hipSuccess || !s.land.reserve(std::max<uint64_t>(ebase[n], 1) * 4))
-        return fail(AHA_E_HIP, "hipMalloc failed for the landing area");
-    }
-  // payload of shard p as shard r sees it arrive: triples land in place, words in the landing area
-  auto landing = [&](Shard &s, size_t p) -> void * {
-    return words ? (void *)((uint32_t *)s.land.p + ebase[p]) : (void *)((aha_hit *)s.all.p + base[p]);
-  };
-  auto payload = [&](const Shard &q) -> const void * { return words ? q.pk.p : q.out.p; };
-  if (via != kCopies) {
-    if (g->comms.empty()) {
-      if (!g->rccl.load(g->err)) return AHA_E_HIP;
-      g->comms.assign(n, nullptr);
-      bool ok = true;
-      if (via == kRccl) {  // one communicator, rank r on devices[r]
-        std::vector<int> devs;
-        for (const Shard &s : g->shards) devs.push_back(s.device);
-        ok = g->rccl.CommInitAll(g->comms.data(), (int)n, devs.data()) == 0;
-      } else {  // rehearsal: one communicator of ONE rank per shard
-        for (size_t r = 0; r < n && ok; r++) {
-          const int dev = g->shards[r].device;
-          ok = g->rccl.CommInitAll(&g->comms[r], 1, &dev) == 0;
-        }
-      }
-      if (!ok) {
-        for (ncclComm_t c : g->comms)
-          if (c) (void)g->rccl.CommDestroy(c);
-        g->comms.clear();
-        return fail(AHA_E_HIP, "ncclCommInitAll failed");
-      }
-    }
-    bool ok = g->rccl.GroupStart() == 0;
-    for (size_t r = 0; r < n && ok; r++) {
-      Shard &s = g->shards[r];
-      ok = hipSetDevice(s.device) == hipSuccess;  // the calls of rank r are made with its device current
-      for (size_t p = 0; p < n && ok; p++) {
-        if (via == kRccl ? p == r : p != r) continue;  // real exchange: every peer; rehearsal: the own stream only
-        const int peer = via == kRccl ? (int)p : 0;
-        if (s.n_words) ok = ok && g->rccl.Send(payload(s), s.n_words, kNcclInt32, peer, g->comms[r], s.stream) == 0;
-        if (g->shards[p].n_words)
-          ok = ok && g->rccl.Recv(landing(s, p), g->shards[p].n_words, kNcclInt32, peer, g->comms[r], s.stream) == 0;
-      }
-    }
-    ok = (g->rccl.GroupEnd() == 0) && ok;
-    if (!ok) return fail(AHA_E_HIP, "RCCL send/recv failed");
-  }
-  if (via != kRccl) {  // shards on one device: the peers' payloads by device-to-device copies
-    for (size_t r = 0; r < n; r++) {
-      Shard &s = g->shards[r];
-      if (hipSetDevice(s.device) != hipSuccess) return fail(AHA_E_HIP, "hipSetDevice failed");
-      for (size_t p = 0; p < n; p++) {
-        const Shard &q = g->shards[p];
-        if (p != r && q.n_words &&
-            hipMemcpyAsync(landing(s, p), payload(q), q.n_words * 4, hipMemcpyDeviceToDevice, s.stream) != hipSuccess)
-          return fail(AHA_E_HIP, "device-to-device copy failed");
-      }
-    }
-  }
-  // the own part as it is (unless it came back through RCCL: then it is rebuilt like a peer's, so the test of the
-  // rehearsal checks the bytes RCCL delivered); all streams that arrived are rebuilt into triples by ONE launch
-  const bool own_via_rccl = via == kSelfRccl;
-  for (size_t r = 0; r < n; r++) {
-    Shard &s = g->shards[r];
-    if (hipSetDevice(s.device) != hipSuccess) return fail(AHA_E_HIP, "hipSetDevice failed");
-    if (s.n_hits && !own_via_rccl &&
-        hipMemcpyAsync((aha_hit *)s.all.p + base[r], s.out.p, s.n_hits * sizeof(aha_hit), hipMemcpyDeviceToDevice,
-                       s.stream) != hipSuccess)
-      return fail(AHA_E_HIP, "device-to-device copy failed");
-    if (!words) continue;  // triples landed in place
-    std::vector<aha_stream_seg> segs;
-    for (size_t p = 0; p < n; p++) {
-      if ((p == r && !own_via_rccl) || !g->shards[p].n_hits) continue;
-      segs.push_back(aha_stream_seg{ebase[p], g->shards[p].n_hits, base[p]});
-    }
-    for (size_t k = 0; k < segs.size(); k += 64) {
-      int32_t rc = aha_ac_hits_unpack4_segs_device(s.ac, (const uint32_t *)s.land.p, segs.data() + k,
-                                                   (uint32_t)std::min<size_t>(64, segs.size() - k), chars,
-                                                   (aha_hit *)s.all.p, s.stream);
-      if (rc != AHA_OK) return fail(rc, std::string("rebuild: ") + aha_last_error(s.ac));
-    }
-  }
-  for (size_t r = 0; r < n; r++) {
-    Shard &s = g->shards[r];
-    if (hipSetDevice(s.device) != hipSuccess || hipStreamSynchronize(s.stream) != hipSuccess)
-      return fail(AHA_E_HIP, "exchange failed");
-  }
-  T.ms_exchange = (float)ms_since(t_x);
-  T.exchange = (uint32_t)via;
-  T.packed = words ? 1u : 0u;
-  g->gathered = total;
   for (auto &x : dl)
     if (x.joinable()) x.join();
   for (size_t r = 0; r < n; r++)
     if (dl_rc[r]) return fail(AHA_E_HIP, "download of a shard's hits failed");
   T.ms_download = (float)ms_since(t_d);  // (from the first download's start: it runs beside the exchange)
   return AHA_OK;
+}
+
+// ---- the batch resident on the devices: what a caller that keeps its corpus in HBM (the metric's "corpus resident") calls
+
+struct aha_group_corpus {
+  aha_group *g = nullptr;
+  std::vector<aha_corpus *> parts;  // shard r's documents on shard r's device
+  std::vector<uint64_t> bounds;     // document bounds of the shards
+  uint64_t n_docs = 0, n_bytes = 0;
+};
+
+int32_t aha_group_corpus_upload(aha_group *g, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                                aha_group_corpus **out) {
+  if (!g || !doc_offsets || !out) return AHA_E_INVALID;
+  *out = nullptr;
+  if (doc_offsets[0] != 0) return AHA_E_INVALID;
+  for (uint64_t d = 0; d < n_docs; d++) {
+    if (doc_offsets[d + 1] < doc_offsets[d]) return AHA_E_INVALID;
+    if (doc_offsets[d + 1] - doc_offsets[d] >= 0x7FFFFFFFull) return AHA_E_TOO_LONG;
+  }
+  const uint64_t N = doc_offsets[n_docs];
+  if (N && !corpus) return AHA_E_INVALID;
+  std::lock_guard<std::mutex> lk(g->mu);
+  const size_t n = g->shards.size();
+  aha_group_corpus *c = nullptr;
+  try {
+    c = new aha_group_corpus();
+    c->g = g;
+    c->n_docs = n_docs;
+    c->n_bytes = N;
+    c->parts.assign(n, nullptr);
+    c->bounds.assign(n + 1, 0);
+    (void)aha_group_partition(doc_offsets, n_docs, (int32_t)n, c->bounds.data());
+    // every device takes its range over its own PCIe link: a thread per shard (shards that share a device take turns on it)
+    std::vector<int32_t> rcs(n, AHA_OK);
+    std::vector<std::thread> th;
+    auto up = [&](size_t r) {
+      const uint64_t d0 = c->bounds[r], d1 = c->bounds[r + 1], b0 = doc_offsets[d0];
+      try {
+        std::vector<uint64_t> rel(d1 - d0 + 1);
+        for (uint64_t d = d0; d <= d1; d++) rel[d - d0] = doc_offsets[d] - b0;
+        rcs[r] = aha_corpus_upload(g->shards[r].device, corpus ? corpus + b0 : nullptr, rel.data(), d1 - d0, &c->parts[r]);
+      } catch (...) {
+        rcs[r] = AHA_E_NOMEM;
+      }
+    };
+    if (g->distinct && n > 1) {
+      for (size_t r = 0; r < n; r++) th.emplace_back(up, r);
+      for (auto &t : th) t.join();
+    } else {
+      for (size_t r = 0; r < n; r++) up(r);
+    }
+    for (size_t r = 0; r < n; r++)
+      if (rcs[r] != AHA_OK) {
+        g->err = "shard " + std::to_string(r) + ": upload of its documents failed";
+        const int32_t rc = rcs[r];
+        for (aha_corpus *p : c->parts) aha_corpus_free(p);
+        delete c;
+        return rc;
+      }
+  } catch (...) {
+    if (c) {
+      for (aha_corpus *p : c->parts) aha_corpus_free(p);
+      delete c;
+    }
+    return AHA_E_NOMEM;
+  }
+  *out = c;
+  return AHA_OK;
+}
+
+void aha_group_corpus_free(aha_group_corpus *c) {
+  if (!c) return;
+  for (aha_corpus *p : c->parts) aha_corpus_free(p);
+  delete c;
+}
+
+int32_t aha_group_match_batch_device(aha_group *g, const aha_group_corpus *c, const aha_match_params *params,
+                                     uint64_t *doc_hit_offsets, uint64_t *n_hits) {
+  if (!g || !c || !n_hits || c->g != g) return AHA_E_INVALID;
+  std::lock_guard<std::mutex> lk(g->mu);
+  auto fail = [g](int32_t rc, const std::string &what) {
+    g->err = what;
+    return rc;
+  };
+  g->gathered = 0;
+  *n_hits = 0;
+  const size_t n = g->shards.size();
+  if (c->parts.size() != n) return AHA_E_INVALID;
+  aha_group_timing &T = g->last;
+  memset(&T, 0, sizeof(T));
+  T.struct_size = sizeof(T);
+  T.n_devices = (uint32_t)n;
+  enum Transport { kCopies = 0, kRccl = 1, kSelfRccl = 2 };
+  const Transport via = (g->distinct && n > 1) ? kRccl : (g->self_rccl ? kSelfRccl : kCopies);
+  aha_ac_info_t info{};
+  info.struct_size = sizeof(info);
+  (void)aha_ac_info(g->shards[0].ac, &info);
+  uint32_t sf_step = 0, sf_len = 0;
+  const bool fits = aha_ac_stream_format(g->shards[0].ac, &sf_step, &sf_len) == AHA_OK && (sf_len != 0 || info.n_keys <= (1u << 20));
+  const bool words = (n > 1 || via == kSelfRccl) && fits;
+
+  // ---- every device matches its resident range (a host thread per shard: the calls block), packs its exchange stream
+  const auto t_all = std::chrono::steady_clock::now();
+  auto work = [&](size_t r) {
+    Shard &s = g->shards[r];
+    const aha_corpus *part = c->parts[r];
+    const uint64_t D = aha_corpus_n_docs(part), nb = aha_corpus_n_bytes(part);
+    s.d0 = c->bounds[r];
+    s.d1 = c->bounds[r + 1];
+    s.rc = AHA_OK;
+    s.n_hits = 0;
+    s.err.clear();
+    if (hipSetDevice(s.device) != hipSuccess) {
+      s.rc = AHA_E_HIP;
+      s.err = "hipSetDevice failed";
+      return;
+    }
+    // room for one hit per 16 input bytes up front (what is there from earlier calls stays); a denser shard reports its
+    // exact count and is matched once more
+    const uint64_t want = std::max<uint64_t>(s.out.bytes / sizeof(aha_hit), nb / 16 + 4096);
+    if (!s.out.reserve(want * sizeof(aha_hit)) || !s.dho.reserve((D + 1) * 8)) {
+      s.rc = AHA_E_HIP;
+      s.err = "hipMalloc failed for the shard's buffers";
+      return;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int attempt = 0; attempt < 2; attempt++) {
+      uint64_t nh = 0;
+      s.rc = aha_ac_match_batch_device(s.ac, aha_corpus_bytes(part), aha_corpus_doc_offsets(part), D, nb, params, (aha_hit *)s.out.p,
+                                       s.out.bytes / sizeof(aha_hit), (uint64_t *)s.dho.p, &nh, s.stream);
+      s.n_hits = nh;
+      if (s.rc != AHA_E_CAPACITY) break;
+      if (!s.out.reserve(nh * sizeof(aha_hit))) {
+        s.rc = AHA_E_HIP;
+        s.err = "hipMalloc failed for the shard's hits";
+        return;
+      }
+    }
+    s.ms_match = ms_since(t0);
+    if (s.rc != AHA_OK) {
+      s.err = aha_last_error(s.ac);
+      return;
+    }
+    if (doc_hit_offsets) {
+      s.h_dho.assign(D + 1, 0);
+      if (hipMemcpyAsync(s.h_dho.data(), s.dho.p, (D + 1) * 8, hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
+          hipStreamSynchronize(s.stream) != hipSuccess) {
+        s.rc = AHA_E_HIP;
+        s.err = "download of the per-document offsets failed";
+        return;
+      }
+    }
+    if (words) {
+      const uint64_t capw = 2 * s.n_hits + (s.n_hits + 1023) / 1024 + 16;
+      if (!s.pk.reserve(capw * 4) || !s.nw.reserve(8)) {
+        s.rc = AHA_E_HIP;
+        s.err = "hipMalloc failed for the packed stream";
+        return;
+      }
+      s.rc = aha_ac_hits_pack4_device(s.ac, (const aha_hit *)s.out.p, s.n_hits, (uint32_t *)s.pk.p, capw, (uint64_t *)s.nw.p,
+                                      s.stream);
+      if (s.rc != AHA_OK) s.err = std::string("pack: ") + aha_last_error(s.ac);
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < n; r++) {
+      g->shards[r].rc = AHA_E_NOMEM;
+      g->shards[r].err = "worker thread not started";
+    }
+    for (size_t r = 0; r < n; r++) {
+      try {
+        th.emplace_back([&, r]() {
+          try {
+            work(r);
+          } catch (...) {
+            g->shards[r].rc = AHA_E_NOMEM;
+            g->shards[r].err = "out of host memory";
+          }
+        });
+      } catch (...) {
+        break;
+      }
+    }
+    for (auto &t : th) t.join();
+  }
+  T.ms_match = (float)ms_since(t_all);
+  uint64_t total = 0;
+  std::vector<uint64_t> base(n + 1, 0);
+  for (size_t r = 0; r < n; r++) {
+    Shard &s = g->shards[r];
+    if (s.rc != AHA_OK) return fail(s.rc, std::string("shard ") + std::to_string(r) + ": " + s.err);
+    T.ms_match_max_shard = std::max(T.ms_match_max_shard, (float)s.ms_match);
+    base[r] = total;
+    total += s.n_hits;
+  }
+  base[n] = total;
+  *n_hits = total;
+  T.n_hits = total;
+  if (doc_hit_offsets) {
+    for (size_t r = 0; r < n; r++) {
+      const Shard &s = g->shards[r];
+      for (uint64_t d = s.d0; d < s.d1; d++) doc_hit_offsets[d] = base[r] + s.h_dho[d - s.d0];
+    }
+    doc_hit_offsets[c->n_docs] = total;
+  }
+  return group_exchange(g, params, words, (int)via, base, total);
 }
 
 int32_t aha_group_download_shard(aha_group *g, int32_t shard, aha_hit *out, uint64_t cap, uint64_t *n_hits) {

@@ -183,6 +183,12 @@ lib LibAhaHip
   fun aha_group_partition(doc_offsets : UInt64*, n_docs : UInt64, n_parts : Int32, bounds : UInt64*) : Int32
   fun aha_group_download_shard(g : Group, shard : Int32, out : Hit*, cap : UInt64, n_hits : UInt64*) : Int32
   fun aha_group_last_timing(g : Group, t : GroupTiming*) : Int32
+  # ABI 7: the batch resident on the group's devices
+  type GroupCorpus = Void*
+  fun aha_group_corpus_upload(g : Group, corpus : UInt8*, doc_offsets : UInt64*, n_docs : UInt64, out_c : GroupCorpus*) : Int32
+  fun aha_group_corpus_free(c : GroupCorpus) : Void
+  fun aha_group_match_batch_device(g : Group, c : GroupCorpus, params : MatchParams*, doc_hit_offsets : UInt64*,
+                                   n_hits : UInt64*) : Int32
   fun aha_group_match_batch(g : Group, corpus : UInt8*, doc_offsets : UInt64*, n_docs : UInt64,
                             params : MatchParams*, out : Hit*, cap : UInt64,
                             doc_hit_offsets : UInt64*, n_hits : UInt64*) : Int32
@@ -448,6 +454,50 @@ module Aha
         break
       end
       result
+    end
+
+    # The batch resident on the devices (aha_group_corpus_upload): every shard's documents on its device, uploaded once.
+    class Corpus
+      getter handle : LibAhaHip::GroupCorpus
+      getter n_docs : Int32
+
+      def initialize(@handle, @n_docs)
+      end
+
+      def finalize
+        LibAhaHip.aha_group_corpus_free(@handle)
+      end
+    end
+
+    def upload(docs : Array(String) | Array(Bytes)) : Corpus
+      corpus = IO::Memory.new
+      offs = Array(UInt64).new(docs.size + 1)
+      offs << 0_u64
+      docs.each do |d|
+        corpus.write(d.is_a?(String) ? d.to_slice : d)
+        offs << corpus.pos.to_u64
+      end
+      rc = LibAhaHip.aha_group_corpus_upload(@group, corpus.to_slice.to_unsafe, offs.to_unsafe, docs.size.to_u64, out c)
+      raise String.new(LibAhaHip.aha_strerror(rc)) if rc != 0
+      Corpus.new(c, docs.size)
+    end
+
+    # Every device matches its resident range, then the all-gatherv; the hits stay on the devices (every device holds the
+    # whole ordered stream).  Returns the hit count and the per-document hit offsets; `shard_hits` reads one device's copy.
+    def match_resident(c : Corpus, chars : Bool = false) : {UInt64, Array(UInt64)}
+      params = AC.params(chars, nil)
+      dho = Array(UInt64).new(c.n_docs + 1, 0_u64)
+      rc = LibAhaHip.aha_group_match_batch_device(@group, c.handle, pointerof(params), dho.to_unsafe, out n)
+      raise String.new(LibAhaHip.aha_strerror(rc)) if rc != 0
+      {n, dho}
+    end
+
+    def shard_hits(shard : Int32) : Array(Hit)
+      LibAhaHip.aha_group_download_shard(@group, shard, Pointer(LibAhaHip::Hit).null, 0_u64, out n)
+      buf = Pointer(LibAhaHip::Hit).malloc(n + 1)
+      rc = LibAhaHip.aha_group_download_shard(@group, shard, buf, n + 1, out got)
+      raise String.new(LibAhaHip.aha_strerror(rc)) if rc != 0
+      Array(Hit).new(got.to_i32) { |i| Hit.new(buf[i].start, buf[i].end_, buf[i].value) }
     end
   end
 end

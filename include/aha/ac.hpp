@@ -260,4 +260,107 @@ class AC {
 // Aha::ACBig = ACX(Int64) (src/aha/ac.cr:9): wider node ids, the same Hit with an Int32 value (ac.cr:273)
 using ACBig = AC;
 
+// Several GPUs of one node behind one object (aha_group_*): contiguous byte-balanced document ranges, one per device entry,
+// all-gatherv of the hit buffers.  match_batch: host buffers in and out; upload + match_resident: the batch stays on the
+// devices, the hits too (shard_hits reads one device's copy of the whole ordered stream).
+class Group {
+ public:
+  Group(const Group &) = delete;
+  Group &operator=(const Group &) = delete;
+  ~Group() { aha_group_free(g_); }
+
+  static Group compile(const std::vector<std::string> &keys, const std::vector<int32_t> &devices) {
+    if (aha_abi_version() != AHA_ABI_VERSION) throw Error(AHA_E_INVALID, "libaha_hip.so is not the ABI this header declares");
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> offs(keys.size() + 1, 0);
+    for (size_t i = 0; i < keys.size(); i++) {
+      blob.insert(blob.end(), keys[i].begin(), keys[i].end());
+      offs[i + 1] = blob.size();
+    }
+    aha_group *g = nullptr;
+    uint32_t bad = 0;
+    int32_t rc = aha_group_compile(blob.data(), offs.data(), (uint32_t)keys.size(), devices.data(), (int32_t)devices.size(), 0, &g,
+                                   &bad);
+    if (rc == AHA_E_DUP_KEY) throw Error(rc, "key:" + keys[bad] + " appear twice.", bad);
+    if (rc != AHA_OK) throw Error(rc, aha_strerror(rc), bad);
+    return Group(g);
+  }
+  Group(Group &&o) noexcept : g_(o.g_) { o.g_ = nullptr; }
+
+  std::vector<Hit> match_batch(std::string_view corpus, const std::vector<uint64_t> &doc_offsets,
+                               std::vector<uint64_t> *doc_hit_offsets = nullptr, bool chars = false) const {
+    if (doc_offsets.empty()) throw Error(AHA_E_INVALID, "doc_offsets holds D + 1 entries");
+    aha_match_params p{};
+    p.struct_size = sizeof(p);
+    p.char_offsets = chars ? 1 : 0;
+    std::vector<uint64_t> dho(doc_offsets.size(), 0);
+    std::vector<Hit> out(corpus.size() / 8 + 64);
+    uint64_t n = 0;
+    for (;;) {
+      int32_t rc = aha_group_match_batch(g_, reinterpret_cast<const uint8_t *>(corpus.data()), doc_offsets.data(),
+                                         doc_offsets.size() - 1, &p, out.data(), out.size(), dho.data(), &n);
+      if (rc == AHA_E_CAPACITY) {
+        out.resize(n);
+        continue;
+      }
+      if (rc != AHA_OK) throw Error(rc, aha_group_last_error(g_));
+      break;
+    }
+    out.resize(n);
+    if (doc_hit_offsets) *doc_hit_offsets = dho;
+    return out;
+  }
+
+  // the batch resident on the devices (aha_group_corpus_upload); must not outlive its group
+  class Resident {
+   public:
+    Resident(const Resident &) = delete;
+    Resident &operator=(const Resident &) = delete;
+    Resident(Resident &&o) noexcept : c_(o.c_), n_docs_(o.n_docs_) { o.c_ = nullptr; }
+    ~Resident() { aha_group_corpus_free(c_); }
+    uint64_t n_docs() const { return n_docs_; }
+    const aha_group_corpus *handle() const { return c_; }
+
+   private:
+    friend class Group;
+    Resident(aha_group_corpus *c, uint64_t n) : c_(c), n_docs_(n) {}
+    aha_group_corpus *c_;
+    uint64_t n_docs_;
+  };
+  Resident upload(std::string_view corpus, const std::vector<uint64_t> &doc_offsets) const {
+    if (doc_offsets.empty()) throw Error(AHA_E_INVALID, "doc_offsets holds D + 1 entries");
+    aha_group_corpus *c = nullptr;
+    int32_t rc = aha_group_corpus_upload(g_, reinterpret_cast<const uint8_t *>(corpus.data()), doc_offsets.data(),
+                                         doc_offsets.size() - 1, &c);
+    if (rc != AHA_OK) throw Error(rc, aha_group_last_error(g_));
+    return Resident(c, doc_offsets.size() - 1);
+  }
+  // every device matches its resident range, then the all-gatherv: the hit count (the hits stay on the devices)
+  uint64_t match_resident(const Resident &c, std::vector<uint64_t> *doc_hit_offsets = nullptr, bool chars = false) const {
+    aha_match_params p{};
+    p.struct_size = sizeof(p);
+    p.char_offsets = chars ? 1 : 0;
+    std::vector<uint64_t> dho(c.n_docs() + 1, 0);
+    uint64_t n = 0;
+    int32_t rc = aha_group_match_batch_device(g_, c.handle(), &p, dho.data(), &n);
+    if (rc != AHA_OK) throw Error(rc, aha_group_last_error(g_));
+    if (doc_hit_offsets) *doc_hit_offsets = dho;
+    return n;
+  }
+  std::vector<Hit> shard_hits(int32_t shard) const {
+    uint64_t n = 0;
+    aha_group_download_shard(g_, shard, nullptr, 0, &n);
+    std::vector<Hit> out(n + 1);
+    int32_t rc = aha_group_download_shard(g_, shard, out.data(), out.size(), &n);
+    if (rc != AHA_OK) throw Error(rc, aha_group_last_error(g_));
+    out.resize(n);
+    return out;
+  }
+  aha_group *handle() const { return g_; }
+
+ private:
+  explicit Group(aha_group *g) : g_(g) {}
+  aha_group *g_;
+};
+
 }  // namespace aha

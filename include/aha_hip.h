@@ -41,7 +41,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define AHA_ABI_VERSION 6
+#define AHA_ABI_VERSION 7
 
 /* Aha::Hit -- src/aha/matcher.cr:2-11.  Half-open [start,end) offsets
  * relative to the start of the sequence (document); value = key index in
@@ -374,6 +374,19 @@ int32_t aha_group_match_batch(aha_group *g, const uint8_t *corpus, const uint64_
  * whole ordered stream: this is how a test, or a caller that wants a particular device's copy, reads it back). */
 int32_t aha_group_download_shard(aha_group *g, int32_t shard, aha_hit *out, uint64_t cap, uint64_t *n_hits);
 int32_t aha_group_last_timing(const aha_group *g, aha_group_timing *t);
+/* ABI 7 -- the batch RESIDENT on the group's devices (the group counterpart of aha_corpus_upload + aha_ac_match_batch_device;
+ * keeps the reference's one call per batch, src/aha/ac.cr:280-286): aha_group_corpus_upload partitions the documents like
+ * aha_group_match_batch does and leaves every shard's range on its device (each over its own PCIe link);
+ * aha_group_match_batch_device matches the resident ranges, every device its own, and runs the same all-gatherv -- nothing of
+ * the batch crosses PCIe any more.  The hits stay on the devices: every device holds the whole ordered stream
+ * (aha_group_download_shard reads one device's copy); *n_hits and doc_hit_offsets (n_docs + 1 entries, optional) are host
+ * memory.  A corpus belongs to the group it was uploaded for and must be freed before that group. */
+typedef struct aha_group_corpus aha_group_corpus;
+int32_t aha_group_corpus_upload(aha_group *g, const uint8_t *corpus, const uint64_t *doc_offsets, uint64_t n_docs,
+                                aha_group_corpus **out);
+void aha_group_corpus_free(aha_group_corpus *c);
+int32_t aha_group_match_batch_device(aha_group *g, const aha_group_corpus *c, const aha_match_params *params,
+                                     uint64_t *doc_hit_offsets, uint64_t *n_hits);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

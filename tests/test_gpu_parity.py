@@ -1025,6 +1025,18 @@ def test_group_of_shards_on_one_device(engine, transport, monkeypatch):
     t = grp.last_timing()
     assert t["n_devices"] == 3 and t["exchange"] == (2 if transport == "self-rccl" else 0) and t["n_hits"] == len(oh)
     assert t["packed"] == 1 and t["wire_bytes"] < 4.3 * len(oh)  # the 4-byte stream travelled between the shards
+    # the resident entry (aha_group_corpus_upload + aha_group_match_batch_device): the ranges stay on the devices, the hits too
+    res = grp.upload_corpus(corpus, doc)
+    for chars in (True, False):
+        oh, od = o.match_batch(corpus, doc, chars=chars)
+        for _ in range(2):  # (the second call meets buffers of the right size)
+            n, gd = grp.match_corpus(res, chars=chars)
+            assert n == len(oh) and np.array_equal(gd, od)
+            for shard in range(3):
+                assert grp.download_shard(shard).tobytes() == oh.tobytes(), (chars, shard)
+    t = grp.last_timing()
+    assert t["n_devices"] == 3 and t["n_hits"] == len(oh) and t["packed"] == 1
+    del res
     if transport == "self-rccl":  # a group of ONE shard has nothing to exchange -- except in this mode
         g1 = ACGroup.compile_packed(blob, offs, [0])
         gh, gd = g1.match_batch(corpus, doc)
@@ -1228,3 +1240,35 @@ def test_sequence_longer_than_int32_is_rejected():
     n = C.c_uint64(0)
     rc = N.lib().aha_ac_match_batch(ac._h, t.ctypes.data, offs.ctypes.data, 1, None, None, 0, None, C.byref(n))
     assert rc == N.AHA_E_TOO_LONG
+
+
+def test_hits_kept_on_the_device_and_a_replicated_handle(engine):
+    """aha_ac_match_batch_keep (host corpus in, hits left in the caller's device buffer) gives the hits of aha_ac_match_batch,
+    also over several ~64 MiB ranges; aha_ac_replicate's copy (same keys, nothing compiled again) matches like the oracle."""
+    if engine not in ("v2", "auto"):
+        pytest.skip("on the byte-level engine and on the library's own choice")
+    import torch
+
+    blob, offs, nf = synth.keys(3, K=20_000)
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=160 << 20, doc_bytes=1 << 20)
+    ac = AC.compile_packed(blob, offs)
+    for chars in (False, True):
+        want, wd = ac.match_batch(corpus, doc, chars=chars, cap=corpus.size // 16)
+        d_hits = torch.zeros((len(want) + 8, 3), dtype=torch.int32, device="cuda")
+        n, gd = ac.match_batch_keep(corpus, doc, d_hits, chars=chars)
+        assert n == len(want) and np.array_equal(gd, wd)
+        assert d_hits[:n].cpu().numpy().tobytes() == want.tobytes()
+        with pytest.raises(AhaError) as e:  # a buffer one hit short: the count, no overrun
+            ac.match_batch_keep(corpus, doc, d_hits[: n - 1], chars=chars)
+        assert e.value.code == N.AHA_E_CAPACITY and e.value.required == n
+    twin = ac.replicate(0)
+    assert twin.info["n_keys"] == ac.info["n_keys"] and twin.info["unit_enabled"] == ac.info["unit_enabled"]
+    o = orc.AC.compile_packed(blob, offs)
+    small, sdoc = corpus[:int(doc[8])], doc[:9]
+    oh, od = o.match_batch(small, sdoc)
+    th, td = twin.match_batch(small, sdoc, cap=len(oh) + 4)
+    assert th.tobytes() == oh.tobytes() and np.array_equal(td, od)
+    del ac  # the copy owns its image
+    th, td = twin.match_batch(small, sdoc, chars=True, cap=len(oh) + 4)
+    oh, od = o.match_batch(small, sdoc, chars=True)
+    assert th.tobytes() == oh.tobytes() and np.array_equal(td, od)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/aha_hip.h but not exported"
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
-    assert N.lib().aha_abi_version() == 6
+    assert N.lib().aha_abi_version() == 7
     # ... and nothing else (-fvisibility=hidden + aha_amd/csrc/exports.map): a drop-in linked into someone else's process
     # must not bring unprefixed helpers, C++ internals or kernel stubs into its symbol space
     import shutil, subprocess
@@ -375,3 +375,23 @@ def test_bench_launches_its_own_ranks():
     env["AHA_BENCH_LAUNCH_TEST"] = "fail1"
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_output_structs_respect_the_callers_size():
+    """aha_ac_info_t / aha_timing grew with the ABI: a caller built against a shorter struct says so in struct_size and must not
+    be written beyond it (0 = a caller from before the field was read: the ABI-5 size)."""
+    ac = AC.compile(["ab", "abc"], host_only=True)
+    L = N.lib()
+    full = C.sizeof(N.aha_ac_info_t)
+    for said, filled in ((full, full), (full - 24, full - 24), (0, full - 24), (full + 64, full), (16, 16)):
+        buf = (C.c_uint8 * (full + 64))(*([0xAA] * (full + 64)))
+        C.cast(buf, C.POINTER(C.c_uint32))[0] = said
+        assert L.aha_ac_info(ac._h, C.cast(buf, C.POINTER(N.aha_ac_info_t))) == 0
+        assert C.cast(buf, C.POINTER(C.c_uint32))[0] == filled
+        assert all(b == 0xAA for b in bytes(buf)[filled:])
+        assert C.cast(buf, C.POINTER(C.c_uint32))[1] == 2  # n_keys
+    tfull = C.sizeof(N.aha_timing)
+    buf = (C.c_uint8 * (tfull + 16))(*([0xAA] * (tfull + 16)))
+    C.cast(buf, C.POINTER(C.c_uint32))[0] = 0
+    assert L.aha_ac_last_timing(ac._h, C.cast(buf, C.POINTER(N.aha_timing))) == 0
+    assert C.cast(buf, C.POINTER(C.c_uint32))[0] == tfull - 8 and all(b == 0xAA for b in bytes(buf)[tfull - 8:])

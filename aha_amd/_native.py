@@ -103,6 +103,8 @@ SIGNATURES = {
     "aha_ac_match_batch_keep": (_i32, [_vp, _vp, _vp, _u64, C.POINTER(aha_match_params), _vp, _u64, _vp,
                                 C.POINTER(_u64)]),
     "aha_ac_replicate": (_i32, [_vp, _i32, C.POINTER(_vp)]),
+    "aha_ac_match_batch_device_stream": (_i32, [_vp, _vp, _vp, _u64, _u64, C.POINTER(aha_match_params), _vp, _u64, _vp,
+                                                 C.POINTER(_u64), _vp, _u64, _vp, _vp]),
     "aha_group_compile": (_i32, [_vp, _vp, _u32, _vp, _i32, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
     "aha_group_free": (None, [_vp]),
     "aha_group_size": (_i32, [_vp]),

@@ -284,10 +284,12 @@ class AC:
             return out[: n.value], dho
 
     def match_batch_device(self, corpus, doc_offsets, out, doc_hit_offsets=None, sep=None, chars=False,
-                           stream=None):
+                           stream=None, words=None, n_words=None):
         """Device-resident batch match on torch CUDA tensors (uint8 corpus,
         int64/uint64 doc offsets, int32 [cap,3] out).  Returns the hit count;
-        raises AhaError(AHA_E_CAPACITY) with .required when out is too small."""
+        raises AhaError(AHA_E_CAPACITY) with .required when out is too small.
+        words (int32, >= 2 cap + cap / 1024 + 2 elements) + n_words (int64[1]): the hits also as the 4-byte exchange stream
+        (aha_ac_match_batch_device_stream: written by the expansion itself where the character-level engine runs)."""
         import torch
 
         assert corpus.is_cuda and corpus.dtype == torch.uint8 and corpus.is_contiguous()
@@ -299,9 +301,15 @@ class AC:
         n = C.c_uint64(0)
         s = stream if stream is not None else torch.cuda.current_stream(corpus.device).cuda_stream
         dho = doc_hit_offsets.data_ptr() if doc_hit_offsets is not None else None
-        rc = N.lib().aha_ac_match_batch_device(self._h, corpus.data_ptr(), doc_offsets.data_ptr(), D,
-                                               corpus.numel(), C.byref(p), out.data_ptr(), cap, dho,
-                                               C.byref(n), C.c_void_p(s))
+        if words is not None:
+            assert words.is_cuda and words.dtype == torch.int32 and n_words.is_cuda and n_words.dtype == torch.int64
+            rc = N.lib().aha_ac_match_batch_device_stream(self._h, corpus.data_ptr(), doc_offsets.data_ptr(), D, corpus.numel(),
+                                                          C.byref(p), out.data_ptr(), cap, dho, C.byref(n), words.data_ptr(),
+                                                          words.numel(), n_words.data_ptr(), C.c_void_p(s))
+        else:
+            rc = N.lib().aha_ac_match_batch_device(self._h, corpus.data_ptr(), doc_offsets.data_ptr(), D,
+                                                   corpus.numel(), C.byref(p), out.data_ptr(), cap, dho,
+                                                   C.byref(n), C.c_void_p(s))
         if rc == N.AHA_E_CAPACITY:
             e = AhaError(rc)
             e.required = int(n.value)

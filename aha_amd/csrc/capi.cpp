@@ -457,6 +457,25 @@ int32_t v2_reserve(aha_ac *ac, Scratch *sc, int i, size_t bytes) {
 //   kSlabs        slab + sort pipeline: separator filter, fewer than 16 hits per chunk expected (its cost follows the
 //                 events, not the chunks), or regions beyond the temp bound
 enum V2Mode { kRegions = 0, kFullRegions = 1, kSlabs = 2 };
+// Field widths of the 4-byte exchange stream for this automaton (include/aha_hip.h): the key id needs vb bits, a key's
+// length lb bits (in bytes; its length in characters is not longer); when at least 6 bits are left for the step of `end`
+// the word carries the length, else only id and a 12-bit step (ids below 2^20) and the receiver looks the length up.
+static StreamFmt stream_fmt(const aha_ac *ac) {
+  auto bits = [](uint32_t x) {
+    uint32_t b = 0;
+    while (x) {
+      b++;
+      x >>= 1;
+    }
+    return b;
+  };
+  const uint32_t vb = std::max(1u, bits(ac->aut.n_keys ? ac->aut.n_keys - 1 : 0)), lb = std::max(1u, bits(ac->aut.max_key_len));
+  // (a step field below 10 bits makes every gap of 1 KiB an exception -- 4 more bytes on the link --, which costs a
+  // sparse hit stream more than the key-length lookup on arrival saves: then the word carries id and a 12-bit step only)
+  if (vb + lb + 10 <= 32) return StreamFmt{std::min(12u, 32 - vb - lb), lb};
+  return StreamFmt{12, 0};
+}
+
 constexpr uint64_t kV2MaxRegionBytes = 48ull << 30;
 
 // returns AHA_OK, an error, +1 when the caller must fall back to the two-pass engine, +2 when a region overflowed
@@ -556,6 +575,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
 
   const bool prof = ac->profiling.load() && sc->ev_ready;
+  bool fused_pack = false;
   HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
   // device-resident offsets nobody has looked at yet: validated here, in front of the traversal; a bad verdict lands in
   // cursor[1], where the traversal and every post pass look first (no read-back before the launch: -30 us per call)
@@ -578,7 +598,23 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
       v2_launch_hit_scan(M, s);
       if (M.chars) v2_launch_lead_scan(M, s);  // characters before every chunk (the traversal counted them per chunk)
       if (prof) HIPCHK(ac, hipEventRecord(sc->ev[3], s));
+      const bool pack = M1.pk_words != nullptr;
+      if (pack) {  // the expansion writes the exchange stream's words beside the triples and counts the exceptions
+        const size_t cnt_bytes = ((size_t)(M1.cap + 1023) / 1024 + 2) * 4;
+        if ((rc = v2_reserve(ac, sc, 22, cnt_bytes))) return rc;
+        HIPCHK(ac, hipMemsetAsync(sc->v2buf[22].p, 0, cnt_bytes, s));
+        const StreamFmt F = stream_fmt(ac);
+        M.pk_words = M1.pk_words;
+        M.pk_cnt = (uint32_t *)sc->v2buf[22].p;
+        M.pk_sb = F.step_bits;
+        M.pk_lb = F.len_bits;
+      }
       unit_launch_expand(M.chars ? ac->d_unit_end_chars : ac->d_unit_end, post, M, 2u * ac->v2_grid, s);
+      if (pack) {
+        launch_hits_pack4_tail(reinterpret_cast<const int32_t *>(M.out), M.totals, M1.cap, M1.pk_words, M.pk_cnt, M1.pk_nwords,
+                               stream_fmt(ac), s);
+        fused_pack = true;
+      }
     } else {
       if (unit) unit_launch_regroup(post, M, s);  // the wave-ordered events back into the chunks' regions, counted
       v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr, unit);
@@ -606,6 +642,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (sc->h_v2[1] == 2) return 2;  // a chunk's event region overflowed: the caller repeats with full-size regions
   if (sc->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = sc->h_v2[2];
+  if (fused_pack && *n_hits <= M1.cap) M1.pk_words = nullptr;  // (written: the caller of match_v2 need not pack)
   if (prof) {
     aha_timing t;
     memset(&t, 0, sizeof(t));
@@ -853,25 +890,6 @@ int32_t aha_ac_hits_unpack_device(aha_ac *ac, const int32_t *d_pairs, uint64_t n
   launch_hits_unpack(ac->dev, d_pairs, n, char_offsets ? 1 : 0, reinterpret_cast<int32_t *>(d_hits), stream);
   HIPCHK(ac, hipGetLastError());
   return AHA_OK;
-}
-
-// Field widths of the 4-byte exchange stream for this automaton (include/aha_hip.h): the key id needs vb bits, a key's
-// length lb bits (in bytes; its length in characters is not longer); when at least 6 bits are left for the step of `end`
-// the word carries the length, else only id and a 12-bit step (ids below 2^20) and the receiver looks the length up.
-static StreamFmt stream_fmt(const aha_ac *ac) {
-  auto bits = [](uint32_t x) {
-    uint32_t b = 0;
-    while (x) {
-      b++;
-      x >>= 1;
-    }
-    return b;
-  };
-  const uint32_t vb = std::max(1u, bits(ac->aut.n_keys ? ac->aut.n_keys - 1 : 0)), lb = std::max(1u, bits(ac->aut.max_key_len));
-  // (a step field below 10 bits makes every gap of 1 KiB an exception -- 4 more bytes on the link --, which costs a
-  // sparse hit stream more than the key-length lookup on arrival saves: then the word carries id and a 12-bit step only)
-  if (vb + lb + 10 <= 32) return StreamFmt{std::min(12u, 32 - vb - lb), lb};
-  return StreamFmt{12, 0};
 }
 
 int32_t aha_ac_stream_format(const aha_ac *ac, uint32_t *step_bits, uint32_t *len_bits) {
@@ -1167,10 +1185,16 @@ int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t) {
   return AHA_OK;
 }
 
+// the hits as the 4-byte exchange stream as well (aha_ac_match_batch_device_stream); null: not asked for
+struct PackOut {
+  uint32_t *d_words;
+  uint64_t cap_words;
+  uint64_t *d_n_words;
+};
 static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
                                        uint64_t n_docs, uint64_t n_bytes, const aha_match_params *params,
                                        aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets, uint64_t *n_hits,
-                                       void *stream, bool offsets_checked);
+                                       void *stream, bool offsets_checked, const PackOut *pk = nullptr);
 
 // the events of a scratch set are created by the first profiled call that leases it
 static int32_t ready_events(aha_ac *ac, Scratch *sc) {
@@ -1195,10 +1219,45 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
                                  d_doc_hit_offsets, n_hits, stream, false);
 }
 
+static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
+                                 uint64_t n_docs, uint64_t n_bytes, const aha_match_params *params, aha_hit *d_out, uint64_t cap,
+                                 uint64_t *d_doc_hit_offsets, uint64_t *n_hits, void *stream, bool offsets_checked,
+                                 const PackOut *pk, bool *packed);
+
 static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
                                        uint64_t n_docs, uint64_t n_bytes, const aha_match_params *params,
                                        aha_hit *d_out, uint64_t cap, uint64_t *d_doc_hit_offsets, uint64_t *n_hits,
-                                       void *stream, bool offsets_checked) {
+                                       void *stream, bool offsets_checked, const PackOut *pk) {
+  if (pk) {
+    if (!ac || !pk->d_words || !pk->d_n_words) return AHA_E_INVALID;
+    if (stream_fmt(ac).len_bits == 0 && ac->aut.n_keys > (1u << 20)) {
+      tls_err = "the 4-byte exchange stream holds key ids below 2^20: use the {end, value} pairs";
+      return AHA_E_INVALID;
+    }
+    if (pk->cap_words < 2 * cap + (cap + 1023) / 1024 + 1) {
+      tls_err = "4-byte exchange stream: capacity below 2 cap + ceil(cap / 1024) + 1 words";
+      return AHA_E_CAPACITY;
+    }
+  }
+  bool packed = false;
+  int32_t rc = device_impl_inner(ac, sc, d_corpus, d_doc_offsets, n_docs, n_bytes, params, d_out, cap, d_doc_hit_offsets, n_hits,
+                                 stream, offsets_checked, pk, &packed);
+  if (rc == AHA_OK && pk && !packed) {
+    // a pipeline that does not write the stream itself (everything but the fused expansion of the character-level engine):
+    // the three pack kernels over the hits, behind the match
+    DeviceGuard g(ac->device);
+    launch_hits_pack4(reinterpret_cast<const int32_t *>(d_out), *n_hits, pk->d_words,
+                      reinterpret_cast<unsigned long long *>(pk->d_n_words), stream_fmt(ac), stream);
+    HIPCHK(ac, hipGetLastError());
+    HIPCHK(ac, hipStreamSynchronize((hipStream_t)stream));
+  }
+  return rc;
+}
+
+static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpus, const uint64_t *d_doc_offsets,
+                                 uint64_t n_docs, uint64_t n_bytes, const aha_match_params *params, aha_hit *d_out, uint64_t cap,
+                                 uint64_t *d_doc_hit_offsets, uint64_t *n_hits, void *stream, bool offsets_checked,
+                                 const PackOut *pk, bool *packed) {
   if (!ac || !n_hits || !d_doc_offsets) return AHA_E_INVALID;
   if (ac->device < 0) {
     tls_err = aha_strerror(AHA_E_NO_DEVICE);
@@ -1319,6 +1378,11 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
     return AHA_OK;
   }
   uint32_t repeats = 0;  // passes thrown away (aha_timing.repeats)
+  if (pk) {
+    M.pk_words = pk->d_words;
+    M.pk_cap = pk->cap_words;
+    M.pk_nwords = reinterpret_cast<unsigned long long *>(pk->d_n_words);
+  }
   if (ac->v2_ok) {
     rc = match_v2(ac, sc, M, s, n_hits, kRegions);
     if (rc == 2) {  // denser than cap said: regions of one event per byte
@@ -1333,6 +1397,7 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
         tls_err = "output buffer too small";
         return AHA_E_CAPACITY;
       }
+      *packed = M.pk_words == nullptr && pk != nullptr;  // (match_v2 clears the field when its expansion wrote the stream)
       return AHA_OK;
     }
     *n_hits = 0;  // rc == 1: fall through to the two-pass engine
@@ -1391,6 +1456,21 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
     return AHA_E_CAPACITY;
   }
   return AHA_OK;
+}
+
+int32_t aha_ac_match_batch_device_stream(aha_ac *ac, const uint8_t *d_corpus, const uint64_t *d_doc_offsets, uint64_t n_docs,
+                                         uint64_t n_bytes, const aha_match_params *params, aha_hit *d_out, uint64_t cap,
+                                         uint64_t *d_doc_hit_offsets, uint64_t *n_hits, uint32_t *d_words, uint64_t cap_words,
+                                         uint64_t *d_n_words, void *stream) {
+  if (!ac) return AHA_E_INVALID;
+  if (ac->device < 0) {
+    tls_err = aha_strerror(AHA_E_NO_DEVICE);
+    return AHA_E_NO_DEVICE;
+  }
+  Lease lease(ac);
+  const PackOut pk{d_words, cap_words, d_n_words};
+  return match_batch_device_impl(ac, lease.get(), d_corpus, d_doc_offsets, n_docs, n_bytes, params, d_out, cap, d_doc_hit_offsets,
+                                 n_hits, stream, false, &pk);
 }
 
 // Host-buffer entry (what `Aha::AC#match(Bytes)`, src/aha/ac.cr:280-286, and a batch of them bind to).  The corpus is

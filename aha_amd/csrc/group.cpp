@@ -691,8 +691,21 @@ int32_t aha_group_match_batch_device(aha_group *g, const aha_group_corpus *c, co
     const auto t0 = std::chrono::steady_clock::now();
     for (int attempt = 0; attempt < 2; attempt++) {
       uint64_t nh = 0;
-      s.rc = aha_ac_match_batch_device(s.ac, aha_corpus_bytes(part), aha_corpus_doc_offsets(part), D, nb, params, (aha_hit *)s.out.p,
-                                       s.out.bytes / sizeof(aha_hit), (uint64_t *)s.dho.p, &nh, s.stream);
+      const uint64_t capo = s.out.bytes / sizeof(aha_hit);
+      if (words) {  // the match leaves the shard's exchange stream as well (written by the expansion, no pack pass)
+        const uint64_t capw = 2 * capo + (capo + 1023) / 1024 + 16;
+        if (!s.pk.reserve(capw * 4) || !s.nw.reserve(8)) {
+          s.rc = AHA_E_HIP;
+          s.err = "hipMalloc failed for the packed stream";
+          return;
+        }
+        s.rc = aha_ac_match_batch_device_stream(s.ac, aha_corpus_bytes(part), aha_corpus_doc_offsets(part), D, nb, params,
+                                                (aha_hit *)s.out.p, capo, (uint64_t *)s.dho.p, &nh, (uint32_t *)s.pk.p, capw,
+                                                (uint64_t *)s.nw.p, s.stream);
+      } else {
+        s.rc = aha_ac_match_batch_device(s.ac, aha_corpus_bytes(part), aha_corpus_doc_offsets(part), D, nb, params, (aha_hit *)s.out.p,
+                                         capo, (uint64_t *)s.dho.p, &nh, s.stream);
+      }
       s.n_hits = nh;
       if (s.rc != AHA_E_CAPACITY) break;
       if (!s.out.reserve(nh * sizeof(aha_hit))) {
@@ -714,17 +727,6 @@ int32_t aha_group_match_batch_device(aha_group *g, const aha_group_corpus *c, co
         s.err = "download of the per-document offsets failed";
         return;
       }
-    }
-    if (words) {
-      const uint64_t capw = 2 * s.n_hits + (s.n_hits + 1023) / 1024 + 16;
-      if (!s.pk.reserve(capw * 4) || !s.nw.reserve(8)) {
-        s.rc = AHA_E_HIP;
-        s.err = "hipMalloc failed for the packed stream";
-        return;
-      }
-      s.rc = aha_ac_hits_pack4_device(s.ac, (const aha_hit *)s.out.p, s.n_hits, (uint32_t *)s.pk.p, capw, (uint64_t *)s.nw.p,
-                                      s.stream);
-      if (s.rc != AHA_OK) s.err = std::string("pack: ") + aha_last_error(s.ac);
     }
   };
   {

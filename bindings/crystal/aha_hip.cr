@@ -128,6 +128,11 @@ lib LibAhaHip
   fun aha_ac_info(ac : Ac, info : Info*) : Int32
   fun aha_ac_set_profiling(ac : Ac, enabled : Int32) : Int32
   fun aha_ac_last_timing(ac : Ac, t : Timing*) : Int32
+  # ABI 7: the device match that also leaves the hits as the 4-byte exchange stream
+  fun aha_ac_match_batch_device_stream(ac : Ac, d_corpus : UInt8*, d_doc_offsets : UInt64*, n_docs : UInt64, n_bytes : UInt64,
+                                       params : MatchParams*, d_out : Hit*, cap : UInt64, d_doc_hit_offsets : UInt64*,
+                                       n_hits : UInt64*, d_words : UInt32*, cap_words : UInt64, d_n_words : UInt64*,
+                                       stream : Void*) : Int32
   fun aha_ac_release_scratch(ac : Ac) : Int32
   fun aha_ac_scratch_bytes(ac : Ac) : Int64
   fun aha_ac_export(ac : Ac, which : Int32, buf : Void*, cap_bytes : UInt64) : Int64

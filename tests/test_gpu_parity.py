@@ -1272,3 +1272,62 @@ def test_hits_kept_on_the_device_and_a_replicated_handle(engine):
     th, td = twin.match_batch(small, sdoc, chars=True, cap=len(oh) + 4)
     oh, od = o.match_batch(small, sdoc, chars=True)
     assert th.tobytes() == oh.tobytes() and np.array_equal(td, od)
+
+
+def test_match_leaves_the_exchange_stream(engine):
+    """aha_ac_match_batch_device_stream: the hits AND their 4-byte exchange stream from one call.  Where the character-level
+    engine's fused expansion runs, the expansion writes the words itself (more exceptions than the pack kernels make: every
+    chunk's first hit -- the receiver does not care); every other pipeline packs behind its match, bit-identical to the pack
+    kernels.  In every case the stream rebuilds exactly the hits of the call -- dense and sparse text, tiny documents, char
+    offsets, zero hits -- and stays within 2 n + n / 1024 + 1 words."""
+    if engine not in ("v2", "u", "ur", "auto"):
+        pytest.skip("the byte-level engine (packs behind the match), the fused expansion, the general post passes, the library's choice")
+    import torch
+
+    from aha_amd.distributed import PK4_BLOCK, pack4_host
+
+    dev = torch.device("cuda:0")
+    blob, offs, nf = synth.keys(3, K=20_000)
+    g = AC.compile_packed(blob, offs)
+    g.set_profiling(True)
+    cases = []
+    corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 23, doc_bytes=1 << 16)
+    cases.append((corpus, doc, False))
+    cases.append((corpus, doc, True))
+    cases.append((corpus[: 1 << 20], np.arange(0, (1 << 20) + 1, 64, dtype=np.uint64), False))  # 16 Ki tiny documents
+    sparse = np.full(1 << 22, 0x20, dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    for p in range(100, sparse.size - 100, 9000):
+        k = int(rng.integers(0, 20_000))
+        kb = blob[int(offs[k]):int(offs[k + 1])]
+        sparse[p:p + kb.size] = kb
+    cases.append((sparse, np.array([0, sparse.size], dtype=np.uint64), False))
+    cases.append((np.full(4096, 0x20, dtype=np.uint8), np.array([0, 4096], dtype=np.uint64), False))  # zero hits
+    for corpus, doc, chars in cases:
+        dc = torch.from_numpy(corpus).to(dev)
+        dd = torch.from_numpy(doc.astype(np.int64)).to(dev)
+        cap = corpus.size // 8 + 16
+        ref = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+        n = g.match_batch_device(dc, dd, ref, None, chars=chars)
+        out = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+        words = torch.full((2 * cap + cap // 1024 + 2,), -1, dtype=torch.int32, device=dev)
+        n_words = torch.zeros(1, dtype=torch.int64, device=dev)
+        dho = torch.zeros(doc.size, dtype=torch.int64, device=dev)
+        assert g.match_batch_device(dc, dd, out, dho, chars=chars, words=words, n_words=n_words) == n
+        assert torch.equal(out[:n], ref[:n])
+        nw = int(n_words[0])
+        nb = (n + PK4_BLOCK - 1) // PK4_BLOCK
+        assert n + 2 * nb <= nw + nb <= 2 * n + nb + 1 or n == 0
+        if g.last_timing()["engine"] != 4 or engine == "ur":
+            want = pack4_host(ref[:n].cpu(), g.stream_format())
+            assert nw == want.numel() and torch.equal(words[:nw].cpu(), want)
+        else:  # the fused expansion: a chunk's first hit is an exception too -- a few per thousand hits on dense text
+            assert nw <= pack4_host(ref[:n].cpu(), g.stream_format()).numel() + 2 * (corpus.size // 1024 + 64)
+        back = torch.full((n + 3, 3), -7, dtype=torch.int32, device=dev)
+        g.hits_unpack4_device(words, n, back, chars=chars)
+        torch.cuda.synchronize()
+        assert torch.equal(back[:n], ref[:n]) and bool((back[n:] == -7).all())
+    # too little room for the stream is said before anything runs
+    with pytest.raises(AhaError) as e:
+        g.match_batch_device(dc, dd, out, None, words=words[:64], n_words=n_words)
+    assert e.value.code == N.AHA_E_CAPACITY

@@ -575,7 +575,6 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
 
   const bool prof = ac->profiling.load() && sc->ev_ready;
-  bool fused_pack = false;
   HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
   // device-resident offsets nobody has looked at yet: validated here, in front of the traversal; a bad verdict lands in
   // cursor[1], where the traversal and every post pass look first (no read-back before the launch: -30 us per call)
@@ -598,23 +597,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
       v2_launch_hit_scan(M, s);
       if (M.chars) v2_launch_lead_scan(M, s);  // characters before every chunk (the traversal counted them per chunk)
       if (prof) HIPCHK(ac, hipEventRecord(sc->ev[3], s));
-      const bool pack = M1.pk_words != nullptr;
-      if (pack) {  // the expansion writes the exchange stream's words beside the triples and counts the exceptions
-        const size_t cnt_bytes = ((size_t)(M1.cap + 1023) / 1024 + 2) * 4;
-        if ((rc = v2_reserve(ac, sc, 22, cnt_bytes))) return rc;
-        HIPCHK(ac, hipMemsetAsync(sc->v2buf[22].p, 0, cnt_bytes, s));
-        const StreamFmt F = stream_fmt(ac);
-        M.pk_words = M1.pk_words;
-        M.pk_cnt = (uint32_t *)sc->v2buf[22].p;
-        M.pk_sb = F.step_bits;
-        M.pk_lb = F.len_bits;
-      }
       unit_launch_expand(M.chars ? ac->d_unit_end_chars : ac->d_unit_end, post, M, 2u * ac->v2_grid, s);
-      if (pack) {
-        launch_hits_pack4_tail(reinterpret_cast<const int32_t *>(M.out), M.totals, M1.cap, M1.pk_words, M.pk_cnt, M1.pk_nwords,
-                               stream_fmt(ac), s);
-        fused_pack = true;
-      }
     } else {
       if (unit) unit_launch_regroup(post, M, s);  // the wave-ordered events back into the chunks' regions, counted
       v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr, unit);
@@ -642,7 +625,6 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (sc->h_v2[1] == 2) return 2;  // a chunk's event region overflowed: the caller repeats with full-size regions
   if (sc->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = sc->h_v2[2];
-  if (fused_pack && *n_hits <= M1.cap) M1.pk_words = nullptr;  // (written: the caller of match_v2 need not pack)
   if (prof) {
     aha_timing t;
     memset(&t, 0, sizeof(t));
@@ -1243,8 +1225,8 @@ static int32_t match_batch_device_impl(aha_ac *ac, Scratch *sc, const uint8_t *d
   int32_t rc = device_impl_inner(ac, sc, d_corpus, d_doc_offsets, n_docs, n_bytes, params, d_out, cap, d_doc_hit_offsets, n_hits,
                                  stream, offsets_checked, pk, &packed);
   if (rc == AHA_OK && pk && !packed) {
-    // a pipeline that does not write the stream itself (everything but the fused expansion of the character-level engine):
-    // the three pack kernels over the hits, behind the match
+    // the three pack kernels over the hits, behind the match on the same stream (the expansion writing the words itself was
+    // built and measured in round 5: +0.40 ms on the match against the pack's 0.25, profiles/r05_fused_exchange_stream.txt)
     DeviceGuard g(ac->device);
     launch_hits_pack4(reinterpret_cast<const int32_t *>(d_out), *n_hits, pk->d_words,
                       reinterpret_cast<unsigned long long *>(pk->d_n_words), stream_fmt(ac), stream);
@@ -1378,11 +1360,6 @@ static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpu
     return AHA_OK;
   }
   uint32_t repeats = 0;  // passes thrown away (aha_timing.repeats)
-  if (pk) {
-    M.pk_words = pk->d_words;
-    M.pk_cap = pk->cap_words;
-    M.pk_nwords = reinterpret_cast<unsigned long long *>(pk->d_n_words);
-  }
   if (ac->v2_ok) {
     rc = match_v2(ac, sc, M, s, n_hits, kRegions);
     if (rc == 2) {  // denser than cap said: regions of one event per byte
@@ -1397,7 +1374,6 @@ static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpu
         tls_err = "output buffer too small";
         return AHA_E_CAPACITY;
       }
-      *packed = M.pk_words == nullptr && pk != nullptr;  // (match_v2 clears the field when its expansion wrote the stream)
       return AHA_OK;
     }
     *n_hits = 0;  // rc == 1: fall through to the two-pass engine

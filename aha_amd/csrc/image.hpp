@@ -64,10 +64,6 @@ struct MatchArgs {
   aha_hit *out;
   uint64_t cap;
   uint64_t *doc_hit_off;     // [D+1] or null
-  // optional: the hits as the 4-byte exchange stream as well (aha_ac_match_batch_device_stream); capacity in words
-  uint32_t *pk_words;
-  uint64_t pk_cap;
-  unsigned long long *pk_nwords;
 };
 
 constexpr int kBlock = 256;  // threads per block in the traversal kernels
@@ -129,11 +125,6 @@ struct V2Args {
   aha_hit *out;
   uint64_t cap;
   uint64_t *doc_hit_off;
-  // the hits once more as the 4-byte exchange stream (kernels.hip), written by the expansion beside the triples (null: off):
-  // pk_words[i] = the word of hit i (step = 2^pk_sb - 1: an exception), pk_cnt[i >> 10] += 1 per exception
-  uint32_t *pk_words;
-  uint32_t *pk_cnt;
-  uint32_t pk_sb, pk_lb;
 };
 
 // ---- character-level engine (scan_unit.hip, unit.hpp) ---------------------------
@@ -180,10 +171,6 @@ struct StreamFmt {
 };
 void launch_hits_pack4(const int32_t *hits, uint64_t n, uint32_t *stream_words, unsigned long long *n_words, StreamFmt F,
                        void *stream);
-// the rest of the stream when the expansion has written the words and counted the exceptions per 1024 hits (cnt): the blocks'
-// exception offsets, the stream's length, the exceptions' absolute ends.  *n_dev = number of hits (device memory)
-void launch_hits_pack4_tail(const int32_t *hits, const uint64_t *n_dev, uint64_t cap_hits, uint32_t *stream_words,
-                            const uint32_t *cnt, unsigned long long *n_words, StreamFmt F, void *stream);
 void launch_hits_unpack4(const DevAut &A, const uint32_t *stream_words, uint64_t n, int chars, int32_t *hits, StreamFmt F,
                          void *stream);
 // several streams in one launch: stream k starts at word word_off[k] of `land`, holds n_hits[k] hits, goes to hits[out_off[k]..]

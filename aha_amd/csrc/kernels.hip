@@ -600,58 +600,6 @@ __global__ __launch_bounds__(kPk4Block) void k_pack4_write(const int32_t *hits, 
   if (x) exc[(uint64_t)blk[blockIdx.x] + rank] = e;
 }
 
-// The stream's tail when the expansion has written the words (scan_unit.hip ku_expand_groups<.., PACK>): cnt[b] = exceptions
-// among the hits [1024 b, 1024 b + 1024).  k_pack4_scan_cnt: blk[] (behind the n words) = exclusive sums, n_words; then
-// k_pack4_exc writes the exceptions' absolute ends (from the triples) in hit order.  n comes from device memory.
-__global__ __launch_bounds__(1024) void k_pack4_scan_cnt(const uint32_t *cnt, const uint64_t *n_dev, uint32_t *words,
-                                                         unsigned long long *n_words) {
-  __shared__ uint32_t wsum[16];
-  __shared__ unsigned long long run;
-  const uint64_t n = *n_dev, nb = (n + kPk4Block - 1) / kPk4Block;
-  uint32_t *blk = words + n;
-  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-  if (t == 0) run = 0;
-  __syncthreads();
-  for (uint64_t base = 0; base < nb; base += 1024) {
-    const uint64_t i = base + t;
-    const uint32_t v = i < nb ? cnt[i] : 0;
-    uint32_t inc = v;
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t u = __shfl_up(inc, o);
-      if ((int)lane >= o) inc += u;
-    }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t u = 0; u < w; u++) before += wsum[u];
-    const unsigned long long r = run;
-    if (i < nb) blk[i] = (uint32_t)(r + before + inc - v);
-    __syncthreads();
-    if (t == 1023) run = r + before + inc;
-    __syncthreads();
-  }
-  if (t == 0) *n_words = n + nb + run;
-}
-
-__global__ __launch_bounds__(kPk4Block) void k_pack4_exc(const int32_t *hits, const uint64_t *n_dev, uint32_t *words, StreamFmt F) {
-  __shared__ uint32_t wcnt[16];
-  const uint64_t n = *n_dev, nb = (n + kPk4Block - 1) / kPk4Block;
-  if (blockIdx.x >= nb) return;
-  const uint32_t *blk = words + n;
-  int32_t *exc = reinterpret_cast<int32_t *>(words + n + nb);
-  const uint32_t xc = (1u << F.step_bits) - 1u;
-  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const uint64_t i = (uint64_t)blockIdx.x * kPk4Block + t;
-  const bool x = i < n && (words[i] & xc) == xc;
-  const unsigned long long m = __ballot(x);
-  if (lane == 0) wcnt[w] = (uint32_t)__popcll(m);
-  __syncthreads();
-  if (!x) return;
-  uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-  for (uint32_t u = 0; u < w; u++) rank += wcnt[u];
-  exc[(uint64_t)blk[blockIdx.x] + rank] = hits[i * 3 + 1];
-}
-
 // Rebuilds the Hit triples of up to kMaxSegs streams in ONE launch (an 8-GPU step receives seven): the workgroups
 // [blk0[s], blk0[s+1]) belong to stream s, which starts at word woff[s] of `land`, holds nh[s] hits and is written
 // to hits[ooff[s]..].
@@ -791,14 +739,6 @@ __global__ __launch_bounds__(kUnpThreads) void k_unpack4(const uint32_t *land, S
     const uint32_t total = (uint32_t)min<uint64_t>(rest, kPk4Block) * 3;
     for (uint32_t j = t; j < total; j += kUnpThreads) dst[j] = st[j];
   }
-}
-
-void launch_hits_pack4_tail(const int32_t *hits, const uint64_t *n_dev, uint64_t cap_hits, uint32_t *stream_words,
-                            const uint32_t *cnt, unsigned long long *n_words, StreamFmt F, void *stream) {
-  hipStream_t s = (hipStream_t)stream;
-  const uint64_t nb_cap = (cap_hits + kPk4Block - 1) / kPk4Block;
-  hipLaunchKernelGGL(k_pack4_scan_cnt, dim3(1), dim3(1024), 0, s, cnt, n_dev, stream_words, n_words);
-  if (nb_cap) hipLaunchKernelGGL(k_pack4_exc, dim3((uint32_t)nb_cap), dim3(kPk4Block), 0, s, hits, n_dev, stream_words, F);
 }
 
 void launch_hits_pack4(const int32_t *hits, uint64_t n, uint32_t *stream_words, unsigned long long *n_words,

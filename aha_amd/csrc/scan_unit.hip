@@ -520,18 +520,13 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
 // (shape, gather and stores measured apart: profiles/r04_expansion_lab.txt -- 1024 threads x 1 record beat 256 x 4 by 20 %)
 constexpr int kXgThreads = 1024, kXgPer = 1, kXgBlock = kXgThreads * kXgPer, kXgStage = 1536;
 constexpr int kXgCacheBits = 11;
-// PACK: every hit also leaves as the word of the 4-byte exchange stream (kernels.hip: value | length | step of `end`): the
-// hit before it in the final order is the one staged before it, or -- the first of a chunk in this block -- the chunk's last
-// hit of the block before (s_prev); a chunk's first hit, the first of every 1024 and a step the field does not hold are
-// exceptions (the absolute end follows in the stream's tail, launch_hits_pack4_tail), counted per 1024 hits.
-template <bool CHARS, bool PACK>
+template <bool CHARS>
 __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend, DevAut A, V2Args M) {
   __shared__ uint32_t s_hs[kXgStage], s_he[kXgStage], s_hk[kXgStage];  // staged hits: start, end, key
   __shared__ uint8_t s_hl[kXgStage];                                    // ... and the chunk (lane tag) of each
   __shared__ uint32_t s_tot[2][64], s_start[64], s_run[64], s_all;
   __shared__ uint64_t s_base[64];  // the chunk's place in the output
   __shared__ uint32_t s_adj[64];   // CHARS: characters between the start of the document that contains the chunk start and it
-  __shared__ uint32_t s_prev[64];  // PACK: `end` of the chunk's last hit so far (0x80000000: none yet)
   // uend entries this workgroup has seen, direct-mapped by a hash of the base: {base + 1, first word}.  Hits pile up on few
   // END states (cfg 3: 28 M of 30 M events end one of 676 two-letter keys), but those states' bases -- and with them their
   // uend lines -- lie all over the image: 676 lines do not stay in a 32 KiB L1, 676 entries do in 16 KiB of LDS.  Only states
@@ -551,7 +546,6 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
       s_base[lane] = c < M.n_chunks ? M.hit_base[c] : 0ull;
       s_run[lane] = 0;
       s_tot[0][lane] = 0;
-      if (PACK) s_prev[lane] = 0x80000000u;
     }
     uint32_t total = c < M.n_chunks ? min(M.ev_cnt[c], stride) : 0u;
 #pragma unroll
@@ -636,23 +630,9 @@ __global__ __launch_bounds__(kXgThreads) void ku_expand_groups(const uint2 *uend
             hit.end = (int32_t)s_he[j];
             hit.value = (int32_t)s_hk[j];
             M.out[idx] = hit;
-            if (PACK) {
-              const uint32_t xc = (1u << M.pk_sb) - 1u;
-              const uint32_t prev = (j > 0 && s_hl[j - 1] == l) ? s_he[j - 1] : s_prev[l];
-              const int64_t dlt = (int64_t)(int32_t)s_he[j] - (int64_t)(int32_t)prev;
-              const bool exc = (idx & 1023u) == 0u || prev == 0x80000000u || dlt < 0 || dlt >= (int64_t)xc;
-              const uint32_t len = M.pk_lb ? s_he[j] - s_hs[j] : 0u;
-              M.pk_words[idx] = (s_hk[j] << (M.pk_sb + M.pk_lb)) | (len << M.pk_sb) | (exc ? xc : (uint32_t)dlt);
-              if (exc) atomicAdd(&M.pk_cnt[idx >> 10], 1u);
-            }
           }
         }
         __syncthreads();
-        if (PACK) {  // (read above, before the barrier; the next window's reads come behind its staging barrier)
-          for (uint32_t j = threadIdx.x; j < nh; j += kXgThreads)
-            if (j + 1 == nh || s_hl[j + 1] != s_hl[j]) s_prev[s_hl[j]] = s_he[j];
-          __syncthreads();  // (the next window's staging overwrites s_hl / s_he)
-        }
       }
       if (wv == 0) s_run[lane] += s_tot[par][lane];
     }
@@ -715,17 +695,11 @@ void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, uin
   const uint64_t n_groups = (M.n_chunks + 63) / 64;
   // persistent workgroups (two of 1024 threads fit a CU): each keeps its LDS cache of uend entries over its groups
   const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_groups, workgroups)));
-  const bool pack = M.pk_words != nullptr;
   if (M.chars) {
     hipLaunchKernelGGL(ku_chunk_adj, dim3((uint32_t)((M.n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M);
-    if (pack)
-      hipLaunchKernelGGL((ku_expand_groups<true, true>), grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
-    else
-      hipLaunchKernelGGL((ku_expand_groups<true, false>), grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
-  } else if (pack) {
-    hipLaunchKernelGGL((ku_expand_groups<false, true>), grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
+    hipLaunchKernelGGL(ku_expand_groups<true>, grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
   } else {
-    hipLaunchKernelGGL((ku_expand_groups<false, false>), grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
+    hipLaunchKernelGGL(ku_expand_groups<false>, grid, dim3(kXgThreads), 0, (hipStream_t)stream, uend, A, M);
   }
   if (M.doc_hit_off)
     hipLaunchKernelGGL(ku_doc_offsets, dim3((uint32_t)((M.n_docs + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M);

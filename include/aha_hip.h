@@ -226,9 +226,8 @@ int32_t aha_ac_match_batch_device(aha_ac *ac, const uint8_t *d_corpus,
 
 /* ABI 7 -- aha_ac_match_batch_device that leaves the hits ALSO as the 4-byte exchange stream (below: the format of
  * aha_ac_hits_pack4_device, bit-compatible with aha_ac_hits_unpack4_*): d_words[0 .. *d_n_words) on the device, capacity
- * cap_words >= 2 cap + ceil(cap / 1024) + 1 words.  The character-level engine's expansion writes the words beside the triples
- * (no second pass over the hits: what a rank of the all-gatherv calls every step); every other pipeline packs behind its
- * match.  Final when the call returns. */
+ * cap_words >= 2 cap + ceil(cap / 1024) + 1 words: the pack kernels run behind the match on the same stream, one call instead
+ * of two (what every resident shard of a group calls).  Final when the call returns. */
 int32_t aha_ac_match_batch_device_stream(aha_ac *ac, const uint8_t *d_corpus, const uint64_t *d_doc_offsets, uint64_t n_docs,
                                          uint64_t n_bytes, const aha_match_params *params, aha_hit *d_out, uint64_t cap,
                                          uint64_t *d_doc_hit_offsets, uint64_t *n_hits, uint32_t *d_words, uint64_t cap_words,

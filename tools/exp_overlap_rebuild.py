@@ -1,6 +1,9 @@
 """Experiment: what does an 8-GPU step cost ONE GPU in kernels -- the match of the next step beside the pack of the own
 hits and the rebuild of the seven peers' exchange streams (one launch over a segment table since round 3; pass
---launches 7 for the round-2 form, one unpack launch per peer)?  Two host threads, two streams, one GPU."""
+--launches 7 for the round-2 form, one unpack launch per peer)?  Two host threads, two streams, one GPU.
+Round 5: the match call leaves the exchange stream as well (aha_ac_match_batch_device_stream: the pack kernels behind the match
+on ITS stream); --separate-pack runs round 4's form (the pack on the second stream, beside the next match).
+(profiles/r05_fused_exchange_stream.txt: the expansion writing the words itself was built, measured slower and removed.)"""
 import os
 import sys
 import threading
@@ -28,6 +31,10 @@ nw = torch.zeros(1, dtype=torch.int64, device=dev)
 ac.hits_pack4_device(out, n, words, nw)
 allh = torch.zeros((8 * n, 3), dtype=torch.int32, device=dev)
 one_launch = "--launches" not in sys.argv
+fused = "--separate-pack" not in sys.argv
+capo = out.shape[0]
+words2 = torch.zeros(2 * capo + capo // 1024 + 2, dtype=torch.int32, device=dev)
+nw2 = torch.zeros_like(nw)
 nwords = None
 out2 = torch.zeros_like(out)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
@@ -36,12 +43,16 @@ K = 10
 
 def match_loop():
     for _ in range(K):
-        ac.match_batch_device(dc, dd, out2, dho, stream=sa.cuda_stream)
+        if fused:
+            ac.match_batch_device(dc, dd, out2, dho, stream=sa.cuda_stream, words=words2, n_words=nw2)
+        else:
+            ac.match_batch_device(dc, dd, out2, dho, stream=sa.cuda_stream)
 
 
 def rebuild_loop():
     for _ in range(K):
-        ac.hits_pack4_device(out, n, words, nw, stream=sb.cuda_stream)
+        if not fused:
+            ac.hits_pack4_device(out, n, words, nw, stream=sb.cuda_stream)
         if one_launch:  # the seven peers' streams (here: seven times the own one) rebuilt by one launch
             ac.hits_unpack4_segs_device(words, [(0, n, p * n) for p in range(1, 8)], allh, stream=sb.cuda_stream)
         else:
@@ -62,7 +73,9 @@ def run(fns):
     return (time.perf_counter() - t0) / K * 1e3
 
 
-for fns, name in (([match_loop], "match alone"), ([rebuild_loop], "pack + 7 rebuilds alone"),
+print("match + pack in one call, one stream" if fused else "separate pack kernels (round 4)", flush=True)
+for fns, name in (([match_loop], "match (+ stream) alone" if fused else "match alone"),
+                  ([rebuild_loop], "7 rebuilds alone" if fused else "pack + 7 rebuilds alone"),
                   ([match_loop, rebuild_loop], "both, two streams")):
     run(fns)
     print(f"{name}: {run(fns):.3f} ms per step", flush=True)

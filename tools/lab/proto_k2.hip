@@ -20,6 +20,7 @@ struct K2P {
   const uint8_t *disp;
   const uint4 *pairs, *deep;
   uint32_t n_groups, pair_log2, deep_log2, k1, max_len;
+  int max_steps;
   unsigned long long *out;  // [0] events [1] hits [2] checksum [3] starts with more than kMaxEnds END steps [4] candidates [5] pair hits
 };
 
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void k2_walk(K2P P) {
           }
         }
       }
-      for (int step = 0; step < 40; step++) {  // (bounded: no key has more characters)
+      for (int step = 0; step < P.max_steps; step++) {  // (bounded: no key has more characters)
         uint32_t c, L;
         char_at(min(p, (uint32_t)(kRowBytes - 8)), dend, c, L);
         const bool go = alive & p < dend & ((CF >> (mul24(c, kHK2) >> 27)) & 1u) != 0u;
@@ -219,8 +220,8 @@ __global__ __launch_bounds__(kThreads) void k2_walk(K2P P) {
 
 extern "C" int proto_k2_run(const uint8_t *text, uint64_t n_bytes, const uint64_t *bitmap, const uint8_t *disp, const void *pairs,
                             const void *deep, uint32_t n_groups, uint32_t pair_log2, uint32_t deep_log2, uint32_t k1,
-                            uint32_t max_len, unsigned long long *out, int grid, int reps, float *ms_out) {
-  K2P P{text, n_bytes, bitmap, disp, (const uint4 *)pairs, (const uint4 *)deep, n_groups, pair_log2, deep_log2, k1, max_len, out};
+                            uint32_t max_len, unsigned long long *out, int grid, int reps, float *ms_out, int max_steps) {
+  K2P P{text, n_bytes, bitmap, disp, (const uint4 *)pairs, (const uint4 *)deep, n_groups, pair_log2, deep_log2, k1, max_len, max_steps, out};
   const size_t lds = ((n_groups + 15u) & ~15u) + 256 + (size_t)(kThreads / 64) * (kRowBytes + 64 * 2 + 16);
   if (hipFuncSetAttribute((const void *)k2_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
   hipEvent_t a, b;

@@ -66,12 +66,12 @@ print(f"K1 filter rc {rc}: {ms1.value:.3f} ms", flush=True)
 dd_ = torch.from_numpy(disp).cuda(); dp = torch.from_numpy(pairs.view(np.int32)).cuda(); de = torch.from_numpy(deep.view(np.int32)).cuda()
 cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
 ms2 = C.c_float(0)
-for grid in (1024, 2048):
+for grid, steps in ((1024, 40), (1024, 0), (1024, 1), (1024, 2)):
     rc = L2.proto_k2_run(C.c_void_p(dc.data_ptr()), C.c_uint64(n_bytes), C.c_void_p(bitmap.data_ptr()), C.c_void_p(dd_.data_ptr()),
                          C.c_void_p(dp.data_ptr()), C.c_void_p(de.data_ptr()), C.c_uint32(n_groups), C.c_uint32(pair_log2),
-                         C.c_uint32(deep_log2), C.c_uint32(k1), C.c_uint32(max_len), C.c_void_p(cnt.data_ptr()), grid, 5, C.byref(ms2))
+                         C.c_uint32(deep_log2), C.c_uint32(k1), C.c_uint32(max_len), C.c_void_p(cnt.data_ptr()), grid, 5, C.byref(ms2), steps)
     torch.cuda.synchronize()
     c = cnt.cpu().numpy()
-    print(f"K2 walks rc {rc} grid {grid}: {ms2.value:.3f} ms; events {c[0]} (product {n_events}), hits {c[1]} (product {n}), "
+    print(f"K2 walks rc {rc} grid {grid} deep steps <= {steps}: {ms2.value:.3f} ms; events {c[0]} (product {n_events}), hits {c[1]} (product {n}), "
           f"starts with more than 4 END steps {c[3]}, candidates {c[4]}, pair hits {c[5]}", flush=True)
 print(f"K1 + K2: {ms1.value + ms2.value:.3f} ms against the product traversal's {t['ms_count']:.3f} ms", flush=True)

@@ -685,12 +685,12 @@ def test_host_entry_pipeline_and_buffer_api(engine):
 
 
 # ---- the headline configuration at FULL size ----------------------------------
-@pytest.mark.parametrize("cfg", [3])
+@pytest.mark.parametrize("cfg", [2, 3])
 def test_full_size_properties(cfg, engine):
-    """BASELINE config 3 at full size (100k keys, 1 GiB): size-independent
+    """BASELINE configs 2 (1k ASCII keys, 64 MiB) and 3 (100k keys, 1 GiB) at their full sizes: size-independent
     properties instead of a full oracle run -- ordering, every hit spells its
     key, document independence (any split of the batch gives the same hits),
-    engine agreement by checksum -- plus the oracle on a sample of documents."""
+    engine agreement by checksum -- plus the oracle on a sample of documents (cfg 2: on ALL of them: 64 MiB are cheap)."""
     if engine not in ("v2", "u", "auto"):
         pytest.skip("full-size run: the byte-level and the character-level traversals, and the library's own choice")
     import hashlib
@@ -741,6 +741,10 @@ def test_full_size_properties(cfg, engine):
     assert hashlib.sha256(np.concatenate(parts).tobytes()).hexdigest() == h
     # (4) the oracle on a sample of whole documents
     o = orc.AC.compile_packed(blob, offs)
+    if cfg == 2:  # the whole batch against the oracle, offsets included
+        oh, od = o.match_batch(corpus, doc)
+        assert hits.tobytes() == oh.tobytes() and np.array_equal(offsets, od.astype(np.int64))
+        return
     for d in rng.integers(0, D, size=6):
         oh, _ = o.match_batch(corpus[int(doc[d]):int(doc[d + 1])], np.array([0, doc_len[d]], dtype=np.uint64))
         assert hits[offsets[d]:offsets[d + 1]].tobytes() == oh.tobytes()

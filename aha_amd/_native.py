@@ -49,10 +49,10 @@ class aha_ac_info_t(C.Structure):
                 ("n_slots", C.c_uint64), ("image_bytes", C.c_uint64), ("max_key_len", C.c_uint32),
                 ("slot_bytes", C.c_uint32), ("lds_slots", C.c_uint32), ("device", C.c_int32),
                 ("fail_s1_lo", C.c_uint32), ("fail_s2_lo", C.c_uint32), ("fail_hdr_lo", C.c_uint32),
-                ("reserved", C.c_uint32), ("unit_enabled", C.c_uint32), ("unit_slots", C.c_uint32),
+                ("unit_header_beside", C.c_uint32), ("unit_enabled", C.c_uint32), ("unit_slots", C.c_uint32),
                 ("unit_syms", C.c_uint32), ("unit_multi_permille", C.c_uint32), ("unit_big_lo", C.c_uint32),
                 ("unit_big_block", C.c_uint32), ("unit_n_low", C.c_uint32), ("unit_n_big", C.c_uint32),
-                ("unit_base_bits", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("unit_base_bits", C.c_uint32), ("unit_headers", C.c_uint32)]
 
 
 class aha_timing(C.Structure):

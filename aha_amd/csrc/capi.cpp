@@ -432,6 +432,10 @@ void v2_setup(aha_ac *ac) {
       ac->udev.base_bits = ac->unit.base_bits;
       ac->udev.n_syms = ac->unit.n_syms;
       ac->udev.max_len = a.max_key_len;
+      // text falls out of deep matches where many states own a fail header: then the header comes beside the probe (a second
+      // load in every trip) instead of in a trip of its own -- -8.5 % on cfg 5, +3.5 % on cfg 3 (profiles/r04_two_walks.txt)
+      const char *hb = getenv("AHA_UNIT_HEADER_BESIDE");  // 0 / 1: tests
+      ac->udev.hdr_beside = hb ? (uint32_t)(atoi(hb) != 0) : (uint32_t)((uint64_t)ac->unit.n_nfr * 5 >= ac->unit.n_states);
       ac->unit_ok = true;
     }
   }
@@ -1024,6 +1028,8 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *caller_info) {
   info->unit_n_low = ac->unit.n_low;
   info->unit_n_big = ac->unit.n_big;
   info->unit_base_bits = ac->unit.ok ? ac->unit.base_bits : 0;
+  info->unit_headers = ac->unit.ok ? ac->unit.n_nfr : 0;
+  info->unit_header_beside = ac->unit_ok ? ac->udev.hdr_beside : 0;
   copy_sized(caller_info, &full, caller_info->struct_size, sizeof(full), sizeof(full) - 24);
   return AHA_OK;
 }

@@ -139,6 +139,7 @@ struct UnitDev {
   uint32_t base_bits;      // 22 or 23 (unit.hpp, BASE WIDTH)
   uint32_t n_syms;
   uint32_t max_len;        // longest key, bytes
+  uint32_t hdr_beside;     // 1: the traversal requests a state's header beside its probe (scan_unit.hip ku_traverse<.., HB>)
 };
 size_t unit_lds_bytes(uint32_t n_syms);
 int unit_prepare(uint32_t n_syms);  // raises the dynamic-LDS limit; hipError_t as int

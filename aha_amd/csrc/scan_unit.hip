@@ -70,7 +70,11 @@ __host__ __device__ inline size_t u_lds(uint32_t n_syms) {
 // 0x80..0xBF: one per unit that does not start with a stray continuation byte -- of the lane's chunk up to and
 // including the unit, << 1 | "counted from the start of the document" (the format of k2_traverse<.., CHARS>: the
 // expansion adds the characters between the start of the document and the chunk).
-template <bool CHARS, int BB>
+// HB ("header beside"): the word of the fail state -- the state's header slot -- is requested beside the probe by the lanes whose
+// state has one, and a miss continues in the fail state in the SAME trip.  A second load in every trip (+3.5 % on cfg 3, whose
+// text rarely falls out of a deep match) against a trip per header (-8.5 % on cfg 5: 1.19 trips per byte); chosen per image when
+// it is compiled (capi.cpp: the share of states that own a header), reported in aha_ac_info_t.unit_header_beside.
+template <bool CHARS, int BB, bool HB>
 __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   if (M.cursor[1] >= 16ull) return;  // the doc offsets are not what the call says (k_check_docs ran in front): index nothing
@@ -270,9 +274,14 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             const uint32_t fc = BB == 22 ? (code & 7u) : min(code & 7u, 6u);
             const bool probe = act & good & (((E | 0x20000000u) >> ((uint32_t)BB + fc)) & 1u) != 0u & Bq != 0u;
             unsigned long long enw = 0;
+            uint32_t hdw = 0;
             {
               const uint2 *ap = slots + (probe ? (Bq ^ se) : 0u);
               asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(enw) : "v"(ap) : "memory");
+              if (HB) {  // the header of a state whose fail state is neither the root nor a one-character state
+                const uint2 *hp = slots + ((act & u_nfr(E) & !u_f1(E)) ? Bq : 0u);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(hdw) : "v"(hp) : "memory");
+              }
             }
             if (act) {
               uint32_t n_code, n_L;
@@ -286,7 +295,10 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
               // fails to
               const uint32_t rt = rl[code];
               const uint32_t rf = rl[pc];
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(enw) : : "memory");
+              if (HB)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(enw), "+v"(hdw) : : "memory");
+              else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(enw) : : "memory");
               const uint32_t enx = (uint32_t)enw, eny = (uint32_t)(enw >> 32);
               const bool symhit = probe & u_sym(eny) == se & !grp;  // (a group record's second word is a slot number)
               const bool hit = symhit & !hdr;
@@ -298,7 +310,8 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
               // else the unit is tried again in the fail state: root[the symbol that led here] (F1), or the state's header,
               // fetched by the next trip (falling into a state reports nothing: END is not carried)
               const bool viaroot = !symhit & !redir & (!u_nfr(E) | !good);
-              const uint32_t ft = u_f1(E) ? (rf & 0x7FFFFFFFu) : (Bq | u_all_filter(BB) | 0x20000000u);
+              // (HB: the header has come with the probe; else it is fetched by the next trip: "header pending")
+              const uint32_t ft = u_f1(E) ? (rf & 0x7FFFFFFFu) : (HB ? hdw : (Bq | u_all_filter(BB) | 0x20000000u));
               uint32_t missE = viaroot ? rt : ft;
               missE = redir ? rE : missE;
               E = symhit ? enx : missE;
@@ -667,21 +680,31 @@ size_t unit_lds_bytes(uint32_t n_syms) { return u_lds(n_syms); }
 
 int unit_prepare(uint32_t n_syms) {
   const int lds = (int)unit_lds_bytes(n_syms);
-  int e = (int)hipFuncSetAttribute((const void *)ku_traverse<false, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<true, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<false, 23>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<true, 23>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  int e = 0;
+#define AHA_PREP_KU(C, B, H) \
+  if (!e) e = (int)hipFuncSetAttribute((const void *)ku_traverse<C, B, H>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  AHA_PREP_KU(false, 22, false) AHA_PREP_KU(true, 22, false) AHA_PREP_KU(false, 23, false) AHA_PREP_KU(true, 23, false)
+  AHA_PREP_KU(false, 22, true) AHA_PREP_KU(true, 22, true) AHA_PREP_KU(false, 23, true) AHA_PREP_KU(true, 23, true)
+#undef AHA_PREP_KU
   return e;
 }
 
 void unit_launch_traverse(const UnitDev &U, const V2Args &M, uint32_t grid, void *stream) {
   const size_t lds = unit_lds_bytes(U.n_syms);
-#define AHA_LAUNCH_KU(C, B) hipLaunchKernelGGL((ku_traverse<C, B>), dim3(grid), dim3(kV2Threads), lds, (hipStream_t)stream, U, M)
+#define AHA_LAUNCH_KU(C, B, H) hipLaunchKernelGGL((ku_traverse<C, B, H>), dim3(grid), dim3(kV2Threads), lds, (hipStream_t)stream, U, M)
+#define AHA_LAUNCH_KU2(C, B) \
+  do {                       \
+    if (U.hdr_beside)        \
+      AHA_LAUNCH_KU(C, B, true);  \
+    else                     \
+      AHA_LAUNCH_KU(C, B, false); \
+  } while (0)
   if (U.base_bits == 23) {
-    if (M.chars) AHA_LAUNCH_KU(true, 23); else AHA_LAUNCH_KU(false, 23);
+    if (M.chars) AHA_LAUNCH_KU2(true, 23); else AHA_LAUNCH_KU2(false, 23);
   } else {
-    if (M.chars) AHA_LAUNCH_KU(true, 22); else AHA_LAUNCH_KU(false, 22);
+    if (M.chars) AHA_LAUNCH_KU2(true, 22); else AHA_LAUNCH_KU2(false, 22);
   }
+#undef AHA_LAUNCH_KU2
 #undef AHA_LAUNCH_KU
 }
 

@@ -53,7 +53,7 @@ lib LibAhaHip
     longest : Int32 # 0 = #match, 1 = #match_longest(intersectable: false), 2 = #match_longest(intersectable: true)
   end
 
-  # aha_ac_info_t (ABI 6)
+  # aha_ac_info_t (ABI 7)
   struct Info
     struct_size : UInt32
     n_keys : UInt32
@@ -67,7 +67,7 @@ lib LibAhaHip
     fail_s1_lo : UInt32
     fail_s2_lo : UInt32
     fail_hdr_lo : UInt32
-    reserved : UInt32
+    unit_header_beside : UInt32 # ABI 7: the traversal requests a fail header beside its probe
     unit_enabled : UInt32
     unit_slots : UInt32
     unit_syms : UInt32
@@ -77,7 +77,7 @@ lib LibAhaHip
     unit_n_low : UInt32
     unit_n_big : UInt32
     unit_base_bits : UInt32
-    reserved2 : UInt32
+    unit_headers : UInt32       # ABI 7: states that own a fail header
   end
 
   # aha_timing (ABI 6): filled when profiling is on

@@ -115,7 +115,10 @@ typedef struct {
   uint32_t fail_s1_lo;
   uint32_t fail_s2_lo;
   uint32_t fail_hdr_lo;
-  uint32_t reserved;
+  uint32_t unit_header_beside;  /* ABI 7 (was reserved): 1 = the character-level traversal requests a state's fail header beside
+                                 * its probe instead of in a trip of its own -- chosen when the image is compiled, for key sets
+                                 * where at least a fifth of the states own a header (text then falls out of deep matches often:
+                                 * -8.5 % on BASELINE config 5, +3.5 % on config 3, which keeps the header trip) */
   /* Character-level image (aha_amd/csrc/unit.hpp), built when every key is a sequence of UTF-8-shaped units, at least
    * 30 % of the key bytes lie in multi-byte characters and the keys' characters fit the symbol table (AHA_ENGINE=unit:
    * for every eligible key set).  1 = this handle's matches without a separator filter -- byte or char offsets -- take
@@ -135,7 +138,8 @@ typedef struct {
   uint32_t unit_n_big;
   uint32_t unit_base_bits;      /* 22, or 23 for an image beyond 2^22 slots: width of the base field of a state word; the
                                  * filter takes the bits from there up to bit 28 (7 or 6 of them) */
-  uint32_t reserved2;
+  uint32_t unit_headers;        /* ABI 7 (was reserved): states of the character-level image that own a fail header (their fail
+                                 * state is neither the root nor a one-character state) */
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded

@@ -65,7 +65,7 @@ while time.time() < t_end:
            "AHA_SHADOW_FAIL": rng.choice([None, None, None, "0"]),
            "AHA_ENGINE": rng.choice([None, None, "unit", "unit", "v2", "v1"]),
            "AHA_UNIT_POST": rng.choice([None, None, "regroup"]),
-           "AHA_UNIT_WALKS": rng.choice([None, None, "2"]),
+           "AHA_UNIT_HEADER_BESIDE": rng.choice([None, "0", "1"]),
            "AHA_UNIT_BASE_BITS": rng.choice([None, None, "23"]),
            "AHA_DIRECT": rng.choice([None, None, "0"])}
     for k, v in env.items():
@@ -120,6 +120,13 @@ while time.time() < t_end:
                 np.array_equal(np.asarray(gdo, dtype=np.uint64), np.asarray(od, dtype=np.uint64))
             for shard in range(n_shards):
                 ok = ok and grp.download_shard(shard).tobytes() == np.asarray(gh).tobytes()
+            if ok and rng.random() < 0.5:  # the resident entry: the ranges stay on the device, the hits too
+                res = grp.upload_corpus(text, doc)
+                rn, rdo = grp.match_corpus(res, chars=chars)
+                ok = rn == len(oh) and np.array_equal(np.asarray(rdo, dtype=np.uint64), np.asarray(od, dtype=np.uint64))
+                for shard in range(n_shards):
+                    ok = ok and grp.download_shard(shard).tobytes() == np.asarray(gh).tobytes()
+                del res
             if not ok:
                 print("GROUP MISMATCH seed", seed, "keys", len(keys), "env", env, "shards", n_shards, "n", text.size,
                       "docs", doc.size - 1, "chars", chars, flush=True)

@@ -78,7 +78,7 @@ if tr:
             per[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     u = json.load(open(os.path.join(src, "bench_under_rocprof.json")))
     with open(f"profiles/{rnd}_kernel_trace_full_size.txt", "w") as fo:
-        fo.write("# rocprofv3 --kernel-trace of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`: launches longer than half\n"
+        fo.write("# rocprofv3 --kernel-trace of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end`: launches longer than half\n"
                  "# the kernel's longest one (= the full-size launches of the timed steps, warm-ups and parity pass), ms\n"
                  f"# bench.py's own HIP-event average in the same process: {u['roofline']['kernel']} {u['roofline']['avg_ms']} ms\n")
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):

@@ -52,6 +52,7 @@ del out
 # ---- K1: the pair filter
 L1 = C.CDLL(os.path.join(ROOT, "tools/lab/libproto_k1.so"))
 L2 = C.CDLL(os.path.join(ROOT, "tools/lab/libproto_k2.so"))
+L3 = C.CDLL(os.path.join(ROOT, "tools/lab/libproto_k3.so"))
 lentab = np.full(256, 8, dtype=np.uint8); lentab[0xC0:0xE0] = 16; lentab[0xE0:0xF0] = 24
 db = torch.from_numpy(bloom.view(np.int32)).cuda(); dl = torch.from_numpy(lentab).cuda()
 bitmap = torch.zeros(n_bytes // 64 + 64, dtype=torch.int64, device="cuda")
@@ -66,7 +67,7 @@ print(f"K1 filter rc {rc}: {ms1.value:.3f} ms", flush=True)
 dd_ = torch.from_numpy(disp).cuda(); dp = torch.from_numpy(pairs.view(np.int32)).cuda(); de = torch.from_numpy(deep.view(np.int32)).cuda()
 cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
 ms2 = C.c_float(0)
-for grid, steps in ((1024, 40), (1024, 0), (1024, 1), (1024, 2)):
+for grid, steps in ((1024, 40),):
     rc = L2.proto_k2_run(C.c_void_p(dc.data_ptr()), C.c_uint64(n_bytes), C.c_void_p(bitmap.data_ptr()), C.c_void_p(dd_.data_ptr()),
                          C.c_void_p(dp.data_ptr()), C.c_void_p(de.data_ptr()), C.c_uint32(n_groups), C.c_uint32(pair_log2),
                          C.c_uint32(deep_log2), C.c_uint32(k1), C.c_uint32(max_len), C.c_void_p(cnt.data_ptr()), grid, 5, C.byref(ms2), steps)
@@ -74,4 +75,13 @@ for grid, steps in ((1024, 40), (1024, 0), (1024, 1), (1024, 2)):
     c = cnt.cpu().numpy()
     print(f"K2 walks rc {rc} grid {grid} deep steps <= {steps}: {ms2.value:.3f} ms; events {c[0]} (product {n_events}), hits {c[1]} (product {n}), "
           f"starts with more than 4 END steps {c[3]}, candidates {c[4]}, pair hits {c[5]}", flush=True)
-print(f"K1 + K2: {ms1.value + ms2.value:.3f} ms against the product traversal's {t['ms_count']:.3f} ms", flush=True)
+ms3 = C.c_float(0)
+for grid in (512, 1024):
+    rc = L3.proto_k3_run(C.c_void_p(dc.data_ptr()), C.c_uint64(n_bytes), C.c_void_p(bitmap.data_ptr()), C.c_void_p(dd_.data_ptr()),
+                         C.c_void_p(dp.data_ptr()), C.c_void_p(de.data_ptr()), C.c_uint32(n_groups), C.c_uint32(pair_log2),
+                         C.c_uint32(deep_log2), C.c_uint32(k1), C.c_uint32(max_len), C.c_void_p(cnt.data_ptr()), grid, 5, C.byref(ms3))
+    torch.cuda.synchronize()
+    c = cnt.cpu().numpy()
+    print(f"K3 walks (lane per piece, two pair probes + a walker step in flight) rc {rc} grid {grid}: {ms3.value:.3f} ms; events {c[0]} "
+          f"(product {n_events}), hits {c[1]} (product {n}), overflows {c[2]}, candidates {c[3]}, walkers {c[4]}, wave-iterations {c[5]}", flush=True)
+print(f"K1 + K3: {ms1.value + ms3.value:.3f} ms against the product traversal's {t['ms_count']:.3f} ms", flush=True)

@@ -149,6 +149,15 @@ class HitGatherer:
             if self.exchange == "words" and self._fmt[1] == 0 and ac.n_keys > (1 << 20):
                 raise ValueError("the 4-byte exchange stream holds key ids below 2^20")
             self._klen = None if self._cuda else torch.from_numpy(ac.key_lengths(chars))
+            # the stream carries no format tag: every rank must pack and unpack with the same field widths, i.e. run the same
+            # library build over the same keys -- agreed once, before the first payload travels
+            from . import _native as _N
+            mine = torch.tensor([int(_N.lib().aha_abi_version()), int(self._fmt[0]), int(self._fmt[1]), int(ac.n_keys)],
+                                dtype=torch.int64, device=device)
+            every = torch.zeros(self.world * 4, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(every, mine, group=group)
+            if not bool((every.view(self.world, 4) == mine).all()):
+                raise RuntimeError(f"ranks disagree on ABI / exchange stream format / key count: {every.view(self.world, 4).tolist()}")
 
     # -- payload: what this rank sends to every peer -----------------------------------
     def _payload(self, hits, n, slot):

@@ -73,6 +73,12 @@ struct aha_ac {
   uint32_t v2_lds_slots = 0;
   uint32_t v2_grid = 0;
   uint32_t v2_bpc = 1;
+  // prefix-filter engine (scan_filter.hip): blocked Bloom filter over the keys' first pf_d bytes; usable when the keys are at
+  // least 3 bytes long, none longer than 64, the image compact and the filter at most a quarter full
+  std::vector<uint32_t> pf_bloom;
+  uint32_t pf_d = 0;
+  bool pf_ok = false;
+  FilterDev fdev{};
   uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
   // character-level image (unit.hpp, scan_unit.hip): built for key sets of UTF-8-shaped units with mostly multi-byte
   // characters; plain byte-offset matches through the event regions then take one step per character
@@ -391,6 +397,10 @@ void v2_setup(aha_ac *ac) {
   if (reserve < 0 || reserve >= cus) reserve = 0;
   ac->v2_grid = (uint32_t)(cus - reserve) * ac->v2_bpc;
   ac->v2_ok = true;
+  if (ac->pf_d && upload(ac, ac->pf_bloom, &ac->fdev.bloom) == AHA_OK) {
+    ac->fdev.d = ac->pf_d;
+    ac->pf_ok = true;
+  }
   // character-level engine: one step per UTF-8-shaped unit (unit.hpp).  One workgroup per CU: its LDS holds the root's
   // transitions of the whole alphabet.
   if (ac->unit.ok && ac->v2_bpc == 1 && unit_lds_bytes(ac->unit.n_syms) <= kLdsPerCU) {
@@ -492,6 +502,10 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   uint64_t lanes = (uint64_t)ac->v2_grid * kV2Threads;
   uint64_t S = ((N + lanes - 1) / lanes + 63) / 64 * 64;
   S = std::min<uint64_t>(std::max<uint64_t>(S, s_min), kV2MaxS);
+  // the prefix-filter engine: byte offsets, no separator filter, the event regions; chunks of 4 KiB (a wave's tile)
+  const bool filt = ac->pf_ok && !ac->unit_ok && !M1.chars && !M1.sep && !M1.no_filter && mode != kSlabs &&
+                    !(de && strcmp(de, "0") == 0);
+  if (filt) S = 4096;
   V2Args M{};
   M.text = M1.text;
   M.doc_off = M1.doc_off;
@@ -514,7 +528,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (de && strcmp(de, "0") == 0) mode = kSlabs;
   // (the character-level engine leaves its events wave by wave and expands them group by group: its cost follows the
   // events too, so a handle that has it keeps the regions for sparse batches)
-  if (M.sep || (mode == kRegions && sparse && !ac->unit_ok)) mode = kSlabs;
+  if (M.sep || (mode == kRegions && sparse && !ac->unit_ok && !filt)) mode = kSlabs;
   if (mode == kRegions && dense) mode = kFullRegions;
   uint64_t stride = S;
   // twice the average the caller allows for, plus a slack of 1/64 of the chunk (64 events at 4 KiB): 16 bytes per hit of
@@ -542,7 +556,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
                       M.chars ? M.n_chunks * 8 : 0,
                       (unit && ac->unit_fused) ? 0 : n_reg * 8, 0 /* [17]: aligned copy of an unaligned corpus */,
                       direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
-                      unit ? (M.n_docs + 1) * 4 : 0, unit ? n_reg * 12 : 0, 0, 0};
+                      unit ? (M.n_docs + 1) * 4 : 0, unit ? n_reg * 12 : 0,
+                      filt ? ((N + 63) / 64 + 2) * 8 : 0 /* [22]: candidate bitmap */, filt ? M.n_chunks * 4 : 0 /* [23] */};
   for (int i = 0; i < 24; i++) {
     if (!sizes[i]) continue;
     if ((rc = v2_reserve(ac, sc, i, sizes[i]))) {
@@ -590,6 +605,11 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     post.end_info = ac->d_unit_end_info;  // events carry bases of the unit image
     post.compact = 1;
     unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+  } else if (filt) {
+    // filter (one bit per byte position), then the candidates' goto walks, a wave per chunk; cursor[5] counts the candidates
+    filter_launch_filter(ac->fdev, M.text, N, sc->v2buf[22].p, M.cursor + 5, ac->v2_grid, s);
+    filter_launch_walk(ac->dev, M, sc->v2buf[22].p, (uint32_t *)sc->v2buf[23].p,
+                       (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((M.n_chunks + 3) / 4, (uint64_t)ac->v2_grid * 4)), s);
   } else {
     v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   }
@@ -626,6 +646,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     return AHA_E_TOO_LONG;
   }
   M1.check_docs = 0;  // (looked at: a repeated pass or the two-pass engine need not look again)
+  if (sc->h_v2[1] == 3) return 3;  // the prefix-filter engine gave up (candidates too dense, nested keys): the caller repeats without it
   if (sc->h_v2[1] == 2) return 2;  // a chunk's event region overflowed: the caller repeats with full-size regions
   if (sc->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = sc->h_v2[2];
@@ -633,7 +654,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
-    t.engine = unit ? 4 : 2;
+    t.engine = unit ? 4 : (filt ? 5 : 2);
     t.chunk_bytes = M.S;
     t.n_kernels = 9;
     (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
@@ -804,6 +825,33 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     const char *eng = getenv("AHA_ENGINE");
     if (!eng || strcmp(eng, "unit") == 0) build_unit(ac->aut, ac->unit, eng != nullptr);
     if (getenv("AHA_DEBUG") && !ac->unit.ok) fprintf(stderr, "aha: no character-level image: %s\n", ac->unit.why);
+    // prefix filter (scan_filter.hip): the keys' first D = min(4, shortest key) bytes in a blocked Bloom filter of 64 KiB.
+    // For key sets of at least 3-byte keys (a shorter prefix passes too much text), none beyond 64 bytes (a walk's reach
+    // into the next chunk), compact images, and a filter at most a quarter full.  AHA_ENGINE=filter / unset: built;
+    // v2 / v1 / unit: not.
+    if ((!eng || strcmp(eng, "filter") == 0) && !ac->unit.ok && ac->img.compact && ac->aut.n_keys > 0 && ac->aut.max_key_len <= 64) {
+      uint32_t minlen = ~0u;
+      for (uint32_t k = 0; k < ac->aut.n_keys; k++) minlen = std::min(minlen, ac->aut.key_len[k]);
+      if (minlen >= 3) {
+        const uint32_t D = std::min(4u, minlen);
+        ac->pf_bloom.assign((size_t)1 << kFilterLog2, 0u);
+        for (uint32_t k = 0; k < ac->aut.n_keys; k++) {
+          uint32_t w = 0;
+          for (uint32_t j = 0; j < D; j++) w |= (uint32_t)ac->aut.blob[ac->aut.offs[k] + j] << (8 * j);
+          uint32_t h = w * 0x9E3779B1u;  // (kf_hash)
+          h ^= h >> 15;
+          ac->pf_bloom[h >> (32 - kFilterLog2)] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+        }
+        uint64_t bits = 0;
+        for (uint32_t x : ac->pf_bloom) bits += (uint64_t)__builtin_popcount(x);
+        if (bits * 4 <= ((uint64_t)32 << kFilterLog2)) {
+          ac->pf_d = D;
+        } else {
+          std::vector<uint32_t>().swap(ac->pf_bloom);
+          if (getenv("AHA_DEBUG")) fprintf(stderr, "aha: no prefix filter: it would be more than a quarter full\n");
+        }
+      }
+    }
   }
   if (!(flags & AHA_OPT_HOST_ONLY)) {
     const int32_t rc = attach_device(ac, device);
@@ -836,6 +884,8 @@ int32_t aha_ac_replicate(const aha_ac *src, int32_t device, aha_ac **out) {
     ac->s2_lo = src->s2_lo;
     ac->s2_hi = src->s2_hi;
     ac->unit = src->unit;
+    ac->pf_bloom = src->pf_bloom;
+    ac->pf_d = src->pf_d;
     ac->seg2 = src->seg2;
     ac->state_base = src->state_base;
   } catch (...) {
@@ -1368,8 +1418,17 @@ static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpu
   uint32_t repeats = 0;  // passes thrown away (aha_timing.repeats)
   if (ac->v2_ok) {
     rc = match_v2(ac, sc, M, s, n_hits, kRegions);
+    if (rc == 3) {  // the prefix-filter engine handed the batch back: once more on the byte-level engine
+      repeats++;
+      M.no_filter = 1;
+      rc = match_v2(ac, sc, M, s, n_hits, kRegions);
+    }
     if (rc == 2) {  // denser than cap said: regions of one event per byte
       repeats++;
+      rc = match_v2(ac, sc, M, s, n_hits, kFullRegions);
+    }
+    if (rc == 3) {
+      M.no_filter = 1;
       rc = match_v2(ac, sc, M, s, n_hits, kFullRegions);
     }
     if (rc == 2) rc = match_v2(ac, sc, M, s, n_hits, kSlabs);  // (not reached: full-size regions cannot overflow)

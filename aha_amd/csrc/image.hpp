@@ -51,6 +51,7 @@ struct MatchArgs {
   int32_t sep;               // 1: match(seq, sep) (ac.cr:321-340)
   uint32_t sep_block[8];     // bit c set <=> (c < sep.size && !sep[c])
   int32_t has_nul;           // match_longest, chunked form: the batch holds NUL bytes (the warm-ups look for them)
+  int32_t no_filter;         // host side: this call has been handed back by the prefix-filter engine (scan_filter.hip)
   int32_t check_docs;        // host side: the device-resident doc offsets have not been validated yet -- the single-traversal
                              // pipelines do it on the device, in front of the traversal, without a round trip to the host
   // scratch
@@ -150,6 +151,18 @@ void unit_launch_regroup(const DevAut &A, const V2Args &M, void *stream);  // ev
 void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, uint32_t workgroups, void *stream);
 void v2_launch_hit_scan(const V2Args &M, void *stream);   // chunk_hits -> hit_base, totals[0]
 void v2_launch_lead_scan(const V2Args &M, void *stream);  // lead_cnt -> lead_base, totals[1] (char offsets)
+
+// ---- prefix-filter engine (scan_filter.hip): byte-level, for batches where few positions can start a key
+constexpr uint32_t kFilterLog2 = 14;  // 2^14 words = 64 KiB: blocked Bloom filter over the keys' first D bytes
+struct FilterDev {
+  const uint32_t *bloom;
+  uint32_t d;  // bytes of a key the filter looks at: min(4, shortest key)
+};
+size_t filter_walk_lds();
+void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, unsigned long long *n_cand,
+                          uint32_t grid, void *stream);
+// bitmap (one bit per byte position) -> evd / ev_cnt / doc_ev_rank of chunks of 4096 bytes; chunk_dn: n_chunks words of scratch
+void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, uint32_t *chunk_dn, uint32_t grid, void *stream);
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int

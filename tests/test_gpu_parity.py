@@ -17,7 +17,7 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u23", "uh", "auto"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u23", "uh", "f", "auto"], autouse=True)
 def engine(request, monkeypatch):
     """Every parity test runs on the single-traversal engine (scan_v2.hip, byte level), on the two-pass engine
     (kernels.hip: the fallback for tiny capacities and very long keys), on the single-traversal engine with its LDS
@@ -29,13 +29,18 @@ def engine(request, monkeypatch):
     regroup + count + expand passes; "u23" --
     AHA_UNIT_BASE_BITS=23 -- builds every image in the wide format of images beyond 2^22 slots: 23-bit bases, 6-bit filter,
     3-bit hit count in the event record; "uh" -- AHA_UNIT_HEADER_BESIDE=1 -- the traversal that requests a state's fail header
-    beside its probe, ku_traverse<.., HB>, which the library picks for key sets like cfg 5's; "u" pins the header trip).  "auto" sets
+    beside its probe, ku_traverse<.., HB>, which the library picks for key sets like cfg 5's; "u" pins the header trip; "f" --
+    AHA_ENGINE=filter -- the prefix-filter engine, scan_filter.hip, for every key set it takes: keys of 3 to 64 bytes, byte
+    offsets, no separator filter -- what the library picks for such key sets when they get no character-level image).  "auto" sets
     no variable: the library decides per key set, which is what a caller and bench.py get.  The variables are read when a
     handle is compiled."""
+    only = os.environ.get("AHA_TEST_ENGINES")  # (development: run the suite on some variants only, e.g. AHA_TEST_ENGINES=f,auto)
+    if only and request.param not in only.split(","):
+        pytest.skip("variant not selected by AHA_TEST_ENGINES")
     if request.param == "auto":
         monkeypatch.delenv("AHA_ENGINE", raising=False)
     else:
-        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u23": "unit", "uh": "unit"}.get(request.param, "v2"))
+        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u23": "unit", "uh": "unit", "f": "filter"}.get(request.param, "v2"))
     if request.param in ("u", "uh"):
         monkeypatch.setenv("AHA_UNIT_HEADER_BESIDE", "1" if request.param == "uh" else "0")
     else:
@@ -480,7 +485,7 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
             t0 = time.perf_counter()
             assert g.match_batch_device(view, dd, out) == n
             best = min(best, time.perf_counter() - t0)
-        assert g.last_timing()["engine"] == (4 if engine in ("u", "u23", "uh") else 2)
+        assert g.last_timing()["engine"] == (4 if engine in ("u", "u23", "uh") else 5 if engine == "f" else 2)
         res[shift] = (best, out[:n].cpu().numpy().tobytes())
     assert res[0][1] == res[1][1]
     assert res[0][0] / res[1][0] >= 0.7, (res[0][0], res[1][0])
@@ -492,11 +497,11 @@ def test_engine_selected(engine, monkeypatch):
     ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u23", "uh", "auto") else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u23", "uh", "auto") else (2, 5) if engine == "f" else (2,))
     ac = AC.compile(["ab", "ba"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"ab ba " * 60))[:3] == [(0, 2, 0), (3, 5, 1), (6, 8, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u23", "uh", "auto") else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u23", "uh", "auto") else (2, 5) if engine == "f" else (2,))
     if engine in ("u", "ur", "u23", "uh"):
         # the library's own choice (no AHA_ENGINE): keys of multi-byte characters get the character-level traversal for
         # byte- and char-offset batches, ASCII keys keep the byte-level one
@@ -516,10 +521,10 @@ def test_engine_selected(engine, monkeypatch):
         asc = AC.compile(["abc", "bcd"])
         asc.set_profiling(True)
         asc.match_array(b"abcd" * 3000)
-        assert asc.info["unit_enabled"] == 0 and asc.last_timing()["engine"] == 2
+        assert asc.info["unit_enabled"] == 0 and asc.last_timing()["engine"] == 5  # keys of 3 bytes: the prefix-filter engine
     # char offsets run on the character-level engine too, the separator filter on the byte-level engines only
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4) if engine in ("u", "ur", "u23", "uh", "auto") else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u23", "uh", "auto") else (2, 5) if engine == "f" else (2,))
     sep = BitArray(256)
     sep[ord(" ")] = True
     assert [tuple(h) for h in ac.match("ab ba", sep)] == [(0, 2, 0), (3, 5, 1)]
@@ -697,7 +702,7 @@ def test_full_size_properties(cfg, engine):
     properties instead of a full oracle run -- ordering, every hit spells its
     key, document independence (any split of the batch gives the same hits),
     engine agreement by checksum -- plus the oracle on a sample of documents (cfg 2: on ALL of them: 64 MiB are cheap)."""
-    if engine not in ("v2", "u", "auto"):
+    if engine not in ("v2", "u", "f", "auto"):
         pytest.skip("full-size run: the byte-level and the character-level traversals, and the library's own choice")
     import hashlib
 

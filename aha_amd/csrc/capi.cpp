@@ -77,6 +77,8 @@ struct aha_ac {
   // least 3 bytes long, none longer than 64, the image compact and the filter at most a quarter full
   std::vector<uint32_t> pf_bloom;
   uint32_t pf_d = 0;
+  uint32_t pf_cus = 0;
+  uint32_t pf_log2 = 0;
   bool pf_ok = false;
   FilterDev fdev{};
   uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
@@ -397,8 +399,10 @@ void v2_setup(aha_ac *ac) {
   if (reserve < 0 || reserve >= cus) reserve = 0;
   ac->v2_grid = (uint32_t)(cus - reserve) * ac->v2_bpc;
   ac->v2_ok = true;
-  if (ac->pf_d && upload(ac, ac->pf_bloom, &ac->fdev.bloom) == AHA_OK) {
+  if (ac->pf_d && filter_prepare() == 0 && upload(ac, ac->pf_bloom, &ac->fdev.bloom) == AHA_OK) {
     ac->fdev.d = ac->pf_d;
+    ac->fdev.log2 = ac->pf_log2;
+    ac->pf_cus = (uint32_t)(cus - reserve);
     ac->pf_ok = true;
   }
   // character-level engine: one step per UTF-8-shaped unit (unit.hpp).  One workgroup per CU: its LDS holds the root's
@@ -502,10 +506,14 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   uint64_t lanes = (uint64_t)ac->v2_grid * kV2Threads;
   uint64_t S = ((N + lanes - 1) / lanes + 63) / 64 * 64;
   S = std::min<uint64_t>(std::max<uint64_t>(S, s_min), kV2MaxS);
-  // the prefix-filter engine: byte offsets, no separator filter, the event regions; chunks of 4 KiB (a wave's tile)
+  // the prefix-filter engine: byte offsets, no separator filter, the event regions; a wave takes a chunk of 4, 8 or 16 KiB
+  // (the larger, the fuller its batches of 64 candidates; at least 16 chunks per wave of the device all the same)
   const bool filt = ac->pf_ok && !ac->unit_ok && !M1.chars && !M1.sep && !M1.no_filter && mode != kSlabs &&
                     !(de && strcmp(de, "0") == 0);
-  if (filt) S = 4096;
+  if (filt) {
+    S = 4096;
+    while (S < 16384 && N / (2 * S) >= (uint64_t)ac->pf_cus * 16 * 4) S *= 2;
+  }
   V2Args M{};
   M.text = M1.text;
   M.doc_off = M1.doc_off;
@@ -557,7 +565,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
                       (unit && ac->unit_fused) ? 0 : n_reg * 8, 0 /* [17]: aligned copy of an unaligned corpus */,
                       direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
                       unit ? (M.n_docs + 1) * 4 : 0, unit ? n_reg * 12 : 0,
-                      filt ? ((N + 63) / 64 + 2) * 8 : 0 /* [22]: candidate bitmap */, filt ? M.n_chunks * 4 : 0 /* [23] */};
+                      filt ? ((N + 63) / 64 + 2) * 8 : 0 /* [22]: candidate bitmap */, filt ? M.n_chunks * filter_chunk_rec_bytes() : 0 /* [23] */};
   for (int i = 0; i < 24; i++) {
     if (!sizes[i]) continue;
     if ((rc = v2_reserve(ac, sc, i, sizes[i]))) {
@@ -606,10 +614,9 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     post.compact = 1;
     unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   } else if (filt) {
-    // filter (one bit per byte position), then the candidates' goto walks, a wave per chunk; cursor[5] counts the candidates
-    filter_launch_filter(ac->fdev, M.text, N, sc->v2buf[22].p, M.cursor + 5, ac->v2_grid, s);
-    filter_launch_walk(ac->dev, M, sc->v2buf[22].p, (uint32_t *)sc->v2buf[23].p,
-                       (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((M.n_chunks + 3) / 4, (uint64_t)ac->v2_grid * 4)), s);
+    // filter (one bit per byte position), then the candidates' goto walks, a wave per chunk
+    filter_launch_filter(ac->fdev, M.text, N, sc->v2buf[22].p, ac->pf_cus, s);
+    filter_launch_walk(ac->dev, M, sc->v2buf[22].p, sc->v2buf[23].p, ac->pf_cus, s);
   } else {
     v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   }
@@ -834,19 +841,26 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
       for (uint32_t k = 0; k < ac->aut.n_keys; k++) minlen = std::min(minlen, ac->aut.key_len[k]);
       if (minlen >= 3) {
         const uint32_t D = std::min(4u, minlen);
-        ac->pf_bloom.assign((size_t)1 << kFilterLog2, 0u);
-        for (uint32_t k = 0; k < ac->aut.n_keys; k++) {
-          uint32_t w = 0;
-          for (uint32_t j = 0; j < D; j++) w |= (uint32_t)ac->aut.blob[ac->aut.offs[k] + j] << (8 * j);
-          uint32_t h = w * 0x9E3779B1u;  // (kf_hash)
-          h ^= h >> 15;
-          ac->pf_bloom[h >> (32 - kFilterLog2)] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+        // the smallest filter (2^10 .. 2^kFilterLog2 words) that stays under 1/64 full (false candidates: about the square of that) -- every block of kf_filter stages it
+        // into LDS, 64 KiB of that is felt on a batch of 64 MiB -- or the largest while it is no more than a quarter full
+        for (uint32_t lg = 10; lg <= kFilterLog2; lg++) {
+          ac->pf_bloom.assign((size_t)1 << lg, 0u);
+          for (uint32_t k = 0; k < ac->aut.n_keys; k++) {
+            uint32_t w = 0;
+            for (uint32_t j = 0; j < D; j++) w |= (uint32_t)ac->aut.blob[ac->aut.offs[k] + j] << (8 * j);
+            uint32_t h = w * 0x9E3779B1u;  // (kf_hash)
+            h ^= h >> 15;
+            ac->pf_bloom[h >> (32 - lg)] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+          }
+          uint64_t bits = 0;
+          for (uint32_t x : ac->pf_bloom) bits += (uint64_t)__builtin_popcount(x);
+          if (bits * (lg < kFilterLog2 ? 64 : 4) <= ((uint64_t)32 << lg)) {
+            ac->pf_d = D;
+            ac->pf_log2 = lg;
+            break;
+          }
         }
-        uint64_t bits = 0;
-        for (uint32_t x : ac->pf_bloom) bits += (uint64_t)__builtin_popcount(x);
-        if (bits * 4 <= ((uint64_t)32 << kFilterLog2)) {
-          ac->pf_d = D;
-        } else {
+        if (!ac->pf_d) {
           std::vector<uint32_t>().swap(ac->pf_bloom);
           if (getenv("AHA_DEBUG")) fprintf(stderr, "aha: no prefix filter: it would be more than a quarter full\n");
         }
@@ -886,6 +900,8 @@ int32_t aha_ac_replicate(const aha_ac *src, int32_t device, aha_ac **out) {
     ac->unit = src->unit;
     ac->pf_bloom = src->pf_bloom;
     ac->pf_d = src->pf_d;
+    ac->pf_cus = src->pf_cus;
+    ac->pf_log2 = src->pf_log2;
     ac->seg2 = src->seg2;
     ac->state_base = src->state_base;
   } catch (...) {

@@ -133,6 +133,33 @@ __device__ __forceinline__ T wave_incl_scan(T v) {
   return v;
 }
 
+// 32-bit scans over the wave with DPP moves instead of six trips through the LDS crossbar (__shfl_up is ds_bpermute):
+// row_shr 1, 2, 4, 8 scan each row of 16 lanes; row_bcast15 adds the last lane of rows 0 / 2 to rows 1 / 3, row_bcast31 the
+// last lane of row 1 to rows 2 and 3.  A lane without a source (or in a row the mask leaves out) receives `old`, the
+// operation's identity.
+#define AHA_DPP_SCAN(V, ID, OP)                                                                   \
+  V = OP(V, (uint32_t)__builtin_amdgcn_update_dpp((int)(ID), (int)(V), 0x111, 0xf, 0xf, false)); \
+  V = OP(V, (uint32_t)__builtin_amdgcn_update_dpp((int)(ID), (int)(V), 0x112, 0xf, 0xf, false)); \
+  V = OP(V, (uint32_t)__builtin_amdgcn_update_dpp((int)(ID), (int)(V), 0x114, 0xf, 0xf, false)); \
+  V = OP(V, (uint32_t)__builtin_amdgcn_update_dpp((int)(ID), (int)(V), 0x118, 0xf, 0xf, false)); \
+  V = OP(V, (uint32_t)__builtin_amdgcn_update_dpp((int)(ID), (int)(V), 0x142, 0xa, 0xf, false)); \
+  V = OP(V, (uint32_t)__builtin_amdgcn_update_dpp((int)(ID), (int)(V), 0x143, 0xc, 0xf, false));
+__device__ __forceinline__ uint32_t dpp_op_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t dpp_op_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  AHA_DPP_SCAN(v, 0u, dpp_op_add)
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_max(uint32_t v) {
+  AHA_DPP_SCAN(v, 0u, dpp_op_max)
+  return v;
+}
+// lane i <- lane i - 1 (lane 0 <- first), lane 63's value for everyone
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t first) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+
 // exclusive scan over the block's kBlock threads; total returned via *total
 template <typename T>
 __device__ __forceinline__ T block_excl_scan(T v, T *smem /*[kBlock/64]*/, T *total) {

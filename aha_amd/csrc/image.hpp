@@ -156,13 +156,16 @@ void v2_launch_lead_scan(const V2Args &M, void *stream);  // lead_cnt -> lead_ba
 constexpr uint32_t kFilterLog2 = 14;  // 2^14 words = 64 KiB: blocked Bloom filter over the keys' first D bytes
 struct FilterDev {
   const uint32_t *bloom;
-  uint32_t d;  // bytes of a key the filter looks at: min(4, shortest key)
+  uint32_t d;     // bytes of a key the filter looks at: min(4, shortest key)
+  uint32_t log2;  // the filter has 2^log2 words (10 .. kFilterLog2)
 };
-size_t filter_walk_lds();
-void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, unsigned long long *n_cand,
-                          uint32_t grid, void *stream);
-// bitmap (one bit per byte position) -> evd / ev_cnt / doc_ev_rank of chunks of 4096 bytes; chunk_dn: n_chunks words of scratch
-void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, uint32_t *chunk_dn, uint32_t grid, void *stream);
+constexpr uint32_t kFilterImageLds = 96u << 10;  // kf_walk keeps an image up to this size in LDS, beside the waves' candidate lists
+bool filter_image_in_lds(uint32_t n_slots);
+int filter_prepare();  // once per process, before the first launch (LDS beyond 64 KiB is opt-in)
+void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, uint32_t cus, void *stream);
+// bitmap (one bit per byte position) -> evd / ev_cnt / doc_ev_rank of chunks of M.S bytes (4, 8 or 16 KiB); chunk_rec: n_chunks * filter_chunk_rec_bytes() of scratch
+size_t filter_chunk_rec_bytes();
+void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, void *chunk_rec, uint32_t cus, void *stream);
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int

@@ -24,9 +24,11 @@ void v2_launch_sort(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("
 void v2_launch_expand(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("v2_launch_expand"); }
 void v2_launch_direct_post(const DevAut &, const V2Args &, void *, void *, bool) { no_gpu("v2_launch_direct_post"); }
 void launch_has_nul(const uint8_t *, uint64_t, uint64_t *, void *) { no_gpu("launch_has_nul"); }
-size_t filter_walk_lds() { return 0; }
-void filter_launch_filter(const FilterDev &, const uint8_t *, uint64_t, void *, unsigned long long *, uint32_t, void *) { no_gpu("filter_launch_filter"); }
-void filter_launch_walk(const DevAut &, const V2Args &, const void *, uint32_t *, uint32_t, void *) { no_gpu("filter_launch_walk"); }
+bool filter_image_in_lds(uint32_t) { return false; }
+int filter_prepare() { return 0; }
+void filter_launch_filter(const FilterDev &, const uint8_t *, uint64_t, void *, uint32_t, void *) { no_gpu("filter_launch_filter"); }
+size_t filter_chunk_rec_bytes() { return 24; }
+void filter_launch_walk(const DevAut &, const V2Args &, const void *, void *, uint32_t, void *) { no_gpu("filter_launch_walk"); }
 void unit_launch_regroup(const DevAut &, const V2Args &, void *) { no_gpu("unit_launch_regroup"); }
 void unit_launch_expand(const uint2 *, const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("unit_launch_expand"); }
 void v2_launch_hit_scan(const V2Args &, void *) { no_gpu("v2_launch_hit_scan"); }

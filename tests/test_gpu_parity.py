@@ -520,8 +520,13 @@ def test_engine_selected(engine, monkeypatch):
             (600000, 600006, 0), (600003, 600009, 1), (600006, 600009, 2)]
         asc = AC.compile(["abc", "bcd"])
         asc.set_profiling(True)
-        asc.match_array(b"abcd" * 3000)
-        assert asc.info["unit_enabled"] == 0 and asc.last_timing()["engine"] == 5  # keys of 3 bytes: the prefix-filter engine
+        # keys of 3 bytes: the prefix-filter engine, while the text has few places where a key could start ...
+        got = asc.match_array(b"abcd" + b" " * 60 + (b"xbcdx" + b"-" * 59) * 300)
+        assert asc.info["unit_enabled"] == 0 and asc.last_timing()["engine"] == 5
+        assert len(got) == 302 and [tuple(h) for h in got[:3].tolist()] == [(0, 3, 0), (1, 4, 1), (65, 68, 1)]
+        # ... and a text that is nothing but key starts goes back to the byte-level engine (same hits, kf_walk gives up)
+        got = asc.match_array(b"abcd" * 3000)
+        assert asc.last_timing()["engine"] == 2 and len(got) == 6000
     # char offsets run on the character-level engine too, the separator filter on the byte-level engines only
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
     assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u23", "uh", "auto") else (2, 5) if engine == "f" else (2,))

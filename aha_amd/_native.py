@@ -52,7 +52,8 @@ class aha_ac_info_t(C.Structure):
                 ("unit_header_beside", C.c_uint32), ("unit_enabled", C.c_uint32), ("unit_slots", C.c_uint32),
                 ("unit_syms", C.c_uint32), ("unit_multi_permille", C.c_uint32), ("unit_big_lo", C.c_uint32),
                 ("unit_big_block", C.c_uint32), ("unit_n_low", C.c_uint32), ("unit_n_big", C.c_uint32),
-                ("unit_base_bits", C.c_uint32), ("unit_headers", C.c_uint32)]
+                ("unit_base_bits", C.c_uint32), ("unit_headers", C.c_uint32),
+                ("filter_prefix_bytes", C.c_uint32), ("filter_words", C.c_uint32)]
 
 
 class aha_timing(C.Structure):

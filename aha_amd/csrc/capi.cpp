@@ -79,6 +79,7 @@ struct aha_ac {
   uint32_t pf_d = 0;
   uint32_t pf_cus = 0;
   uint32_t pf_log2 = 0;
+  std::atomic<uint32_t> pf_skip{0}, pf_streak{0};  // calls to go without the filter; give-ups in a row
   bool pf_ok = false;
   FilterDev fdev{};
   uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
@@ -513,6 +514,10 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (filt) {
     S = 4096;
     while (S < 16384 && N / (2 * S) >= (uint64_t)ac->pf_cus * 16 * 4) S *= 2;
+    if (const char *fc = getenv("AHA_FILTER_CHUNK")) {  // the tests' way to the larger chunks without a batch of 128+ MiB
+      const long v = atol(fc);
+      if (v == 4096 || v == 8192 || v == 16384) S = (uint64_t)v;
+    }
   }
   V2Args M{};
   M.text = M1.text;
@@ -1096,7 +1101,10 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *caller_info) {
   info->unit_base_bits = ac->unit.ok ? ac->unit.base_bits : 0;
   info->unit_headers = ac->unit.ok ? ac->unit.n_nfr : 0;
   info->unit_header_beside = ac->unit_ok ? ac->udev.hdr_beside : 0;
-  copy_sized(caller_info, &full, caller_info->struct_size, sizeof(full), sizeof(full) - 24);
+  const bool pf = ac->device < 0 ? ac->pf_d != 0 : ac->pf_ok;
+  info->filter_prefix_bytes = pf ? ac->pf_d : 0;
+  info->filter_words = pf ? 1u << ac->pf_log2 : 0;
+  copy_sized(caller_info, &full, caller_info->struct_size, sizeof(full), sizeof(full) - 32);
   return AHA_OK;
 }
 
@@ -1433,11 +1441,22 @@ static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpu
   }
   uint32_t repeats = 0;  // passes thrown away (aha_timing.repeats)
   if (ac->v2_ok) {
+    // a handle whose batches keep coming back from the prefix-filter engine (text dense with key starts) skips it for 2, 4,
+    // .. 64 calls before it tries again: a batch that is handed back has paid for the filter and part of the walks
+    if (ac->pf_ok && ac->pf_skip.load(std::memory_order_relaxed) > 0) {
+      ac->pf_skip.fetch_sub(1, std::memory_order_relaxed);
+      M.no_filter = 1;
+    }
+    const bool tried = ac->pf_ok && !M.no_filter;
     rc = match_v2(ac, sc, M, s, n_hits, kRegions);
     if (rc == 3) {  // the prefix-filter engine handed the batch back: once more on the byte-level engine
       repeats++;
       M.no_filter = 1;
+      const uint32_t streak = std::min(ac->pf_streak.fetch_add(1, std::memory_order_relaxed) + 1, 6u);
+      ac->pf_skip.store(1u << streak, std::memory_order_relaxed);
       rc = match_v2(ac, sc, M, s, n_hits, kRegions);
+    } else if (tried && rc == AHA_OK) {
+      ac->pf_streak.store(0, std::memory_order_relaxed);
     }
     if (rc == 2) {  // denser than cap said: regions of one event per byte
       repeats++;

@@ -78,6 +78,8 @@ lib LibAhaHip
     unit_n_big : UInt32
     unit_base_bits : UInt32
     unit_headers : UInt32       # ABI 7: states that own a fail header
+    filter_prefix_bytes : UInt32 # ABI 7: the prefix-filter engine looks at this many first bytes of a key (0: none)
+    filter_words : UInt32       # ABI 7: 32-bit words of its Bloom filter
   end
 
   # aha_timing (ABI 6): filled when profiling is on

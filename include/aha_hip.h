@@ -140,6 +140,14 @@ typedef struct {
                                  * filter takes the bits from there up to bit 28 (7 or 6 of them) */
   uint32_t unit_headers;        /* ABI 7 (was reserved): states of the character-level image that own a fail header (their fail
                                  * state is neither the root nor a one-character state) */
+  /* ABI 7: the prefix-filter engine (aha_amd/csrc/scan_filter.hip; aha_timing.engine = 5).  Built for a key set without a
+   * character-level image whose keys are 3 .. 64 bytes long (a keyword list): a blocked Bloom filter over the keys' first
+   * filter_prefix_bytes bytes (min(4, shortest key); 0 = this handle has none) of filter_words 32-bit words.  Matches with
+   * byte offsets and no separator filter then look at every text position through the filter and walk the automaton only
+   * from the positions it lets through; a batch whose text is dense with such positions (more than about one in ten)
+   * is handed to the single-traversal engine by the call itself (aha_timing.repeats counts it). */
+  uint32_t filter_prefix_bytes;
+  uint32_t filter_words;
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded
@@ -154,7 +162,8 @@ typedef struct {
   float ms_aux;             /* engine 2: hits per chunk + scan (regions) or event sort (slabs); engine 1: char-offset prefix pass */
   uint64_t n_chunks;
   uint64_t n_hits;
-  uint32_t engine;          /* 4 = character-level traversal, 2 = single-traversal engine, 1 = two-pass engine */
+  uint32_t engine;          /* 5 = prefix filter + candidate walks, 4 = character-level traversal, 2 = single-traversal engine,
+                             * 1 = two-pass engine */
   uint32_t chunk_bytes;     /* bytes per lane chunk */
   /* ABI 6: passes over the batch that were thrown away before this one: 1 when a chunk's event region overflowed -- the
    * batch was denser than `cap` said -- and the match ran once more with full-size regions (the call took about twice

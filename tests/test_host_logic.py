@@ -383,7 +383,9 @@ def test_output_structs_respect_the_callers_size():
     ac = AC.compile(["ab", "abc"], host_only=True)
     L = N.lib()
     full = C.sizeof(N.aha_ac_info_t)
-    for said, filled in ((full, full), (full - 24, full - 24), (0, full - 24), (full + 64, full), (16, 16)):
+    abi5 = 80  # the struct before unit_big_lo .. (ABI 6) and the filter fields (ABI 7) were appended
+    assert full == 112
+    for said, filled in ((full, full), (full - 8, full - 8), (abi5, abi5), (0, abi5), (full + 64, full), (16, 16)):
         buf = (C.c_uint8 * (full + 64))(*([0xAA] * (full + 64)))
         C.cast(buf, C.POINTER(C.c_uint32))[0] = said
         assert L.aha_ac_info(ac._h, C.cast(buf, C.POINTER(N.aha_ac_info_t))) == 0

@@ -1,9 +1,10 @@
 """Differential fuzzing of the HIP path against the CPU oracle (test tooling, run on the GPU box):
 random automata (small alphabets -> deep fail links, UTF-8-like bytes, nested keys), random batches
 (ragged documents, NUL bytes), random image variants (compact/wide, capped LDS prefix, shadow fail
-links on/off, two-pass and character-level engines, the latter with the fused and with the general post passes),
+links on/off, two-pass, character-level and prefix-filter engines, the character-level one with the fused and with the
+general post passes, the prefix-filter one with every chunk size on keyword-list shaped cases: keys of 3+ bytes, sparse text),
 match_longest against the oracle (stale END flags included).  python tools/fuzz_gpu.py [seconds] [seed]"""
-import os, random, sys, time
+import faulthandler, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
@@ -17,16 +18,32 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
 ALPHABETS = [b"ab", b"abc", b"abcd", b"ab\xe4\xb8\x80", b"abcdefgh", b"xyz\xd0\xb0\xd1\x8f\xe4\xb8\xad\xe5\x9b\xbd",
              bytes(range(0x61, 0x7b)), bytes(range(1, 256))]
-n_cases = n_hits = n_long = n_group = 0
+n_cases = n_hits = n_long = n_group = n_filter = 0
 seed = seed0
 while time.time() < t_end:
     rng = random.Random(seed)
+    faulthandler.dump_traceback_later(180, exit=True)  # a case that takes three minutes is a hang: say where
     alpha = rng.choice(ALPHABETS)
     nk = rng.choice([1, 3, 20, 200, 2000, 20000])
     lo, hi = rng.choice([(1, 3), (1, 8), (2, 12), (1, 24)])
     keys, seen = [], set()
     tries = 0
     big = rng.random() < 0.2
+    kwl = not big and rng.random() < 0.3  # a keyword list: keys of 3+ bytes, text with few places where a key could start
+    if kwl:
+        alpha = rng.choice([bytes(range(0x61, 0x7b)), bytes(range(1, 256)), b"abcdefgh", b"ab\xe4\xb8\x80xyz"])
+        nk = rng.choice([3, 50, 1000, 1000, 20000])
+        lo, hi = rng.choice([(3, 6), (3, 12), (4, 16), (3, 40)])
+        while len(keys) < nk and tries < nk * 20:
+            tries += 1
+            if keys and rng.random() < 0.25:  # extensions and suffixes: several keys end on one walk
+                k = rng.choice(keys)
+                k = k[rng.randint(0, len(k) - 3):] if rng.random() < 0.4 else k + bytes(rng.choice(alpha) for _ in range(rng.randint(1, 3)))
+            else:
+                k = bytes(rng.choice(alpha) for _ in range(rng.randint(lo, hi)))
+            if len(k) >= 3 and k not in seen and len(k) <= 64:
+                seen.add(k)
+                keys.append(k)
     if big:  # a wide alphabet of whole characters and a few hub characters that most keys start with: states with hundreds
         # of transitions (the unit image's big states: direct row, group records, child runs) beside ordinary ones
         cps = rng.sample(range(0x4E00, 0x9FA5), rng.choice([60, 300, 1500])) + list(range(0x61, 0x7B)) + \
@@ -41,7 +58,7 @@ while time.time() < t_end:
                 seen.add(k)
                 keys.append(k)
         alpha = b"".join(rng.sample(units, min(len(units), 40)) + hubs * 6) + b"\xe4\xb8\xf0 "
-    elif rng.random() < 0.3:  # whole UTF-8 characters as the alphabet (eligible for the character-level engine); the
+    elif not kwl and rng.random() < 0.3:  # whole UTF-8 characters as the alphabet (eligible for the character-level engine); the
         # text below is still cut anywhere and mixed with malformed sequences
         units = [c.encode() for c in rng.sample("abcéжя中国人我是々 ", rng.randint(2, 8))]
         while len(keys) < nk and tries < nk * 20:
@@ -67,14 +84,21 @@ while time.time() < t_end:
            "AHA_UNIT_POST": rng.choice([None, None, "regroup"]),
            "AHA_UNIT_HEADER_BESIDE": rng.choice([None, "0", "1"]),
            "AHA_UNIT_BASE_BITS": rng.choice([None, None, "23"]),
-           "AHA_DIRECT": rng.choice([None, None, "0"])}
+           "AHA_DIRECT": rng.choice([None, None, "0"]),
+           "AHA_FILTER_CHUNK": rng.choice([None, "8192", "16384"])}
+    if kwl:
+        env["AHA_ENGINE"] = rng.choice([None, "filter"])
+        env["AHA_DIRECT"] = None
     for k, v in env.items():
         if v is None:
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
     wide = rng.random() < 0.25
+    if os.environ.get("AHA_FUZZ_VERBOSE"):
+        print("seed", seed, "keys", len(keys), "kwl", kwl, "big", big, "env", env, flush=True)
     ac = AC.compile(keys, force_wide=wide)
+    ac.set_profiling(True)
     o = orc.AC.compile(keys)
     grp, n_shards = None, 0
     if not wide and rng.random() < 0.3:  # (the group compiles with the library's own slot format)
@@ -84,11 +108,16 @@ while time.time() < t_end:
             del os.environ["AHA_GROUP_RCCL"]
         grp = ACGroup.compile(keys, [0] * n_shards)
     for _ in range(rng.randint(1, 3)):
-        n = rng.choice([0, 1, 17, 1000, 20000, 300000])
+        n = rng.choice([0, 1, 17, 1000, 20000, 300000] + ([2000000] if kwl else []))
         parts = []
-        while sum(map(len, parts)) < n:
+        p_key = rng.choice([0.02, 0.1]) if kwl else 0.4
+        have = 0
+        while have < n:
             r = rng.random()
-            if r < 0.4 and keys:
+            if kwl and r >= p_key:  # filler: mostly bytes no key starts with, now and then the alphabet's own
+                parts.append(bytes(rng.choice(alpha) for _ in range(rng.randint(1, 9))) if r < p_key + 0.05
+                             else rng.choice([b" ", b"-- ", b"\n", b"0123456789 ", b"\x00"]) * rng.randint(1, 12))
+            elif r < p_key and keys:
                 parts.append(rng.choice(keys))
             elif big and r < 0.7:  # characters (not bytes) of the wide alphabet: hub + any
                 parts.append(rng.choice(hubs) + rng.choice(units))
@@ -96,6 +125,7 @@ while time.time() < t_end:
                 parts.append(b"\x00")
             else:
                 parts.append(bytes(rng.choice(alpha) for _ in range(rng.randint(1, 9))))
+            have += len(parts[-1])
         text = np.frombuffer(b"".join(parts)[:n] if n else b"", dtype=np.uint8)
         cuts = sorted(set([0, text.size] + [rng.randint(0, text.size) for _ in range(rng.choice([0, 1, 5, 60]))]))
         if rng.random() < 0.3:
@@ -112,6 +142,7 @@ while time.time() < t_end:
             sys.exit(1)
         n_cases += 1
         n_hits += len(gh)
+        n_filter += 1 if text.size and ac.last_timing()["engine"] == 5 else 0
         if grp is not None and text.size <= 300000:
             # the group API over shards on this one device: partition, shards in turn through the pipelined host entry, the
             # 4-byte exchange stream (or triples), the rebuild -- the caller's copy and every shard's gathered copy
@@ -149,4 +180,4 @@ while time.time() < t_end:
     seed += 1
     if seed % 5 == 0:
         print(f"[fuzz] {seed - seed0} automata, {n_cases} batches, {n_hits} hits ok", flush=True)
-print(f"fuzz ok: {n_group} group batches, {n_long} match_longest documents, {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")
+print(f"fuzz ok: {n_filter} batches on the prefix-filter engine, {n_group} group batches, {n_long} match_longest documents, {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")

@@ -621,6 +621,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   } else if (filt) {
     // filter (one bit per byte position), then the candidates' goto walks, a wave per chunk
     filter_launch_filter(ac->fdev, M.text, N, sc->v2buf[22].p, ac->pf_cus, s);
+    if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));  // (profiling only: ms_count = the filter, ms_scan = the walks)
     filter_launch_walk(ac->dev, M, sc->v2buf[22].p, sc->v2buf[23].p, ac->pf_cus, s);
   } else {
     v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
@@ -670,7 +671,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     t.chunk_bytes = M.S;
     t.n_kernels = 9;
     (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
-    (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], sc->ev[1]);
+    (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], filt ? sc->ev[2] : sc->ev[1]);
+    if (filt) (void)hipEventElapsedTime(&t.ms_scan, sc->ev[2], sc->ev[1]);
     if (direct) {
       (void)hipEventElapsedTime(&t.ms_aux, sc->ev[1], sc->ev[3]);
     } else {

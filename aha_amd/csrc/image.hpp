@@ -159,7 +159,7 @@ struct FilterDev {
   uint32_t d;     // bytes of a key the filter looks at: min(4, shortest key)
   uint32_t log2;  // the filter has 2^log2 words (10 .. kFilterLog2)
 };
-constexpr uint32_t kFilterImageLds = 96u << 10;  // kf_walk keeps an image up to this size in LDS, beside the waves' candidate lists
+constexpr uint32_t kFilterImageLds = 88u << 10;  // kf_walk keeps an image up to this size in LDS, beside the waves' candidate lists
 bool filter_image_in_lds(uint32_t n_slots);
 int filter_prepare();  // once per process, before the first launch (LDS beyond 64 KiB is opt-in)
 void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, uint32_t cus, void *stream);

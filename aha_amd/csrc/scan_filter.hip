@@ -15,7 +15,7 @@
 //               outlives no later start's END (which lies at least D bytes behind that start).
 // The events leave in the byte-level engine's region format ({END state, end offset in the document} at
 // evd[chunk * ev_stride + seq], ev_cnt, doc_ev_rank), so count / scan / expansion / document offsets are scan_v2.hip's
-// (v2_launch_direct_post).  Candidates are what the text makes of the key set: a chunk with more than about one per ten
+// (v2_launch_direct_post).  Candidates are what the text makes of the key set: a chunk with more than one per sixteen
 // bytes (or a walk through more than kfMaxEnds nested keys) makes kf_walk give the whole call to the other engines
 // (cursor[1] = 3; capi.cpp repeats it there), and capi.cpp builds no filter that would be more than a quarter full.
 // (No counter of the batch's candidates: thousands of atomics on one address cost kf_filter 40..85 us a launch.)
@@ -33,8 +33,11 @@ namespace {
 
 constexpr int kfWarm = 64, kfAhead = 64;
 constexpr int kfMaxWords = 4;      // bitmap words a lane of kf_walk takes: chunks of up to 16 KiB
-constexpr int kfListPer4K = 384;   // candidates a chunk may hold per 4 KiB; a denser batch is not this engine's
+constexpr int kfListPer4K = 256;   // candidates a chunk may hold per 4 KiB (one per 16 bytes); a denser batch is not this engine's
 constexpr int kfMaxEnds = 4;  // END steps a walk keeps; a walk with more hands the call to the other engines
+
+// LDS of a wave of kf_walk: its candidate list, the document boundaries near its chunk, the END steps of a batch's walks
+constexpr int kfWaveLds = kfListPer4K * kfMaxWords * 2 + 64 * 4 + 64 * kfMaxEnds * 8;
 
 __device__ __forceinline__ uint32_t kf_hash(uint32_t w) {
   uint32_t h = w * 0x9E3779B1u;
@@ -79,11 +82,10 @@ __global__ __launch_bounds__(1024) void kf_filter(FilterDev F, const uint8_t *__
   }
 }
 
-// per chunk: the first d with doc_off[d] >= chunk start and the boundaries either side of the chunk start (kf_walk reads one
-// record per chunk, a chunk ahead, instead of searching)
+// per chunk: the first d with doc_off[d] >= chunk start and the boundary before it (kf_walk reads one record per chunk, a
+// chunk ahead, instead of searching)
 struct KfChunk {
   uint64_t dn;
-  int64_t b_next;  // doc_off[dn], >= chunk start
   int64_t b_prev;  // doc_off[dn - 1] < chunk start (the start of the document that holds the byte before the chunk), or 0
 };
 __global__ __launch_bounds__(256) void kf_chunk_doc(V2Args M, KfChunk *rec) {
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void kf_chunk_doc(V2Args M, KfChunk *rec) {
   const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= M.n_chunks) return;
   const uint64_t dn = first_boundary(M.doc_off, M.n_docs, c * (uint64_t)M.S);
-  rec[c] = KfChunk{dn, (int64_t)M.doc_off[dn], dn > 0 ? (int64_t)M.doc_off[dn - 1] : 0};
+  rec[c] = KfChunk{dn, dn > 0 ? (int64_t)M.doc_off[dn - 1] : 0};
 }
 
 typedef uint32_t kf_v4u __attribute__((ext_vector_type(4)));
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
   const uint32_t W = M.S / 4096u;  // bitmap words per lane (1, 2 or 4)
   const uint32_t list_cap = kfListPer4K * W;
   uint16_t *list = reinterpret_cast<uint16_t *>(smem) + (size_t)wave * (kfListPer4K * kfMaxWords);
-  uint32_t *lslots = reinterpret_cast<uint32_t *>(smem + (size_t)WPB * kfListPer4K * kfMaxWords * 2);
+  uint32_t *bnd = reinterpret_cast<uint32_t *>(smem + (size_t)WPB * kfListPer4K * kfMaxWords * 2) + wave * 64;
+  uint2 *ends = reinterpret_cast<uint2 *>(smem + (size_t)WPB * (kfListPer4K * kfMaxWords * 2 + 256)) + wave * (64 * kfMaxEnds);
+  uint32_t *lslots = reinterpret_cast<uint32_t *>(smem + (size_t)WPB * kfWaveLds);
   const uint32_t *gslots = reinterpret_cast<const uint32_t *>(A.slots);
   if (IMG) {
     for (uint32_t i = threadIdx.x; i < A.n_slots; i += 1024) lslots[i] = gslots[i];
@@ -164,20 +168,19 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
     const int64_t a = (int64_t)chunk * M.S;
     const int64_t e = min(a + (int64_t)M.S, N);
     const int64_t g0 = a - kfWarm;  // text position of offset 0
-    // ---- documents: dn = first boundary at or behind the chunk start.  Usually none lies near the chunk: one document.
+    // ---- documents: dn = first boundary at or behind the chunk start.  Lane i looks at boundary dn + i: those below
+    // e + kfAhead are the ones a walk of this chunk can meet (usually none or one); their offsets go to LDS, a candidate
+    // counts the ones at or before it.  64 of them or more (documents of a few bytes): the general way, from memory.
     const uint64_t dn = rec.dn;
-    const int64_t b_next = rec.b_next, b_prev = rec.b_prev;
-    const bool plain = b_next >= e + kfAhead && b_prev <= a - warm;         // no boundary where a walk of this chunk could meet it
-    if (!plain) {  // the documents that start inside the chunk: their events-before counts start at 0
-      for (uint64_t d = dn + (uint64_t)lane; d <= D && (int64_t)M.doc_off[d] < e; d += 64) M.doc_ev_rank[d] = 0;
-    }
+    const int64_t b_prev = rec.b_prev;
+    const int64_t bv = dn + (uint64_t)lane <= D ? (int64_t)M.doc_off[dn + (uint64_t)lane] : INT64_MAX;
     // ---- candidate bits -> the chunk's candidates, in position order, as offsets in LDS
     uint32_t cnt = (uint32_t)__popcll(mw);
 #pragma unroll
     for (int k = 0; k < kfMaxWords; k++) cnt += (uint32_t)__popcll(m[k]);
     const uint32_t incl = wave_incl_scan(cnt);
     const uint32_t total = wave_last(incl);
-    if (total > list_cap) {  // about a candidate per ten bytes: not this engine's text -- the other engines take the call
+    if (total > list_cap) {  // more than a candidate per sixteen bytes: not this engine's text -- the other engines take the call
       if (lane == 0) M.cursor[1] = 3ull;
       break;
     }
@@ -195,6 +198,14 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
           m[k] &= m[k] - 1;
         }
       }
+    }
+    const uint32_t nb = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bv < e + kfAhead));
+    const uint32_t n_in = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bv < e));  // documents that start inside the chunk
+    const bool many = nb >= 64u;
+    if ((uint32_t)lane < nb) bnd[lane] = (uint32_t)(bv - g0);
+    uint32_t before_doc = 0;  // lane i < n_in: events of the chunk that end at or before the first byte of document dn + i
+    if (many) {  // their events-before counts start at 0
+      for (uint64_t d = dn + (uint64_t)lane; d <= D && (int64_t)M.doc_off[d] < e; d += 64) M.doc_ev_rank[d] = 0;
     }
     uint32_t carry = 0;  // furthest offset (exclusive) an earlier start's walk is alive at
     uint32_t seq = 0;    // events of the chunk so far (wave-uniform)
@@ -217,9 +228,13 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
       int32_t ds = 0;  // the document's first byte (negative: it starts before offset 0)
       uint32_t de = 0;
       bool ok = have;
-      if (plain) {
-        ds = (int32_t)(b_prev - g0);
-        de = (uint32_t)(min(b_next, N) - g0);
+      if (!many) {
+        uint32_t idx = 0;
+        for (uint32_t i = 0; i < nb; i++) idx += bnd[i] <= q ? 1u : 0u;
+        // (a warm-up start in front of b_prev lies in a document that ends before the chunk: dead)
+        ok = have && (idx > 0 || g0 + (int64_t)q >= b_prev);
+        ds = idx ? (int32_t)bnd[idx - 1] : (int32_t)(b_prev - g0);
+        de = idx < nb ? bnd[min(idx, 63u)] : (uint32_t)min<int64_t>(N - g0, (int64_t)M.S + kfWarm + kfAhead);
       } else if (have) {
         const int64_t qa = g0 + (int64_t)q;
         uint64_t d = dn > 0 ? dn - 1 : 0;
@@ -232,10 +247,8 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
         }
       }
       // ---- the goto walk from q (byte-level image: slot[base ^ byte] belongs to the state iff its label is the byte)
-      uint32_t reach = 0;  // offset (exclusive) of the last byte the walk is alive at; 0: not even one byte
-      uint32_t ej[kfMaxEnds], eb[kfMaxEnds];
-#pragma unroll
-      for (int k = 0; k < kfMaxEnds; k++) ej[k] = eb[k] = 0;
+      // Branch-free steps: a lane that is out keeps probing its last state and ignores what comes back.  The END steps of a
+      // walk (few) leave {state, offset} in LDS, entry k of lane l at ends[k * 64 + l]; they come back after the walk.
       uint32_t ne = 0;
       bool over = false;
       uint32_t B = A.root, p = q;
@@ -247,33 +260,28 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
         bool run = true;  // (wave-uniform; looked at again every four steps)
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-          const bool go = alive & p < de;
-          if ((i & 3) == 0 && i) run = run && __builtin_amdgcn_ballot_w64(go) != 0ull;
+          if ((i & 3) == 0 && i) run = run && __builtin_amdgcn_ballot_w64(alive & p < de) != 0ull;
           if (!run) continue;
           const uint32_t byte = (t[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-          const uint32_t at = go ? (B ^ byte) : 0u;
-          const uint32_t en = IMG ? lslots[at] : gslots[at];
-          const bool hit = go & byte != 0u & (en & 0xFFu) == byte;  // (label 0 is a fail header's: NUL follows no goto)
+          const uint32_t en = IMG ? lslots[B ^ byte] : gslots[B ^ byte];
+          // (label 0 is a fail header's: NUL follows no goto)
+          const bool hit = alive & p < de & byte != 0u & (en & 0xFFu) == byte;
           alive = hit;
-          if (hit) {
-            B = (en >> C_BASE_SHIFT) & C_BASE_MASK;
-            p++;
-            reach = p;
-            if (en & C_END) {
-              if (ne < (uint32_t)kfMaxEnds) {
-#pragma unroll
-                for (int k = 0; k < kfMaxEnds; k++)
-                  if ((uint32_t)k == ne) {
-                    ej[k] = p;
-                    eb[k] = B;
-                  }
-                ne++;
-              } else {
-                over = true;
-              }
-            }
-          }
+          B = hit ? (en >> C_BASE_SHIFT) & C_BASE_MASK : B;
+          p += hit ? 1u : 0u;
+          const bool end = hit & (en & C_END) != 0u;
+          if (end & ne < (uint32_t)kfMaxEnds) ends[ne * 64u + (uint32_t)lane] = make_uint2(B, p);
+          over |= end & ne >= (uint32_t)kfMaxEnds;
+          ne += end ? 1u : 0u;
         }
+      }
+      const uint32_t reach = p > q ? p : 0u;  // offset (exclusive) of the last byte the walk is alive at; 0: not even one byte
+      uint32_t ej[kfMaxEnds], eb[kfMaxEnds];
+#pragma unroll
+      for (int k = 0; k < kfMaxEnds; k++) {
+        const uint2 r = ends[(uint32_t)k * 64u + (uint32_t)lane];
+        eb[k] = r.x;
+        ej[k] = r.y;
       }
       if (__builtin_amdgcn_ballot_w64(over)) {  // more END steps on one walk than a lane keeps: the other engines take the call
         if (lane == 0) M.cursor[1] = 3ull;
@@ -303,19 +311,28 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
           if (at < M.ev_stride) reg[at] = make_uint2(eb[k], (uint32_t)((int32_t)ej[k] - ds));  // {END state, end offset in the document}
           at++;
         }
-      if (!plain) {  // documents that start inside the chunk: the events that end at or before their first byte
+      // documents that start inside the chunk: the events that end at or before their first byte
+      if (!many) {
+        for (uint32_t i = 0; i < n_in; i++) {
+          const uint32_t bo = bnd[i];
+          uint32_t c = 0;
+#pragma unroll
+          for (int k = 0; k < kfMaxEnds; k++) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(val[k] && ej[k] <= bo));
+          before_doc += (uint32_t)lane == i ? c : 0u;
+        }
+      } else {
         for (uint64_t d = dn; d <= D && (int64_t)M.doc_off[d] < e; d++) {
           const uint32_t bo = (uint32_t)((int64_t)M.doc_off[d] - g0);
           uint32_t c = 0;
 #pragma unroll
-          for (int k = 0; k < kfMaxEnds; k++) c += (val[k] && ej[k] <= bo) ? 1u : 0u;
-          for (int s = 32; s >= 1; s >>= 1) c += __shfl_xor(c, s, 64);
+          for (int k = 0; k < kfMaxEnds; k++) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(val[k] && ej[k] <= bo));
           if ((uint64_t)lane == ((d - dn) & 63) && c) M.doc_ev_rank[d] += c;  // (the lane that zeroed it)
         }
       }
       seq += vtot;
     }
     if (give_up) break;
+    if (!many && (uint32_t)lane < n_in) M.doc_ev_rank[dn + (uint64_t)lane] = before_doc;
     if (lane == 0) {
       M.ev_cnt[chunk] = seq;
       if (seq > M.ev_stride) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
@@ -330,7 +347,7 @@ size_t filter_chunk_rec_bytes() { return sizeof(KfChunk); }
 bool filter_image_in_lds(uint32_t n_slots) { return (size_t)n_slots * 4 <= kFilterImageLds; }
 
 static size_t walk_lds(bool img, uint32_t n_slots) {
-  return (size_t)(img ? 16 : 4) * kfListPer4K * kfMaxWords * 2 + (img ? (size_t)n_slots * 4 : 0);
+  return (size_t)(img ? 16 : 4) * kfWaveLds + (img ? (size_t)n_slots * 4 : 0);
 }
 
 void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, uint32_t cus, void *stream) {
@@ -356,8 +373,10 @@ void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, vo
 
 int filter_prepare() {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&kf_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)walk_lds(true, kFilterImageLds / 4)) != hipSuccess)
+                          (int)walk_lds(true, kFilterImageLds / 4)) != hipSuccess) {
+    (void)hipGetLastError();  // (not left for the next call's check to find)
     return -1;
+  }
   return 0;
 }
 

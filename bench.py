@@ -447,6 +447,11 @@ def main():
         dom, dom_ms = "ku_traverse", avg["ms_count"]
         A = info["unit_slots"] * 8 + info["unit_syms"] * 4 + 11264
         alg_bytes = n_bytes + 8 * (D + 1) + A
+    elif engine == 5:
+        # prefix-filter engine: kf_filter reads every byte of the corpus once (+ its Bloom filter) and is the longest kernel of
+        # the step; the bitmap it writes (1 bit per byte) is scratch like the other engines' event records.  ms_scan = the walks.
+        dom, dom_ms = "kf_filter", avg["ms_count"]
+        alg_bytes = n_bytes + 4 * info["filter_words"]
     elif engine == 2:
         # k2_traverse: corpus + doc offsets + automaton image in; its event records are scratch
         dom, dom_ms = "k2_traverse", avg["ms_count"]

@@ -144,7 +144,7 @@ typedef struct {
    * character-level image whose keys are 3 .. 64 bytes long (a keyword list): a blocked Bloom filter over the keys' first
    * filter_prefix_bytes bytes (min(4, shortest key); 0 = this handle has none) of filter_words 32-bit words.  Matches with
    * byte offsets and no separator filter then look at every text position through the filter and walk the automaton only
-   * from the positions it lets through; a batch whose text is dense with such positions (more than about one in ten)
+   * from the positions it lets through; a batch whose text is dense with such positions (more than one in sixteen)
    * is handed to the single-traversal engine by the call itself (aha_timing.repeats counts it). */
   uint32_t filter_prefix_bytes;
   uint32_t filter_words;
@@ -156,8 +156,9 @@ typedef struct {
   uint32_t struct_size;
   uint32_t n_kernels;
   float ms_total;           /* first launch -> hits and offsets final in HBM */
-  float ms_count;           /* engine 2: the traversal kernel; engine 1: traversal pass 1 */
-  float ms_scan;            /* scans of per-chunk counts (slab pipeline; the region pipelines have them in ms_aux: no event in between) */
+  float ms_count;           /* engines 4, 2: the traversal kernel; engine 5: the filter kernel; engine 1: traversal pass 1 */
+  float ms_scan;            /* scans of per-chunk counts (slab pipeline; the region pipelines have them in ms_aux: no event in
+                             * between); engine 5: the candidates' walks (chunk records + kf_walk) */
   float ms_write;           /* engine 2: chain expansion + doc offsets; engine 1: traversal pass 2 */
   float ms_aux;             /* engine 2: hits per chunk + scan (regions) or event sort (slabs); engine 1: char-offset prefix pass */
   uint64_t n_chunks;

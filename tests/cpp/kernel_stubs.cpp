@@ -27,7 +27,7 @@ void launch_has_nul(const uint8_t *, uint64_t, uint64_t *, void *) { no_gpu("lau
 bool filter_image_in_lds(uint32_t) { return false; }
 int filter_prepare() { return 0; }
 void filter_launch_filter(const FilterDev &, const uint8_t *, uint64_t, void *, uint32_t, void *) { no_gpu("filter_launch_filter"); }
-size_t filter_chunk_rec_bytes() { return 24; }
+size_t filter_chunk_rec_bytes() { return 16; }
 void filter_launch_walk(const DevAut &, const V2Args &, const void *, void *, uint32_t, void *) { no_gpu("filter_launch_walk"); }
 void unit_launch_regroup(const DevAut &, const V2Args &, void *) { no_gpu("unit_launch_regroup"); }
 void unit_launch_expand(const uint2 *, const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("unit_launch_expand"); }

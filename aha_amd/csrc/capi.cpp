@@ -848,20 +848,20 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
       for (uint32_t k = 0; k < ac->aut.n_keys; k++) minlen = std::min(minlen, ac->aut.key_len[k]);
       if (minlen >= 3) {
         const uint32_t D = std::min(4u, minlen);
-        // the smallest filter (2^10 .. 2^kFilterLog2 words) that stays under 1/64 full (false candidates: about the square of that) -- every block of kf_filter stages it
-        // into LDS, 64 KiB of that is felt on a batch of 64 MiB -- or the largest while it is no more than a quarter full
+        // the smallest filter (2^10 .. 2^kFilterLog2 words) that stays under 1/256 full (false candidates: about the square of
+        // the fill; the filter's size does not show in kf_filter's time, its false candidates show in kf_walk's), or the largest
+        // while it is no more than a quarter full
         for (uint32_t lg = 10; lg <= kFilterLog2; lg++) {
           ac->pf_bloom.assign((size_t)1 << lg, 0u);
           for (uint32_t k = 0; k < ac->aut.n_keys; k++) {
             uint32_t w = 0;
             for (uint32_t j = 0; j < D; j++) w |= (uint32_t)ac->aut.blob[ac->aut.offs[k] + j] << (8 * j);
-            uint32_t h = w * 0x9E3779B1u;  // (kf_hash)
-            h ^= h >> 15;
-            ac->pf_bloom[h >> (32 - lg)] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+            const uint32_t h = w * kFilterMul;  // (kf_filter: the word from the product's top lg bits, two bits from the ten below)
+            ac->pf_bloom[h >> (32 - lg)] |= (1u << ((h >> (32 - lg - 5)) & 31u)) | (1u << ((h >> (32 - lg - 10)) & 31u));
           }
           uint64_t bits = 0;
           for (uint32_t x : ac->pf_bloom) bits += (uint64_t)__builtin_popcount(x);
-          if (bits * (lg < kFilterLog2 ? 64 : 4) <= ((uint64_t)32 << lg)) {
+          if (bits * (lg < kFilterLog2 ? 256 : 4) <= ((uint64_t)32 << lg)) {
             ac->pf_d = D;
             ac->pf_log2 = lg;
             break;

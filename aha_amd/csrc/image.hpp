@@ -153,6 +153,7 @@ void v2_launch_hit_scan(const V2Args &M, void *stream);   // chunk_hits -> hit_b
 void v2_launch_lead_scan(const V2Args &M, void *stream);  // lead_cnt -> lead_base, totals[1] (char offsets)
 
 // ---- prefix-filter engine (scan_filter.hip): byte-level, for batches where few positions can start a key
+constexpr uint32_t kFilterMul = 0x9E3779B1u;  // an entry of the filter: scan_filter.hip kf_filter, capi.cpp filter_entry
 constexpr uint32_t kFilterLog2 = 14;  // 2^14 words = 64 KiB: blocked Bloom filter over the keys' first D bytes
 struct FilterDev {
   const uint32_t *bloom;

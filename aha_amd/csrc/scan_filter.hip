@@ -39,12 +39,11 @@ constexpr int kfMaxEnds = 4;  // END steps a walk keeps; a walk with more hands 
 // LDS of a wave of kf_walk: its candidate list, the document boundaries near its chunk, the END steps of a batch's walks
 constexpr int kfWaveLds = kfListPer4K * kfMaxWords * 2 + 64 * 4 + 64 * kfMaxEnds * 8;
 
-__device__ __forceinline__ uint32_t kf_hash(uint32_t w) {
-  uint32_t h = w * 0x9E3779B1u;
-  return h ^ (h >> 15);
-}
-
-// ---- the filter: bit p of the bitmap <=> text[p .. p + D) may start a key
+// ---- the filter: bit p of the bitmap <=> text[p .. p + D) may start a key.  An entry of the filter: the product
+// w * 0x9E3779B1 of the D bytes (little endian, D < 4: the upper bytes masked off) selects a word with its top log2 bits and
+// two bits of that word with the ten bits below (capi.cpp sets them: filter_entry) -- no fold of the product: its upper half is
+// where a multiplicative hash has mixed all of w's bytes, and the word index carries the discrimination.
+template <bool D4>
 __global__ __launch_bounds__(1024) void kf_filter(FilterDev F, const uint8_t *__restrict__ text, uint64_t n_bytes,
                                                    uint16_t *__restrict__ bitmap) {
   __shared__ uint32_t bl[1 << kFilterLog2];
@@ -73,10 +72,11 @@ __global__ __launch_bounds__(1024) void kf_filter(FilterDev F, const uint8_t *__
     uint32_t bits = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const uint32_t w = ((k & 3) ? __builtin_amdgcn_alignbyte(d[(k >> 2) + 1], d[k >> 2], (uint32_t)(k & 3)) : d[k >> 2]) & dmask;
-      const uint32_t h = kf_hash(w);
+      uint32_t w = (k & 3) ? __builtin_amdgcn_alignbyte(d[(k >> 2) + 1], d[k >> 2], (uint32_t)(k & 3)) : d[k >> 2];
+      if (!D4) w &= dmask;
+      const uint32_t h = w * kFilterMul;
       const uint32_t word = bl[h >> hs];
-      bits |= ((word >> (h & 31u)) & (word >> ((h >> 5) & 31u)) & 1u) << k;  // both bits of the entry (capi.cpp sets them)
+      bits |= ((word >> (h >> (hs - 5u))) & (word >> (h >> (hs - 10u))) & 1u) << k;  // (a shift takes its count's low 5 bits)
     }
     bitmap[p] = (uint16_t)bits;
   }
@@ -353,7 +353,10 @@ static size_t walk_lds(bool img, uint32_t n_slots) {
 void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, uint32_t cus, void *stream) {
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_bytes + 16383) / 16384, (uint64_t)cus * 2));
   // two blocks per CU (2 x 64 KiB of LDS): the loop is VALU work, eight waves per SIMD hide its loads
-  hipLaunchKernelGGL(kf_filter, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap);
+  if (F.d >= 4)
+    hipLaunchKernelGGL(kf_filter<true>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap);
+  else
+    hipLaunchKernelGGL(kf_filter<false>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap);
 }
 
 // M.S: the chunk, 4096 << {0, 1, 2}; cus: the device's compute units (a block per CU when the image sits in LDS)

@@ -526,11 +526,12 @@ def test_engine_selected(engine, monkeypatch):
         assert len(got) == 302 and [tuple(h) for h in got[:3].tolist()] == [(0, 3, 0), (1, 4, 1), (65, 68, 1)]
         # ... and a text that is nothing but key starts goes back to the byte-level engine (same hits, kf_walk gives up)
         got = asc.match_array(b"abcd" * 3000)
-        assert asc.last_timing()["engine"] == 2 and asc.last_timing()["repeats"] == 1 and len(got) == 6000
+        assert asc.last_timing()["engine"] == 2 and len(got) == 6000
         assert asc.info["filter_prefix_bytes"] == 3 and asc.info["filter_words"] == 1024
-        # a handle whose batch came back stays away from the filter for two calls, then tries it again
+        # a handle whose batch came back stays away from the filter for a few calls (2, 4, .. 64), then tries it again
         sparse_text = b"-" * 5000 + b"abcd"
-        assert [asc.match_array(sparse_text).shape[0] and asc.last_timing()["engine"] for _ in range(3)] == [2, 2, 5]
+        engines = [asc.match_array(sparse_text).shape[0] and asc.last_timing()["engine"] for _ in range(6)]
+        assert engines[0] == 2 and engines[-1] == 5 and sorted(engines) == engines
     # char offsets run on the character-level engine too, the separator filter on the byte-level engines only
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
     assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u23", "uh", "auto") else (2, 5) if engine == "f" else (2,))

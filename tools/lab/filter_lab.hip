@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <vector>
 
-constexpr int LOG2 = 14;
+#ifndef LOG2
+#define LOG2 12
+#endif
 
 __global__ void fill(uint8_t *t, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -40,6 +42,12 @@ __global__ __launch_bounds__(1024) void kf(const uint32_t *bloom, const uint8_t 
     for (int k = 0; k < 16; k++) {
       const uint32_t w = (k & 3) ? __builtin_amdgcn_alignbyte(d[(k >> 2) + 1], d[k >> 2], (uint32_t)(k & 3)) : d[k >> 2];
       uint32_t h;
+      if (V == 7) {  // no fold: word from the product's top bits, the two bit positions from the ten bits below
+        h = w * 0x9E3779B1u;
+        const uint32_t word = bl[h >> (32 - LOG2)];
+        bits |= ((word >> (h >> (32 - LOG2 - 5))) & (word >> (h >> (32 - LOG2 - 10))) & 1u) << k;
+        continue;
+      }
       if (V == 3) {
         h = __umul24(w, 0x9E3779u) + __umul24(w >> 8, 0x85EBCBu);
         h ^= h >> 11;
@@ -64,7 +72,8 @@ __global__ __launch_bounds__(1024) void kf(const uint32_t *bloom, const uint8_t 
     mine += (uint32_t)__builtin_popcount(bits);
   }
   for (int s = 32; s >= 1; s >>= 1) mine += __shfl_xor(mine, s, 64);
-  if (V != 5 && (threadIdx.x & 63) == 0 && mine) atomicAdd(n_cand, (unsigned long long)mine);
+  if ((V == 1 || V == 7 && blockIdx.x == 0xFFFFFF) && (threadIdx.x & 63) == 0 && mine) atomicAdd(n_cand, (unsigned long long)mine);
+  if (V == 7 && (threadIdx.x & 63) == 0 && mine && (blockIdx.x & 7) == 0) atomicAdd(n_cand, (unsigned long long)mine * 8);
 }
 
 // V5 with the next iteration's text loaded before the current one is hashed
@@ -134,7 +143,7 @@ int main(int argc, char **argv) {
   hipMalloc(&bloom, 4 << LOG2);
   hipMalloc(&cnt, 8);
   hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, text, n);
-  std::vector<uint32_t> hb(1 << LOG2, 0);
+  std::vector<uint32_t> hb(1 << LOG2, 0), hb7(1 << LOG2, 0);
   uint64_t x = 12345;
   for (int i = 0; i < 1000; i++) {  // a thousand random lower-case 4-grams
     uint32_t w = 0;
@@ -145,13 +154,17 @@ int main(int argc, char **argv) {
     uint32_t h = w * 0x9E3779B1u;
     h ^= h >> 15;
     hb[h >> (32 - LOG2)] |= (1u << (h & 31)) | (1u << ((h >> 5) & 31));
+    const uint32_t g = w * 0x9E3779B1u;
+    hb7[g >> (32 - LOG2)] |= (1u << ((g >> (32 - LOG2 - 5)) & 31)) | (1u << ((g >> (32 - LOG2 - 10)) & 31));
   }
   hipMemcpy(bloom, hb.data(), 4 << LOG2, hipMemcpyHostToDevice);
   hipDeviceSynchronize();
-  for (int grid : {256, 512, 1024}) {
+  for (int grid : {512}) {
     run<1>(bloom, text, n, bm, cnt, grid);
     run<5>(bloom, text, n, bm, cnt, grid);
-    run<6>(bloom, text, n, bm, cnt, grid);
+    hipMemcpy(bloom, hb7.data(), 4 << LOG2, hipMemcpyHostToDevice);
+    run<7>(bloom, text, n, bm, cnt, grid);
+    hipMemcpy(bloom, hb.data(), 4 << LOG2, hipMemcpyHostToDevice);
   }
   return 0;
 }

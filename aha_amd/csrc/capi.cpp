@@ -43,6 +43,7 @@ struct Scratch {
   Buf hostbuf[4];  // device staging of the host-buffer entry points (corpus, doc offsets, doc hit offsets, hits)
   hipStream_t hs[3] = {};  // host-buffer entry: private non-blocking streams for upload, match, download
   unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
+  unsigned long long *h_v2_dev = nullptr;  // the same words as the device addresses them
 };
 constexpr size_t kMaxScratch = 8;
 // last error text of the calling thread (aha_last_error): calls on one handle may run concurrently
@@ -79,7 +80,7 @@ struct aha_ac {
   uint32_t pf_d = 0;
   uint32_t pf_cus = 0;
   uint32_t pf_log2 = 0;
-  std::atomic<uint32_t> pf_skip{0}, pf_streak{0};  // calls to go without the filter; give-ups in a row
+  std::atomic<uint32_t> pf_skip[2] = {}, pf_streak[2] = {};  // calls to go without the filter; give-ups in a row ([1]: char offsets)
   bool pf_ok = false;
   FilterDev fdev{};
   uint32_t s1_lo = 0, s2_lo = 0, s2_hi = 0;   // states with base in [s2_lo, s2_hi): depth >= 3 and a fail target of depth <= 2
@@ -172,6 +173,7 @@ void free_scratch(Scratch *sc, bool all) {
   sc->d_totals = nullptr;
   sc->h_totals = nullptr;
   sc->h_v2 = nullptr;
+  sc->h_v2_dev = nullptr;
   if (sc->ev_ready)
     for (auto &e : sc->ev) (void)hipEventDestroy(e);
   sc->ev_ready = false;
@@ -498,6 +500,17 @@ static StreamFmt stream_fmt(const aha_ac *ac) {
 constexpr uint64_t kV2MaxRegionBytes = 48ull << 30;
 
 // returns AHA_OK, an error, +1 when the caller must fall back to the two-pass engine, +2 when a region overflowed
+// the pinned words a call's verdict and totals come back in, and their device address
+int32_t ensure_h_v2(aha_ac *ac, Scratch *sc) {
+  if (sc->h_v2) return AHA_OK;
+  HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+  if (hipHostGetDevicePointer((void **)&sc->h_v2_dev, sc->h_v2, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    sc->h_v2_dev = nullptr;  // (then the words come back by a copy)
+  }
+  return AHA_OK;
+}
+
 int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t *n_hits, V2Mode mode) {
   const uint64_t N = M1.n_bytes;
   const uint32_t Lmax = ac->aut.max_key_len;
@@ -509,8 +522,9 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   S = std::min<uint64_t>(std::max<uint64_t>(S, s_min), kV2MaxS);
   // the prefix-filter engine: byte offsets, no separator filter, the event regions; a wave takes a chunk of 4, 8 or 16 KiB
   // (the larger, the fuller its batches of 64 candidates; at least 16 chunks per wave of the device all the same)
-  const bool filt = ac->pf_ok && !ac->unit_ok && !M1.chars && !M1.sep && !M1.no_filter && mode != kSlabs &&
-                    !(de && strcmp(de, "0") == 0);
+  // (a call with char offsets enters as a call with byte offsets: the same hits while the batch is plain ASCII, which
+  // kf_filter finds out on its way; a batch that is not comes back with rc 3 like a dense one)
+  const bool filt = ac->pf_ok && !ac->unit_ok && !M1.sep && !M1.no_filter && mode != kSlabs && !(de && strcmp(de, "0") == 0);
   if (filt) {
     S = 4096;
     while (S < 16384 && N / (2 * S) >= (uint64_t)ac->pf_cus * 16 * 4) S *= 2;
@@ -528,7 +542,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.n_chunks = (N + S - 1) / S;
   if (M.n_chunks > 0xFFFFFFFFull) return 1;
   M.lds_slots = ac->v2_lds_slots;
-  M.chars = M1.chars;
+  M.chars = filt ? 0 : M1.chars;
   M.sep = M1.sep;
   memcpy(M.sep_block, M1.sep_block, sizeof(M.sep_block));
   M.out = M1.out;
@@ -604,7 +618,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.doc_hit_rank = (uint32_t *)sc->v2buf[20].p;
   M.chunk_hits = (uint32_t *)sc->v2buf[18].p;
   M.hit_base = (uint64_t *)sc->v2buf[19].p;
-  if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+  if ((rc = ensure_h_v2(ac, sc))) return rc;
 
   const bool prof = ac->profiling.load() && sc->ev_ready;
   HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
@@ -620,9 +634,10 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   } else if (filt) {
     // filter (one bit per byte position), then the candidates' goto walks, a wave per chunk
-    filter_launch_filter(ac->fdev, M.text, N, sc->v2buf[22].p, ac->pf_cus, s);
+    unsigned long long *non_ascii = M1.chars ? M.cursor + 6 : nullptr;
+    filter_launch_filter(ac->fdev, M.text, N, sc->v2buf[22].p, non_ascii, ac->pf_cus, s);
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));  // (profiling only: ms_count = the filter, ms_scan = the walks)
-    filter_launch_walk(ac->dev, M, sc->v2buf[22].p, sc->v2buf[23].p, ac->pf_cus, s);
+    filter_launch_walk(ac->dev, M, sc->v2buf[22].p, sc->v2buf[23].p, non_ascii, ac->pf_cus, s);
   } else {
     v2_launch_traverse(ac->dev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
   }
@@ -648,7 +663,10 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   }
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[4], s));
   HIPCHK(ac, hipGetLastError());
-  HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
+  if (sc->h_v2_dev)
+    launch_publish_words((const unsigned long long *)sc->v2buf[9].p, sc->h_v2_dev, 5, s);
+  else
+    HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(ac, hipStreamSynchronize(s));
   if (sc->h_v2[1] >= 16) {  // the offsets are not what the call says (k_check_docs): nothing was indexed with them
     if (sc->h_v2[1] & 1) {
@@ -1340,7 +1358,7 @@ static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpu
     // the offsets live in HBM: one small kernel and an 4-byte read-back before anything indexes with them
     int32_t rc2;
     if ((rc2 = v2_reserve(ac, sc, 9, 16 * 8))) return rc2;
-    if (!sc->h_v2) HIPCHK(ac, hipHostMalloc((void **)&sc->h_v2, 5 * sizeof(unsigned long long), hipHostMallocDefault));
+    if ((rc2 = ensure_h_v2(ac, sc))) return rc2;
     uint32_t *flag = (uint32_t *)sc->v2buf[9].p + 30;
     HIPCHK(ac, hipMemsetAsync(flag, 0, 4, s));
     launch_check_docs(d_doc_offsets, n_docs, n_bytes, flag, nullptr, s);
@@ -1445,8 +1463,10 @@ static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpu
   if (ac->v2_ok) {
     // a handle whose batches keep coming back from the prefix-filter engine (text dense with key starts) skips it for 2, 4,
     // .. 64 calls before it tries again: a batch that is handed back has paid for the filter and part of the walks
-    if (ac->pf_ok && ac->pf_skip.load(std::memory_order_relaxed) > 0) {
-      ac->pf_skip.fetch_sub(1, std::memory_order_relaxed);
+    const int pm = M.chars ? 1 : 0;  // (calls with char offsets come back for another reason -- text that is not ASCII -- and keep
+                                     // their own count)
+    if (ac->pf_ok && ac->pf_skip[pm].load(std::memory_order_relaxed) > 0) {
+      ac->pf_skip[pm].fetch_sub(1, std::memory_order_relaxed);
       M.no_filter = 1;
     }
     const bool tried = ac->pf_ok && !M.no_filter;
@@ -1454,11 +1474,11 @@ static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpu
     if (rc == 3) {  // the prefix-filter engine handed the batch back: once more on the byte-level engine
       repeats++;
       M.no_filter = 1;
-      const uint32_t streak = std::min(ac->pf_streak.fetch_add(1, std::memory_order_relaxed) + 1, 6u);
-      ac->pf_skip.store(1u << streak, std::memory_order_relaxed);
+      const uint32_t streak = std::min(ac->pf_streak[pm].fetch_add(1, std::memory_order_relaxed) + 1, 6u);
+      ac->pf_skip[pm].store(1u << streak, std::memory_order_relaxed);
       rc = match_v2(ac, sc, M, s, n_hits, kRegions);
     } else if (tried && rc == AHA_OK) {
-      ac->pf_streak.store(0, std::memory_order_relaxed);
+      ac->pf_streak[pm].store(0, std::memory_order_relaxed);
     }
     if (rc == 2) {  // denser than cap said: regions of one event per byte
       repeats++;

@@ -163,10 +163,13 @@ struct FilterDev {
 constexpr uint32_t kFilterImageLds = 88u << 10;  // kf_walk keeps an image up to this size in LDS, beside the waves' candidate lists
 bool filter_image_in_lds(uint32_t n_slots);
 int filter_prepare();  // once per process, before the first launch (LDS beyond 64 KiB is opt-in)
-void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, uint32_t cus, void *stream);
+// non_ascii (nullable): set to 1 by kf_filter when the batch holds a byte >= 0x80; kf_walk then hands the call back (cursor[1] = 3)
+void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, unsigned long long *non_ascii,
+                          uint32_t cus, void *stream);
 // bitmap (one bit per byte position) -> evd / ev_cnt / doc_ev_rank of chunks of M.S bytes (4, 8 or 16 KiB); chunk_rec: n_chunks * filter_chunk_rec_bytes() of scratch
 size_t filter_chunk_rec_bytes();
-void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, void *chunk_rec, uint32_t cus, void *stream);
+void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, void *chunk_rec, const unsigned long long *non_ascii,
+                        uint32_t cus, void *stream);
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);
 int v2_prepare(bool compact, size_t lds_bytes);  // raises the dynamic-LDS limit; hipError_t as int
@@ -197,6 +200,7 @@ void launch_hits_unpack4_segs(const DevAut &A, const uint32_t *land, const uint6
                               const uint64_t *out_off, uint32_t n_segs, int chars, int32_t *hits, StreamFmt F, void *stream);
 
 // flag[0] |= 1: not the offsets of n_docs documents over n_bytes; |= 2: a document of 2^31 bytes or more
+void launch_publish_words(const unsigned long long *src, unsigned long long *host_dst, int n, void *stream);
 void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_bytes, uint32_t *flag, unsigned long long *abort_word,
                        void *stream);
 

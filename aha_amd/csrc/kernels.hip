@@ -807,6 +807,16 @@ void launch_check_docs(const uint64_t *doc_off, uint64_t n_docs, uint64_t n_byte
   hipLaunchKernelGGL(k_check_docs, dim3(g), dim3(256), 0, (hipStream_t)stream, doc_off, n_docs, n_bytes, flag, abort_word);
 }
 
+// The verdict and the totals of a call (five words) into the caller's pinned host words, by a store from the device: the
+// 40-byte hipMemcpyAsync it replaces is a blit kernel of 5 (64 MiB batch) to 17 us (1 GiB) on this stack.
+__global__ void k_publish_words(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ host_dst, int n) {
+  if ((int)threadIdx.x < n) host_dst[threadIdx.x] = src[threadIdx.x];
+  __threadfence_system();
+}
+void launch_publish_words(const unsigned long long *src, unsigned long long *host_dst, int n, void *stream) {
+  hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, (hipStream_t)stream, src, host_dst, n);
+}
+
 // ---------------------------------------------------------------- launchers
 static inline uint32_t blocks_for(uint64_t n_chunks) {
   return (uint32_t)((n_chunks + kBlock - 1) / kBlock);

@@ -15,7 +15,7 @@
 //               outlives no later start's END (which lies at least D bytes behind that start).
 // The events leave in the byte-level engine's region format ({END state, end offset in the document} at
 // evd[chunk * ev_stride + seq], ev_cnt, doc_ev_rank), so count / scan / expansion / document offsets are scan_v2.hip's
-// (v2_launch_direct_post).  Candidates are what the text makes of the key set: a chunk with more than one per sixteen
+// (v2_launch_direct_post).  Candidates are what the text makes of the key set: a chunk with more than one per ~20
 // bytes (or a walk through more than kfMaxEnds nested keys) makes kf_walk give the whole call to the other engines
 // (cursor[1] = 3; capi.cpp repeats it there), and capi.cpp builds no filter that would be more than a quarter full.
 // (No counter of the batch's candidates: thousands of atomics on one address cost kf_filter 40..85 us a launch.)
@@ -33,7 +33,10 @@ namespace {
 
 constexpr int kfWarm = 64, kfAhead = 64;
 constexpr int kfMaxWords = 4;      // bitmap words a lane of kf_walk takes: chunks of up to 16 KiB
-constexpr int kfListPer4K = 256;   // candidates a chunk may hold per 4 KiB (one per 16 bytes); a denser batch is not this engine's
+constexpr int kfListPer4K = 256;   // candidates a chunk's list holds per 4 KiB
+constexpr int kfDensePer4K = 208;  // more than this (one per ~20 bytes) and the batch is not this engine's: the byte-level engine
+                                   // costs what filter + walks cost at about 5.5 % (tools/lab/f4.sh: 30 000 keys over letters, 6.5 %,
+                                   // tie; 10 000 keys, 2.2 %, 1.7 x faster here)
 constexpr int kfMaxEnds = 4;  // END steps a walk keeps; a walk with more hands the call to the other engines
 
 // LDS of a wave of kf_walk: its candidate list, the document boundaries near its chunk, the END steps of a batch's walks
@@ -45,13 +48,14 @@ constexpr int kfWaveLds = kfListPer4K * kfMaxWords * 2 + 64 * 4 + 64 * kfMaxEnds
 // where a multiplicative hash has mixed all of w's bytes, and the word index carries the discrimination.
 template <bool D4>
 __global__ __launch_bounds__(1024) void kf_filter(FilterDev F, const uint8_t *__restrict__ text, uint64_t n_bytes,
-                                                   uint16_t *__restrict__ bitmap) {
+                                                   uint16_t *__restrict__ bitmap, unsigned long long *non_ascii) {
   __shared__ uint32_t bl[1 << kFilterLog2];
   for (uint32_t i = threadIdx.x; i < (1u << F.log2); i += 1024) bl[i] = F.bloom[i];
   const uint32_t hs = 32u - F.log2;
   __syncthreads();
   const uint32_t dmask = F.d >= 4 ? 0xFFFFFFFFu : ((1u << (8 * F.d)) - 1u);
   const uint64_t n_pieces = ((n_bytes + 63) / 64) * 4;  // whole 64-bit words of the bitmap (pieces beyond the text: no bit)
+  uint32_t seen = 0;  // OR of the bytes this lane looked at (a call with char offsets: is the batch plain ASCII?)
   for (uint64_t p = (uint64_t)blockIdx.x * 1024 + threadIdx.x; p < n_pieces; p += (uint64_t)gridDim.x * 1024) {
     const uint64_t g = p * 16;
     uint32_t d[5] = {0, 0, 0, 0, 0};  // 16 bytes + 3 of look-ahead (bytes beyond the text read as 0: no key holds a NUL)
@@ -79,7 +83,10 @@ __global__ __launch_bounds__(1024) void kf_filter(FilterDev F, const uint8_t *__
       bits |= ((word >> (h >> (hs - 5u))) & (word >> (h >> (hs - 10u))) & 1u) << k;  // (a shift takes its count's low 5 bits)
     }
     bitmap[p] = (uint16_t)bits;
+    seen |= d[0] | d[1] | d[2] | d[3];
   }
+  // (a plain store, not an atomic: every wave that has something to say says the same)
+  if (non_ascii && (seen & 0x80808080u)) *non_ascii = 1ull;
 }
 
 // per chunk: the first d with doc_off[d] >= chunk start and the boundary before it (kf_walk reads one record per chunk, a
@@ -124,12 +131,19 @@ __device__ __forceinline__ kf_v4u kf_text16(const uint8_t *__restrict__ text, in
 // (a keyword list's automaton is a few tens of KiB), the block's 16 waves share it; otherwise the slots come through L1/L2.
 template <bool IMG>
 __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, const unsigned long long *__restrict__ bitmap,
-                                                             const KfChunk *__restrict__ chunk_rec) {
+                                                             const KfChunk *__restrict__ chunk_rec,
+                                                             const unsigned long long *non_ascii) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // a call with char offsets came here as a call with byte offsets: the same thing while the batch is plain ASCII (kf_filter
+  // has looked at every byte); if it is not, the call goes to the engines that count characters
+  if (non_ascii && *non_ascii) {
+    if (threadIdx.x == 0) M.cursor[1] = 3ull;
+    return;
+  }
   constexpr int WPB = IMG ? 16 : 4;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t W = M.S / 4096u;  // bitmap words per lane (1, 2 or 4)
-  const uint32_t list_cap = kfListPer4K * W;
+  const uint32_t list_cap = kfDensePer4K * W;
   uint16_t *list = reinterpret_cast<uint16_t *>(smem) + (size_t)wave * (kfListPer4K * kfMaxWords);
   uint32_t *bnd = reinterpret_cast<uint32_t *>(smem + (size_t)WPB * kfListPer4K * kfMaxWords * 2) + wave * 64;
   uint2 *ends = reinterpret_cast<uint2 *>(smem + (size_t)WPB * (kfListPer4K * kfMaxWords * 2 + 256)) + wave * (64 * kfMaxEnds);
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
     for (int k = 0; k < kfMaxWords; k++) cnt += (uint32_t)__popcll(m[k]);
     const uint32_t incl = wave_incl_scan(cnt);
     const uint32_t total = wave_last(incl);
-    if (total > list_cap) {  // more than a candidate per sixteen bytes: not this engine's text -- the other engines take the call
+    if (total > list_cap) {  // more than a candidate per ~20 bytes: not this engine's text -- the other engines take the call
       if (lane == 0) M.cursor[1] = 3ull;
       break;
     }
@@ -350,27 +364,29 @@ static size_t walk_lds(bool img, uint32_t n_slots) {
   return (size_t)(img ? 16 : 4) * kfWaveLds + (img ? (size_t)n_slots * 4 : 0);
 }
 
-void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, uint32_t cus, void *stream) {
+void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, unsigned long long *non_ascii,
+                          uint32_t cus, void *stream) {
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_bytes + 16383) / 16384, (uint64_t)cus * 2));
   // two blocks per CU (2 x 64 KiB of LDS): the loop is VALU work, eight waves per SIMD hide its loads
   if (F.d >= 4)
-    hipLaunchKernelGGL(kf_filter<true>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap);
+    hipLaunchKernelGGL(kf_filter<true>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap, non_ascii);
   else
-    hipLaunchKernelGGL(kf_filter<false>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap);
+    hipLaunchKernelGGL(kf_filter<false>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap, non_ascii);
 }
 
 // M.S: the chunk, 4096 << {0, 1, 2}; cus: the device's compute units (a block per CU when the image sits in LDS)
-void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, void *chunk_rec, uint32_t cus, void *stream) {
+void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, void *chunk_rec, const unsigned long long *non_ascii,
+                        uint32_t cus, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(kf_chunk_doc, dim3((uint32_t)((M.n_chunks + 255) / 256)), dim3(256), 0, s, M, (KfChunk *)chunk_rec);
   const bool img = filter_image_in_lds(A.n_slots);
   const auto *bm = (const unsigned long long *)bitmap;
   if (img) {
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((M.n_chunks + 15) / 16, cus));
-    hipLaunchKernelGGL(kf_walk<true>, dim3(grid), dim3(1024), walk_lds(true, A.n_slots), s, A, M, bm, (const KfChunk *)chunk_rec);
+    hipLaunchKernelGGL(kf_walk<true>, dim3(grid), dim3(1024), walk_lds(true, A.n_slots), s, A, M, bm, (const KfChunk *)chunk_rec, non_ascii);
   } else {
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((M.n_chunks + 3) / 4, (uint64_t)cus * 5));
-    hipLaunchKernelGGL(kf_walk<false>, dim3(grid), dim3(256), walk_lds(false, 0), s, A, M, bm, (const KfChunk *)chunk_rec);
+    hipLaunchKernelGGL(kf_walk<false>, dim3(grid), dim3(256), walk_lds(false, 0), s, A, M, bm, (const KfChunk *)chunk_rec, non_ascii);
   }
 }
 

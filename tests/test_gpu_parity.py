@@ -532,6 +532,16 @@ def test_engine_selected(engine, monkeypatch):
         sparse_text = b"-" * 5000 + b"abcd"
         engines = [asc.match_array(sparse_text).shape[0] and asc.last_timing()["engine"] for _ in range(6)]
         assert engines[0] == 2 and engines[-1] == 5 and sorted(engines) == engines
+        # char offsets: the same engine while the batch is plain ASCII (char offsets are byte offsets then; kf_filter looks
+        # at every byte anyway), the byte-level engine as soon as it is not
+        one = lambda t: (np.frombuffer(t, dtype=np.uint8), np.array([0, len(t)], dtype=np.uint64))
+        hits, _ = asc.match_batch(*one(sparse_text), chars=True)
+        assert asc.last_timing()["engine"] == 5 and [tuple(h) for h in hits.tolist()] == [(5000, 5003, 0), (5001, 5004, 1)]
+        utf = "é".encode() * 2500 + b"abcd"
+        hits, _ = asc.match_batch(*one(utf), chars=True)
+        assert asc.last_timing()["engine"] == 2 and [tuple(h) for h in hits.tolist()] == [(2500, 2503, 0), (2501, 2504, 1)]
+        hits, _ = asc.match_batch(*one(utf))  # (byte offsets: non-ASCII text is nothing special)
+        assert asc.last_timing()["engine"] == 5 and [tuple(h) for h in hits.tolist()] == [(5000, 5003, 0), (5001, 5004, 1)]
     # char offsets run on the character-level engine too, the separator filter on the byte-level engines only
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
     assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u23", "uh", "auto") else (2, 5) if engine == "f" else (2,))

@@ -520,17 +520,21 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   uint64_t lanes = (uint64_t)ac->v2_grid * kV2Threads;
   uint64_t S = ((N + lanes - 1) / lanes + 63) / 64 * 64;
   S = std::min<uint64_t>(std::max<uint64_t>(S, s_min), kV2MaxS);
-  // the prefix-filter engine: byte offsets, no separator filter, the event regions; a wave takes a chunk of 4, 8 or 16 KiB
-  // (the larger, the fuller its batches of 64 candidates; at least 16 chunks per wave of the device all the same)
+  // the prefix-filter engine: no separator filter, the event regions; a wave takes a chunk of 4, 8, 16 or 32 KiB -- the larger,
+  // the fuller its batches of 64 candidates and the fewer chunks the post passes see (cfg 2 at 64 MiB: 0.136 ms with 4 KiB,
+  // 0.117 with 16 KiB) -- while every wave of the device still has one, and while the image, if it fits LDS at all, still
+  // fits beside the longer candidate lists.
   // (a call with char offsets enters as a call with byte offsets: the same hits while the batch is plain ASCII, which
   // kf_filter finds out on its way; a batch that is not comes back with rc 3 like a dense one)
   const bool filt = ac->pf_ok && !ac->unit_ok && !M1.sep && !M1.no_filter && mode != kSlabs && !(de && strcmp(de, "0") == 0);
   if (filt) {
     S = 4096;
-    while (S < 16384 && N / (2 * S) >= (uint64_t)ac->pf_cus * 16 * 4) S *= 2;
+    while (S < kV2MaxS && N / (2 * S) >= (uint64_t)ac->pf_cus * 16 &&
+           (filter_image_in_lds(ac->n_slots, (uint32_t)(2 * S)) || !filter_image_in_lds(ac->n_slots, 4096)))
+      S *= 2;
     if (const char *fc = getenv("AHA_FILTER_CHUNK")) {  // the tests' way to the larger chunks without a batch of 128+ MiB
       const long v = atol(fc);
-      if (v == 4096 || v == 8192 || v == 16384) S = (uint64_t)v;
+      if (v == 4096 || v == 8192 || v == 16384 || v == 32768) S = (uint64_t)v;
     }
   }
   V2Args M{};

@@ -160,13 +160,13 @@ struct FilterDev {
   uint32_t d;     // bytes of a key the filter looks at: min(4, shortest key)
   uint32_t log2;  // the filter has 2^log2 words (10 .. kFilterLog2)
 };
-constexpr uint32_t kFilterImageLds = 88u << 10;  // kf_walk keeps an image up to this size in LDS, beside the waves' candidate lists
-bool filter_image_in_lds(uint32_t n_slots);
+// kf_walk keeps the image in LDS, beside its 16 waves' candidate lists, when both fit (chunks of 32 KiB: 57 KiB of image, 4 KiB: 115)
+bool filter_image_in_lds(uint32_t n_slots, uint32_t chunk_bytes);
 int filter_prepare();  // once per process, before the first launch (LDS beyond 64 KiB is opt-in)
 // non_ascii (nullable): set to 1 by kf_filter when the batch holds a byte >= 0x80; kf_walk then hands the call back (cursor[1] = 3)
 void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, unsigned long long *non_ascii,
                           uint32_t cus, void *stream);
-// bitmap (one bit per byte position) -> evd / ev_cnt / doc_ev_rank of chunks of M.S bytes (4, 8 or 16 KiB); chunk_rec: n_chunks * filter_chunk_rec_bytes() of scratch
+// bitmap (one bit per byte position) -> evd / ev_cnt / doc_ev_rank of chunks of M.S bytes (4, 8, 16 or 32 KiB); chunk_rec: n_chunks * filter_chunk_rec_bytes() of scratch
 size_t filter_chunk_rec_bytes();
 void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, void *chunk_rec, const unsigned long long *non_ascii,
                         uint32_t cus, void *stream);

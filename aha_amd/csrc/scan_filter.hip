@@ -32,15 +32,16 @@ namespace aha {
 namespace {
 
 constexpr int kfWarm = 64, kfAhead = 64;
-constexpr int kfMaxWords = 4;      // bitmap words a lane of kf_walk takes: chunks of up to 16 KiB
+constexpr int kfMaxWords = 8;      // bitmap words a lane of kf_walk takes: chunks of up to 32 KiB
 constexpr int kfListPer4K = 256;   // candidates a chunk's list holds per 4 KiB
 constexpr int kfDensePer4K = 208;  // more than this (one per ~20 bytes) and the batch is not this engine's: the byte-level engine
                                    // costs what filter + walks cost at about 5.5 % (tools/lab/f4.sh: 30 000 keys over letters, 6.5 %,
                                    // tie; 10 000 keys, 2.2 %, 1.7 x faster here)
 constexpr int kfMaxEnds = 4;  // END steps a walk keeps; a walk with more hands the call to the other engines
 
-// LDS of a wave of kf_walk: its candidate list, the document boundaries near its chunk, the END steps of a batch's walks
-constexpr int kfWaveLds = kfListPer4K * kfMaxWords * 2 + 64 * 4 + 64 * kfMaxEnds * 8;
+// LDS of a wave of kf_walk with chunks of W * 4 KiB: its candidate list (2 bytes an entry), the document boundaries near
+// its chunk, the END steps of a batch's walks
+__host__ __device__ constexpr uint32_t kf_wave_lds(uint32_t W) { return kfListPer4K * W * 2 + 64 * 4 + 64 * kfMaxEnds * 8; }
 
 // ---- the filter: bit p of the bitmap <=> text[p .. p + D) may start a key.  An entry of the filter: the product
 // w * 0x9E3779B1 of the D bytes (little endian, D < 4: the upper bytes masked off) selects a word with its top log2 bits and
@@ -142,12 +143,13 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
   }
   constexpr int WPB = IMG ? 16 : 4;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t W = M.S / 4096u;  // bitmap words per lane (1, 2 or 4)
+  const uint32_t W = M.S / 4096u;  // bitmap words per lane (1, 2, 4 or 8)
   const uint32_t list_cap = kfDensePer4K * W;
-  uint16_t *list = reinterpret_cast<uint16_t *>(smem) + (size_t)wave * (kfListPer4K * kfMaxWords);
-  uint32_t *bnd = reinterpret_cast<uint32_t *>(smem + (size_t)WPB * kfListPer4K * kfMaxWords * 2) + wave * 64;
-  uint2 *ends = reinterpret_cast<uint2 *>(smem + (size_t)WPB * (kfListPer4K * kfMaxWords * 2 + 256)) + wave * (64 * kfMaxEnds);
-  uint32_t *lslots = reinterpret_cast<uint32_t *>(smem + (size_t)WPB * kfWaveLds);
+  uint8_t *mine = smem + (size_t)wave * kf_wave_lds(W);
+  uint16_t *list = reinterpret_cast<uint16_t *>(mine);
+  uint32_t *bnd = reinterpret_cast<uint32_t *>(mine + kfListPer4K * W * 2);
+  uint2 *ends = reinterpret_cast<uint2 *>(mine + kfListPer4K * W * 2 + 256);
+  uint32_t *lslots = reinterpret_cast<uint32_t *>(smem + (size_t)WPB * kf_wave_lds(W));
   const uint32_t *gslots = reinterpret_cast<const uint32_t *>(A.slots);
   if (IMG) {
     for (uint32_t i = threadIdx.x; i < A.n_slots; i += 1024) lslots[i] = gslots[i];
@@ -358,10 +360,14 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
 
 size_t filter_chunk_rec_bytes() { return sizeof(KfChunk); }
 
-bool filter_image_in_lds(uint32_t n_slots) { return (size_t)n_slots * 4 <= kFilterImageLds; }
+// LDS of a CU that a block of 16 waves may take (nothing static in kf_walk)
+constexpr size_t kfLdsBudget = 160u << 10;
+bool filter_image_in_lds(uint32_t n_slots, uint32_t chunk_bytes) {
+  return (size_t)n_slots * 4 + 16 * (size_t)kf_wave_lds(chunk_bytes / 4096u) <= kfLdsBudget;
+}
 
-static size_t walk_lds(bool img, uint32_t n_slots) {
-  return (size_t)(img ? 16 : 4) * kfWaveLds + (img ? (size_t)n_slots * 4 : 0);
+static size_t walk_lds(bool img, uint32_t n_slots, uint32_t W) {
+  return (size_t)(img ? 16 : 4) * kf_wave_lds(W) + (img ? (size_t)n_slots * 4 : 0);
 }
 
 void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, unsigned long long *non_ascii,
@@ -374,25 +380,26 @@ void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_by
     hipLaunchKernelGGL(kf_filter<false>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap, non_ascii);
 }
 
-// M.S: the chunk, 4096 << {0, 1, 2}; cus: the device's compute units (a block per CU when the image sits in LDS)
+// M.S: the chunk, 4096 << {0, 1, 2, 3}; cus: the device's compute units (a block per CU when the image sits in LDS)
 void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, void *chunk_rec, const unsigned long long *non_ascii,
                         uint32_t cus, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(kf_chunk_doc, dim3((uint32_t)((M.n_chunks + 255) / 256)), dim3(256), 0, s, M, (KfChunk *)chunk_rec);
-  const bool img = filter_image_in_lds(A.n_slots);
+  const bool img = filter_image_in_lds(A.n_slots, M.S);
+  const uint32_t W = M.S / 4096u;
   const auto *bm = (const unsigned long long *)bitmap;
   if (img) {
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((M.n_chunks + 15) / 16, cus));
-    hipLaunchKernelGGL(kf_walk<true>, dim3(grid), dim3(1024), walk_lds(true, A.n_slots), s, A, M, bm, (const KfChunk *)chunk_rec, non_ascii);
+    hipLaunchKernelGGL(kf_walk<true>, dim3(grid), dim3(1024), walk_lds(true, A.n_slots, W), s, A, M, bm, (const KfChunk *)chunk_rec, non_ascii);
   } else {
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((M.n_chunks + 3) / 4, (uint64_t)cus * 5));
-    hipLaunchKernelGGL(kf_walk<false>, dim3(grid), dim3(256), walk_lds(false, 0), s, A, M, bm, (const KfChunk *)chunk_rec, non_ascii);
+    hipLaunchKernelGGL(kf_walk<false>, dim3(grid), dim3(256), walk_lds(false, 0, W), s, A, M, bm, (const KfChunk *)chunk_rec, non_ascii);
   }
 }
 
 int filter_prepare() {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&kf_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)walk_lds(true, kFilterImageLds / 4)) != hipSuccess) {
+                          (int)kfLdsBudget) != hipSuccess) {
     (void)hipGetLastError();  // (not left for the next call's check to find)
     return -1;
   }

@@ -85,7 +85,7 @@ while time.time() < t_end:
            "AHA_UNIT_HEADER_BESIDE": rng.choice([None, "0", "1"]),
            "AHA_UNIT_BASE_BITS": rng.choice([None, None, "23"]),
            "AHA_DIRECT": rng.choice([None, None, "0"]),
-           "AHA_FILTER_CHUNK": rng.choice([None, "8192", "16384"])}
+           "AHA_FILTER_CHUNK": rng.choice([None, "8192", "16384", "32768"])}
     if kwl:
         env["AHA_ENGINE"] = rng.choice([None, "filter"])
         env["AHA_DIRECT"] = None

@@ -4,9 +4,9 @@
 //
 // The reference's state after byte j is the LONGEST suffix of the text that is a trie path (ac.cr:176-192), i.e. the goto
 // walk of the EARLIEST start that is still alive at j.  So instead of carrying a state through every byte:
-//   kf_filter   every byte position asks a blocked Bloom filter in LDS (64 KiB) whether its next D bytes (D = min(4, shortest
+//   kf_filter   every byte position asks a blocked Bloom filter in LDS (4 .. 64 KiB) whether its next D bytes (D = min(4, shortest
 //               key)) are the first D bytes of some key: one bit per position.  Stateless, position-parallel, coalesced.
-//   kf_walk     a wave takes a chunk of 4 KiB: the candidate bits of the chunk (and of the kfWarm bytes before it: walks that
+//   kf_walk     a wave takes a chunk of 4 .. 32 KiB: the candidate bits of the chunk (and of the kfWarm bytes before it: walks that
 //               reach into the chunk) become batches of 64 candidates in position order, a lane walks ONE candidate's goto
 //               path through the byte-level image (no fail links, no state between candidates); an END step is the
 //               reference's event exactly when no earlier start's walk is still alive at its end -- the exclusive prefix

@@ -25,7 +25,10 @@
  * overflowed its region (aha_timing.repeats then says that the call ran twice).  Plus ~24 bytes per chunk and 4 bytes per
  * document.  A device corpus that is not 16-byte aligned is first copied into scratch (N bytes).
  * Character-level engine (aha_ac_info_t.unit_enabled; aha_timing.engine = 4): its records are 12 bytes and go straight to
- * the expansion -- 24 bytes per hit of capacity + 3N/16 with the fused expansion (output chains of at most 15 keys), + the 8-byte regions above with the general post passes.
+ * the expansion -- 24 bytes per hit of capacity + 3N/16 with the fused expansion (output chains of at most 15 keys), + the
+ * 8-byte regions above with the general post passes.
+ * Prefix-filter engine (aha_ac_info_t.filter_prefix_bytes; aha_timing.engine = 5): the region pipeline's records in chunks
+ * of 4 .. 32 KiB (16 bytes per hit of capacity + N/8 as above) + one bit per input byte (N/8) + 16 bytes per chunk.
  */
 #ifndef AHA_HIP_H
 #define AHA_HIP_H

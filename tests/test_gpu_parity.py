@@ -493,6 +493,71 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
     assert g.match_batch_device(big[1:1 + corpus.size], dd, out) == n  # scratch grows back
 
 
+@pytest.mark.parametrize("chunk", [None, "4096", "8192", "16384", "32768"])
+def test_prefix_filter_engine_edges(engine, monkeypatch, chunk):
+    """The prefix-filter engine's own corners (scan_filter.hip), each against the oracle (src/aha/ac.cr:176-192, 265-278) and
+    with the engine that answered: keys of exactly 3 bytes (the masked window) and of 64 (four blocks of steps), starts in the
+    bytes before a chunk, keys across chunk and document boundaries, documents of a few bytes (more boundaries near a chunk
+    than its table holds), empty documents, NUL bytes, a batch shorter than a window, more nested keys on one walk than a lane
+    keeps (handed back), every chunk size."""
+    if engine not in ("f", "auto"):
+        pytest.skip("the prefix-filter engine's variants")
+    if chunk:
+        monkeypatch.setenv("AHA_FILTER_CHUNK", chunk)
+    else:
+        monkeypatch.delenv("AHA_FILTER_CHUNK", raising=False)
+    rng = random.Random(77)
+
+    def run(keys, text, cuts, want_engine):
+        ac = AC.compile(keys)
+        ac.set_profiling(True)
+        o = orc.AC.compile(keys)
+        t = np.frombuffer(text, dtype=np.uint8)
+        doc = np.array(sorted([0, len(text)] + [c for c in (cuts or []) if c <= len(text)]), dtype=np.uint64)  # (twice: empty)
+        gh, gd = ac.match_batch(t, doc)
+        oh, od = o.match_batch(t, doc)
+        assert np.asarray(gh).tobytes() == oh.tobytes() and np.array_equal(np.asarray(gd, dtype=np.uint64), od)
+        if len(text) and want_engine:
+            assert ac.last_timing()["engine"] == want_engine, (ac.last_timing(), ac.info["filter_prefix_bytes"])
+        return len(oh)
+
+    # keys of exactly three bytes and of sixty-four; filler the keys do not start with
+    k3 = [b"abc", b"bcd", b"xyz", b"zzz"]
+    long = bytes(rng.choice(b"qrstuv") for _ in range(64))
+    keys = k3 + [long, long[:40], long[10:50], b"abcd" * 8]
+    body = []
+    for i in range(4000):
+        # (the last key is sixteen key starts in 32 bytes: rare, or a chunk is denser than the engine takes)
+        body.append(rng.choice(keys[:-1] if rng.random() < 0.9 else keys) if rng.random() < 0.2 else b" " * rng.randint(1, 40))
+    text = b"".join(body)
+    assert run(keys, text, None, 5) > 500
+    # ... the same text cut into documents at random places (keys across boundaries are no hits), with empty documents
+    cuts = sorted(rng.randint(0, len(text)) for _ in range(300))
+    run(keys, text, cuts + cuts[5:9], 5)
+    # keys that start in the bytes before a chunk and end in it, at every chunk size's boundaries; NUL bytes beside them
+    pad = bytearray(b"-" * (3 * 32768 + 100))
+    for edge in range(4096, len(pad) - 70, 4096):
+        back = (1, 2, 3, 17, 63)[(edge // 4096) % 5]
+        pad[edge - back:edge - back + 64] = long
+        pad[edge + 2000:edge + 2003] = b"abc"
+        pad[edge + 100] = 0
+        pad[edge + 101:edge + 104] = b"xyz"
+    run(keys, bytes(pad), [4096, 8192 + 1, 32768 - 1, 32768, 65536 + 3], 5)
+    # documents of a few bytes: hundreds of boundaries in reach of one chunk
+    tiny = (b"abc" + b"-" * 29) * 1500  # (a key start per 32 bytes: below the density the engine hands back)
+    run(keys, tiny, list(range(0, len(tiny), 7)), 5)
+    run(keys, tiny, list(range(0, len(tiny), 3)), 5)
+    # a batch shorter than the filter's window, an empty one, one of exactly a key
+    for t in (b"", b"ab", b"abc", b"zabcd", long):
+        run(keys, t, None, None)
+    # five keys end on one walk: more than a lane keeps -- the call comes back and the byte-level engine answers it
+    nest = [b"abc", b"abcd", b"abcde", b"abcdef", b"abcdefg", b"abcdefgh"]
+    t = (b"-" * 50 + b"abcdefgh") * 200
+    assert run(nest, t, None, 2) == 6 * 200
+    # ... four still fit
+    assert run(nest[:4], t, None, 5) == 4 * 200
+
+
 def test_engine_selected(engine, monkeypatch):
     ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)

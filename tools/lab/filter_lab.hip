@@ -48,6 +48,12 @@ __global__ __launch_bounds__(1024) void kf(const uint32_t *bloom, const uint8_t 
         bits |= ((word >> (h >> (32 - LOG2 - 5))) & (word >> (h >> (32 - LOG2 - 10))) & 1u) << k;
         continue;
       }
+      if (V == 8) {  // the product's HIGH word: its low bits are the middle of the 64-bit product -- word address by one AND
+        h = __umulhi(w, 0x9E3779B1u);
+        const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(bl) + (h & (((1u << LOG2) - 1u) << 2)));
+        bits |= ((word >> (h >> 16)) & (word >> (h >> 21)) & 1u) << k;
+        continue;
+      }
       if (V == 3) {
         h = __umul24(w, 0x9E3779u) + __umul24(w >> 8, 0x85EBCBu);
         h ^= h >> 11;
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(1024) void kf(const uint32_t *bloom, const uint8_t 
   }
   for (int s = 32; s >= 1; s >>= 1) mine += __shfl_xor(mine, s, 64);
   if ((V == 1 || V == 7 && blockIdx.x == 0xFFFFFF) && (threadIdx.x & 63) == 0 && mine) atomicAdd(n_cand, (unsigned long long)mine);
-  if (V == 7 && (threadIdx.x & 63) == 0 && mine && (blockIdx.x & 7) == 0) atomicAdd(n_cand, (unsigned long long)mine * 8);
+  if ((V == 7 || V == 8) && (threadIdx.x & 63) == 0 && mine && (blockIdx.x & 7) == 0) atomicAdd(n_cand, (unsigned long long)mine * 8);
 }
 
 // V5 with the next iteration's text loaded before the current one is hashed
@@ -143,7 +149,7 @@ int main(int argc, char **argv) {
   hipMalloc(&bloom, 4 << LOG2);
   hipMalloc(&cnt, 8);
   hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, text, n);
-  std::vector<uint32_t> hb(1 << LOG2, 0), hb7(1 << LOG2, 0);
+  std::vector<uint32_t> hb(1 << LOG2, 0), hb7(1 << LOG2, 0), hb8(1 << LOG2, 0);
   uint64_t x = 12345;
   for (int i = 0; i < 1000; i++) {  // a thousand random lower-case 4-grams
     uint32_t w = 0;
@@ -155,6 +161,8 @@ int main(int argc, char **argv) {
     h ^= h >> 15;
     hb[h >> (32 - LOG2)] |= (1u << (h & 31)) | (1u << ((h >> 5) & 31));
     const uint32_t g = w * 0x9E3779B1u;
+    const uint32_t mh = (uint32_t)(((uint64_t)w * 0x9E3779B1ull) >> 32);
+    hb8[(mh >> 2) & ((1u << LOG2) - 1u)] |= (1u << ((mh >> 16) & 31)) | (1u << ((mh >> 21) & 31));
     hb7[g >> (32 - LOG2)] |= (1u << ((g >> (32 - LOG2 - 5)) & 31)) | (1u << ((g >> (32 - LOG2 - 10)) & 31));
   }
   hipMemcpy(bloom, hb.data(), 4 << LOG2, hipMemcpyHostToDevice);
@@ -164,6 +172,8 @@ int main(int argc, char **argv) {
     run<5>(bloom, text, n, bm, cnt, grid);
     hipMemcpy(bloom, hb7.data(), 4 << LOG2, hipMemcpyHostToDevice);
     run<7>(bloom, text, n, bm, cnt, grid);
+    hipMemcpy(bloom, hb8.data(), 4 << LOG2, hipMemcpyHostToDevice);
+    run<8>(bloom, text, n, bm, cnt, grid);
     hipMemcpy(bloom, hb.data(), 4 << LOG2, hipMemcpyHostToDevice);
   }
   return 0;

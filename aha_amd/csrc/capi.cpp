@@ -639,7 +639,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   } else if (filt) {
     // filter (one bit per byte position), then the candidates' goto walks, a wave per chunk
     unsigned long long *non_ascii = M1.chars ? M.cursor + 6 : nullptr;
-    filter_launch_filter(ac->fdev, M.text, N, sc->v2buf[22].p, non_ascii, ac->pf_cus, s);
+    filter_launch_filter(ac->fdev, M, sc->v2buf[22].p, sc->v2buf[23].p, non_ascii, ac->pf_cus, s);
     if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));  // (profiling only: ms_count = the filter, ms_scan = the walks)
     filter_launch_walk(ac->dev, M, sc->v2buf[22].p, sc->v2buf[23].p, non_ascii, ac->pf_cus, s);
   } else {

@@ -163,12 +163,14 @@ struct FilterDev {
 // kf_walk keeps the image in LDS, beside its 16 waves' candidate lists, when both fit (chunks of 32 KiB: 57 KiB of image, 4 KiB: 115)
 bool filter_image_in_lds(uint32_t n_slots, uint32_t chunk_bytes);
 int filter_prepare();  // once per process, before the first launch (LDS beyond 64 KiB is opt-in)
-// non_ascii (nullable): set to 1 by kf_filter when the batch holds a byte >= 0x80; kf_walk then hands the call back (cursor[1] = 3)
-void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, unsigned long long *non_ascii,
-                          uint32_t cus, void *stream);
-// bitmap (one bit per byte position) -> evd / ev_cnt / doc_ev_rank of chunks of M.S bytes (4, 8, 16 or 32 KiB); chunk_rec: n_chunks * filter_chunk_rec_bytes() of scratch
+// filter_launch_filter: bitmap (one bit per byte position of M.text) and -- on the same launch -- the chunk records of chunks
+// of M.S bytes (4, 8, 16 or 32 KiB; chunk_rec: n_chunks * filter_chunk_rec_bytes() of scratch).  non_ascii (nullable): set
+// to 1 when the batch holds a byte >= 0x80; kf_walk then hands the call back (cursor[1] = 3).
+// filter_launch_walk: bitmap + records -> evd / ev_cnt / doc_ev_rank.
 size_t filter_chunk_rec_bytes();
-void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, void *chunk_rec, const unsigned long long *non_ascii,
+void filter_launch_filter(const FilterDev &F, const V2Args &M, void *bitmap, void *chunk_rec, unsigned long long *non_ascii,
+                          uint32_t cus, void *stream);
+void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, const void *chunk_rec, const unsigned long long *non_ascii,
                         uint32_t cus, void *stream);
 
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact);

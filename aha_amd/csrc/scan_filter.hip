@@ -43,21 +43,38 @@ constexpr int kfMaxEnds = 4;  // END steps a walk keeps; a walk with more hands 
 // its chunk, the END steps of a batch's walks
 __host__ __device__ constexpr uint32_t kf_wave_lds(uint32_t W) { return kfListPer4K * W * 2 + 64 * 4 + 64 * kfMaxEnds * 8; }
 
+// per chunk: the first d with doc_off[d] >= chunk start and the boundary before it (kf_walk reads one record per chunk, a
+// chunk ahead, instead of searching).  Written by the blocks of kf_filter's launch that stand behind the filter's own.
+struct KfChunk {
+  uint64_t dn;
+  int64_t b_prev;  // doc_off[dn - 1] < chunk start (the start of the document that holds the byte before the chunk), or 0
+};
+__device__ __forceinline__ void kf_chunk_doc(const V2Args &M, KfChunk *rec, uint64_t c) {
+  if (c >= M.n_chunks || M.cursor[1] >= 16ull) return;
+  const uint64_t dn = first_boundary(M.doc_off, M.n_docs, c * (uint64_t)M.S);
+  rec[c] = KfChunk{dn, dn > 0 ? (int64_t)M.doc_off[dn - 1] : 0};
+}
+
 // ---- the filter: bit p of the bitmap <=> text[p .. p + D) may start a key.  An entry of the filter: the product
 // w * 0x9E3779B1 of the D bytes (little endian, D < 4: the upper bytes masked off) selects a word with its top log2 bits and
 // two bits of that word with the ten bits below (capi.cpp sets them: filter_entry) -- no fold of the product: its upper half is
 // where a multiplicative hash has mixed all of w's bytes, and the word index carries the discrimination.
 template <bool D4>
 __global__ __launch_bounds__(1024) void kf_filter(FilterDev F, const uint8_t *__restrict__ text, uint64_t n_bytes,
-                                                   uint16_t *__restrict__ bitmap, unsigned long long *non_ascii) {
+                                                   uint16_t *__restrict__ bitmap, unsigned long long *non_ascii, V2Args M,
+                                                   KfChunk *chunk_rec, uint32_t filter_blocks) {
   __shared__ uint32_t bl[1 << kFilterLog2];
+  if (blockIdx.x >= filter_blocks) {  // (the chunk records ride on this launch: a kernel of their own costs 5 us of a 64 MiB call)
+    kf_chunk_doc(M, chunk_rec, (uint64_t)(blockIdx.x - filter_blocks) * 1024 + threadIdx.x);
+    return;
+  }
   for (uint32_t i = threadIdx.x; i < (1u << F.log2); i += 1024) bl[i] = F.bloom[i];
   const uint32_t hs = 32u - F.log2;
   __syncthreads();
   const uint32_t dmask = F.d >= 4 ? 0xFFFFFFFFu : ((1u << (8 * F.d)) - 1u);
   const uint64_t n_pieces = ((n_bytes + 63) / 64) * 4;  // whole 64-bit words of the bitmap (pieces beyond the text: no bit)
   uint32_t seen = 0;  // OR of the bytes this lane looked at (a call with char offsets: is the batch plain ASCII?)
-  for (uint64_t p = (uint64_t)blockIdx.x * 1024 + threadIdx.x; p < n_pieces; p += (uint64_t)gridDim.x * 1024) {
+  for (uint64_t p = (uint64_t)blockIdx.x * 1024 + threadIdx.x; p < n_pieces; p += (uint64_t)filter_blocks * 1024) {
     const uint64_t g = p * 16;
     uint32_t d[5] = {0, 0, 0, 0, 0};  // 16 bytes + 3 of look-ahead (bytes beyond the text read as 0: no key holds a NUL)
     if (g >= n_bytes) {
@@ -88,20 +105,6 @@ __global__ __launch_bounds__(1024) void kf_filter(FilterDev F, const uint8_t *__
   }
   // (a plain store, not an atomic: every wave that has something to say says the same)
   if (non_ascii && (seen & 0x80808080u)) *non_ascii = 1ull;
-}
-
-// per chunk: the first d with doc_off[d] >= chunk start and the boundary before it (kf_walk reads one record per chunk, a
-// chunk ahead, instead of searching)
-struct KfChunk {
-  uint64_t dn;
-  int64_t b_prev;  // doc_off[dn - 1] < chunk start (the start of the document that holds the byte before the chunk), or 0
-};
-__global__ __launch_bounds__(256) void kf_chunk_doc(V2Args M, KfChunk *rec) {
-  if (M.cursor[1] >= 16ull) return;
-  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= M.n_chunks) return;
-  const uint64_t dn = first_boundary(M.doc_off, M.n_docs, c * (uint64_t)M.S);
-  rec[c] = KfChunk{dn, dn > 0 ? (int64_t)M.doc_off[dn - 1] : 0};
 }
 
 typedef uint32_t kf_v4u __attribute__((ext_vector_type(4)));
@@ -370,21 +373,24 @@ static size_t walk_lds(bool img, uint32_t n_slots, uint32_t W) {
   return (size_t)(img ? 16 : 4) * kf_wave_lds(W) + (img ? (size_t)n_slots * 4 : 0);
 }
 
-void filter_launch_filter(const FilterDev &F, const uint8_t *text, uint64_t n_bytes, void *bitmap, unsigned long long *non_ascii,
+void filter_launch_filter(const FilterDev &F, const V2Args &M, void *bitmap, void *chunk_rec, unsigned long long *non_ascii,
                           uint32_t cus, void *stream) {
-  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_bytes + 16383) / 16384, (uint64_t)cus * 2));
-  // two blocks per CU (2 x 64 KiB of LDS): the loop is VALU work, eight waves per SIMD hide its loads
+  // two blocks per CU (2 x 64 KiB of LDS): the loop is VALU work, eight waves per SIMD hide its loads; behind them the
+  // blocks that write the chunk records (1024 chunks each)
+  const uint32_t fb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((M.n_bytes + 16383) / 16384, (uint64_t)cus * 2));
+  const uint32_t grid = fb + (uint32_t)((M.n_chunks + 1023) / 1024);
   if (F.d >= 4)
-    hipLaunchKernelGGL(kf_filter<true>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap, non_ascii);
+    hipLaunchKernelGGL(kf_filter<true>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, M.text, M.n_bytes, (uint16_t *)bitmap,
+                       non_ascii, M, (KfChunk *)chunk_rec, fb);
   else
-    hipLaunchKernelGGL(kf_filter<false>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, text, n_bytes, (uint16_t *)bitmap, non_ascii);
+    hipLaunchKernelGGL(kf_filter<false>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, F, M.text, M.n_bytes, (uint16_t *)bitmap,
+                       non_ascii, M, (KfChunk *)chunk_rec, fb);
 }
 
 // M.S: the chunk, 4096 << {0, 1, 2, 3}; cus: the device's compute units (a block per CU when the image sits in LDS)
-void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, void *chunk_rec, const unsigned long long *non_ascii,
+void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, const void *chunk_rec, const unsigned long long *non_ascii,
                         uint32_t cus, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(kf_chunk_doc, dim3((uint32_t)((M.n_chunks + 255) / 256)), dim3(256), 0, s, M, (KfChunk *)chunk_rec);
   const bool img = filter_image_in_lds(A.n_slots, M.S);
   const uint32_t W = M.S / 4096u;
   const auto *bm = (const unsigned long long *)bitmap;

@@ -26,9 +26,9 @@ void v2_launch_direct_post(const DevAut &, const V2Args &, void *, void *, bool)
 void launch_has_nul(const uint8_t *, uint64_t, uint64_t *, void *) { no_gpu("launch_has_nul"); }
 bool filter_image_in_lds(uint32_t, uint32_t) { return false; }
 int filter_prepare() { return 0; }
-void filter_launch_filter(const FilterDev &, const uint8_t *, uint64_t, void *, unsigned long long *, uint32_t, void *) { no_gpu("filter_launch_filter"); }
+void filter_launch_filter(const FilterDev &, const V2Args &, void *, void *, unsigned long long *, uint32_t, void *) { no_gpu("filter_launch_filter"); }
 size_t filter_chunk_rec_bytes() { return 16; }
-void filter_launch_walk(const DevAut &, const V2Args &, const void *, void *, const unsigned long long *, uint32_t, void *) { no_gpu("filter_launch_walk"); }
+void filter_launch_walk(const DevAut &, const V2Args &, const void *, const void *, const unsigned long long *, uint32_t, void *) { no_gpu("filter_launch_walk"); }
 void unit_launch_regroup(const DevAut &, const V2Args &, void *) { no_gpu("unit_launch_regroup"); }
 void unit_launch_expand(const uint2 *, const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("unit_launch_expand"); }
 void v2_launch_hit_scan(const V2Args &, void *) { no_gpu("v2_launch_hit_scan"); }

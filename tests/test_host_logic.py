@@ -397,3 +397,20 @@ def test_output_structs_respect_the_callers_size():
     C.cast(buf, C.POINTER(C.c_uint32))[0] = 0
     assert L.aha_ac_last_timing(ac._h, C.cast(buf, C.POINTER(N.aha_timing))) == 0
     assert C.cast(buf, C.POINTER(C.c_uint32))[0] == tfull - 8 and all(b == 0xAA for b in bytes(buf)[tfull - 8:])
+
+
+def test_prefix_filter_is_built_for_keyword_lists_only():
+    """aha_ac_info_t.filter_prefix_bytes / filter_words (include/aha_hip.h): the prefix filter belongs to key sets whose keys
+    are 3 .. 64 bytes long and that get no character-level image; its size follows the number of keys (1/256 full at most
+    below 2^14 words)."""
+    kw = AC.compile(["alpha", "beta", "gamma", "delta"], host_only=True).info
+    assert kw["filter_prefix_bytes"] == 4 and kw["filter_words"] == 1024 and kw["unit_enabled"] == 0
+    assert AC.compile(["abc", "alpha"], host_only=True).info["filter_prefix_bytes"] == 3      # min(4, shortest key)
+    assert AC.compile(["ab", "alpha"], host_only=True).info["filter_prefix_bytes"] == 0       # a key of two bytes: no filter
+    assert AC.compile(["x" * 65, "alpha"], host_only=True).info["filter_prefix_bytes"] == 0   # ... of more than 64
+    cjk = AC.compile(["中国人", "我是中"], host_only=True).info                                # a character-level image instead
+    assert cjk["unit_enabled"] == 1 and cjk["filter_prefix_bytes"] == 0
+    rng = random.Random(3)
+    many = AC.compile(sorted({bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(4, 12)))
+                              for _ in range(5000)}), host_only=True).info
+    assert many["filter_prefix_bytes"] == 4 and many["filter_words"] == 1 << 14               # ~10 000 bits set: 2^14 words

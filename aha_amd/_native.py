@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AHA_HIP_LIB") or os.path.join(_HERE, "libaha_hip.so")
 SYNTH_PATH = os.path.join(_HERE, "libaha_synth.so")
 
-AHA_ABI_VERSION = 7
+AHA_ABI_VERSION = 8
 AHA_OK = 0
 AHA_E_INVALID = -1
 AHA_E_EMPTY_KEY = -2
@@ -32,6 +32,7 @@ AHA_OPT_FORCE_WIDE = 2
 AHA_IMG_SLOTS, AHA_IMG_END_KEY, AHA_IMG_KEY_LN, AHA_IMG_KEY_CNT, AHA_IMG_KEY_KC = 0, 1, 2, 3, 4
 AHA_IMG_STALE_ENDS = 5
 AHA_IMG_UNIT_SLOTS, AHA_IMG_UNIT_ROOT, AHA_IMG_UNIT_END_KEY, AHA_IMG_UNIT_TABLES = 6, 7, 8, 9
+AHA_IMG_UNIT_MARKS = 10
 
 
 class aha_options(C.Structure):
@@ -53,7 +54,8 @@ class aha_ac_info_t(C.Structure):
                 ("unit_syms", C.c_uint32), ("unit_multi_permille", C.c_uint32), ("unit_big_lo", C.c_uint32),
                 ("unit_big_block", C.c_uint32), ("unit_n_low", C.c_uint32), ("unit_n_big", C.c_uint32),
                 ("unit_base_bits", C.c_uint32), ("unit_headers", C.c_uint32),
-                ("filter_prefix_bytes", C.c_uint32), ("filter_words", C.c_uint32)]
+                ("filter_prefix_bytes", C.c_uint32), ("filter_words", C.c_uint32),
+                ("skip_filter_words", C.c_uint32), ("skip_pairs", C.c_uint32)]
 
 
 class aha_timing(C.Structure):

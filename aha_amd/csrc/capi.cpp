@@ -93,6 +93,9 @@ struct aha_ac {
   const uint2 *d_unit_end_chars = nullptr;  // ... with the key's length in characters (char offsets)
   const uint2 *d_unit_end = nullptr;  // fused expansion (scan_unit.hip ku_expand_groups): key, key length, chain offset per END base
   bool unit_fused = false;            // ... usable: flattened chains of at most 15 keys, key lengths below 2^16
+  // skip-ahead traversal over the unit image (unit.hpp MARKS, scan_skip.hip): the filter over the two-unit paths on the device
+  bool skip_ok = false;
+  SkipDev sdev{};
   uint32_t seg2 = 0;  // slots below it: the root's and the depth-1 states' rows
   // match_longest only (cedar_replay.cpp): the states that carry one of Cedar's stale END flags, derived on the first
   // match_longest call (it replays every insert: as long again as the rest of compile); dev_longest = dev + the bitmap
@@ -369,6 +372,23 @@ int32_t fill_params(aha_ac *ac, const aha_match_params *p, MatchArgs &M, int *lo
 // ---- single-traversal engine: sizing, scratch, orchestration ----------------
 constexpr size_t kLdsPerCU = 160 * 1024;
 
+// The skip-ahead traversal (scan_skip.hip) takes a handle's plain byte-offset matches when the unit image has 22-bit bases,
+// no key is a single unit and the filter over its two-unit paths is at most half full (beyond that most positions are
+// marked and the marking pass is pure overhead: cfg 5's million keys).  AHA_ENGINE=unit keeps ku_traverse, AHA_ENGINE=skip
+// builds the unit image for every eligible key set like "unit" does; AHA_SKIP=0 / 1 overrides the fill rule.
+bool skip_eligible(const aha_ac *ac) {
+  const UnitImage &u = ac->unit;
+  if (!u.ok || u.base_bits != 22 || u.unit_key || u.mark_bloom.empty()) return false;
+  const char *eng = getenv("AHA_ENGINE");
+  if (eng && strcmp(eng, "skip") != 0) return false;
+  // (its walk has the header trip only: images whose states mostly own a header take ku_traverse<.., HB> -- v2_setup's rule)
+  const char *hb = getenv("AHA_UNIT_HEADER_BESIDE");
+  if (hb ? atoi(hb) != 0 : (!eng && (uint64_t)u.n_nfr * 5 >= u.n_states)) return false;  // (AHA_ENGINE=skip: the header trip)
+  const char *sk = getenv("AHA_SKIP");
+  if (sk) return atoi(sk) != 0;
+  return (eng != nullptr) || u.mark_fill_permille <= 500;
+}
+
 // Host-only plan: how much of the image the traversal kernel keeps in LDS.
 void plan_engine(aha_ac *ac, const Placement &pl) {
   (void)pl;
@@ -452,8 +472,16 @@ void v2_setup(aha_ac *ac) {
       // text falls out of deep matches where many states own a fail header: then the header comes beside the probe (a second
       // load in every trip) instead of in a trip of its own -- -8.5 % on cfg 5, +3.5 % on cfg 3 (profiles/r04_two_walks.txt)
       const char *hb = getenv("AHA_UNIT_HEADER_BESIDE");  // 0 / 1: tests
-      ac->udev.hdr_beside = hb ? (uint32_t)(atoi(hb) != 0) : (uint32_t)((uint64_t)ac->unit.n_nfr * 5 >= ac->unit.n_states);
+      const char *eng2 = getenv("AHA_ENGINE");
+      ac->udev.hdr_beside = hb ? (uint32_t)(atoi(hb) != 0)
+                               : (uint32_t)(!(eng2 && strcmp(eng2, "skip") == 0) && (uint64_t)ac->unit.n_nfr * 5 >= ac->unit.n_states);
       ac->unit_ok = true;
+      // the skip-ahead traversal over the same image: its filter over the two-unit paths (unit.hpp, MARKS)
+      if (skip_eligible(ac) && !ac->udev.hdr_beside && skip_prepare(ac->unit.n_syms, ac->unit.mark_log2) == 0 &&
+          upload(ac, ac->unit.mark_bloom, &ac->sdev.bloom) == AHA_OK) {
+        ac->sdev.log2 = ac->unit.mark_log2;
+        ac->skip_ok = true;
+      }
     }
   }
 }
@@ -579,6 +607,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   const uint64_t n_reg = direct ? M.n_chunks * M.ev_stride : 0;
   // byte offsets through the event regions: the character-level traversal where the key set has a unit image
   const bool unit = ac->unit_ok && direct;
+  // ... started only at the marks of a first, stateless pass where the handle has the filter for it (byte offsets)
+  const bool skip = unit && ac->skip_ok && !M.chars;
   int32_t rc;
   size_t sizes[24] = {M.ev_cap * 16,      M.ev_cap * 16,      M.ev_cap * 4,     direct ? 0 : n_slabs * 4,
                       M.n_chunks * 4,     (M.n_docs + 1) * 4, M.n_chunks * 8,   n_blk * 8,
@@ -588,7 +618,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
                       (unit && ac->unit_fused) ? 0 : n_reg * 8, 0 /* [17]: aligned copy of an unaligned corpus */,
                       direct ? M.n_chunks * 4 : 0, direct ? M.n_chunks * 8 : 0,
                       unit ? (M.n_docs + 1) * 4 : 0, unit ? n_reg * 12 : 0,
-                      filt ? ((N + 63) / 64 + 2) * 8 : 0 /* [22]: candidate bitmap */, filt ? M.n_chunks * filter_chunk_rec_bytes() : 0 /* [23] */};
+                      filt ? ((N + 63) / 64 + 2) * 8 : (skip ? skip_bitmap_bytes(N) : 0) /* [22]: candidate bitmap / marks */, filt ? M.n_chunks * filter_chunk_rec_bytes() : 0 /* [23] */};
   for (int i = 0; i < 24; i++) {
     if (!sizes[i]) continue;
     if ((rc = v2_reserve(ac, sc, i, sizes[i]))) {
@@ -635,7 +665,13 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (unit) {
     post.end_info = ac->d_unit_end_info;  // events carry bases of the unit image
     post.compact = 1;
-    unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+    if (skip) {
+      skip_launch_mark(ac->sdev, M, sc->v2buf[22].p, ac->v2_grid, s);
+      if (prof) HIPCHK(ac, hipEventRecord(sc->ev[2], s));  // (profiling only: ms_count = the marks, ms_scan = the walk)
+      skip_launch_traverse(ac->udev, M, sc->v2buf[22].p, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+    } else {
+      unit_launch_traverse(ac->udev, M, (uint32_t)std::min<uint64_t>(ac->v2_grid, n_tiles), s);
+    }
   } else if (filt) {
     // filter (one bit per byte position), then the candidates' goto walks, a wave per chunk
     unsigned long long *non_ascii = M1.chars ? M.cursor + 6 : nullptr;
@@ -689,12 +725,12 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     aha_timing t;
     memset(&t, 0, sizeof(t));
     t.struct_size = sizeof(t);
-    t.engine = unit ? 4 : (filt ? 5 : 2);
+    t.engine = skip ? 6 : (unit ? 4 : (filt ? 5 : 2));
     t.chunk_bytes = M.S;
     t.n_kernels = 9;
     (void)hipEventElapsedTime(&t.ms_total, sc->ev[0], sc->ev[4]);
-    (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], filt ? sc->ev[2] : sc->ev[1]);
-    if (filt) (void)hipEventElapsedTime(&t.ms_scan, sc->ev[2], sc->ev[1]);
+    (void)hipEventElapsedTime(&t.ms_count, sc->ev[0], (filt || skip) ? sc->ev[2] : sc->ev[1]);
+    if (filt || skip) (void)hipEventElapsedTime(&t.ms_scan, sc->ev[2], sc->ev[1]);
     if (direct) {
       (void)hipEventElapsedTime(&t.ms_aux, sc->ev[1], sc->ev[3]);
     } else {
@@ -859,7 +895,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     // character-level image: built when the keys are UTF-8-shaped and at least 30 % of their bytes lie in multi-byte
     // characters (AHA_ENGINE=unit forces it for every eligible key set, AHA_ENGINE=v2 / v1 never build it)
     const char *eng = getenv("AHA_ENGINE");
-    if (!eng || strcmp(eng, "unit") == 0) build_unit(ac->aut, ac->unit, eng != nullptr);
+    if (!eng || strcmp(eng, "unit") == 0 || strcmp(eng, "skip") == 0) build_unit(ac->aut, ac->unit, eng != nullptr);
     if (getenv("AHA_DEBUG") && !ac->unit.ok) fprintf(stderr, "aha: no character-level image: %s\n", ac->unit.why);
     // prefix filter (scan_filter.hip): the keys' first D = min(4, shortest key) bytes in a blocked Bloom filter of 64 KiB.
     // For key sets of at least 3-byte keys (a shorter prefix passes too much text), none beyond 64 bytes (a walk's reach
@@ -1089,8 +1125,15 @@ int32_t aha_ac_load(const void *buf, uint64_t n_bytes, const aha_options *opts, 
 
 // Output structs grow with the ABI: the caller says how many bytes its struct has (struct_size, set before the call) and gets
 // no more than that; 0 -- a caller built before the field was read -- means the size the struct had then (ABI 5).
-static void copy_sized(void *dst, const void *full, uint32_t caller_size, size_t full_size, size_t abi5_size) {
-  const size_t n = caller_size == 0 ? abi5_size : std::min<size_t>(caller_size, full_size);
+// Output structs that grew with the ABI are filled up to the caller's struct_size -- when that is a size the struct has had
+// (sizes[]: ascending, 0-terminated; the first is the size of ABI 5, when the structs were output-only and nobody set the
+// field).  Anything else -- 0, or the stack garbage of a caller built against the old header -- gets the ABI-5 size: the
+// library never writes more than the oldest struct holds unless the caller says exactly which newer one it has (a caller
+// built against a LATER header gets the ABI-5 part and reads from struct_size how much was filled).
+static void copy_sized(void *dst, const void *full, uint32_t caller_size, const size_t *sizes) {
+  size_t n = sizes[0];
+  for (int i = 0; sizes[i]; i++)
+    if (caller_size == sizes[i]) n = sizes[i];
   if (n < 4) return;
   memcpy(dst, full, n);
   const uint32_t filled = (uint32_t)n;
@@ -1128,7 +1171,12 @@ int32_t aha_ac_info(const aha_ac *ac, aha_ac_info_t *caller_info) {
   const bool pf = ac->device < 0 ? ac->pf_d != 0 : ac->pf_ok;
   info->filter_prefix_bytes = pf ? ac->pf_d : 0;
   info->filter_words = pf ? 1u << ac->pf_log2 : 0;
-  copy_sized(caller_info, &full, caller_info->struct_size, sizeof(full), sizeof(full) - 32);
+  const bool sk = ac->device < 0 ? skip_eligible(ac) : ac->skip_ok;
+  info->skip_filter_words = sk ? 1u << ac->unit.mark_log2 : 0;
+  info->skip_pairs = sk ? ac->unit.n_pairs : 0;
+  static const size_t kInfoSizes[] = {offsetof(aha_ac_info_t, unit_big_lo) /* ABI 5 */, offsetof(aha_ac_info_t, filter_prefix_bytes) /* 6 */,
+                                      offsetof(aha_ac_info_t, skip_filter_words) /* 7 */, sizeof(aha_ac_info_t), 0};
+  copy_sized(caller_info, &full, caller_info->struct_size, kInfoSizes);
   return AHA_OK;
 }
 
@@ -1199,6 +1247,10 @@ int64_t aha_ac_export(const aha_ac *ac, int32_t which, void *buf, uint64_t cap_b
       src = ac->unit.tables.data();
       bytes = ac->unit.tables.size() * 4;
       break;
+    case AHA_IMG_UNIT_MARKS:
+      src = ac->unit.mark_bloom.data();
+      bytes = skip_eligible(ac) ? ac->unit.mark_bloom.size() * 4 : 0;
+      break;
     case AHA_IMG_STALE_ENDS: {
       // {key id, prefix length} of every state with a stale END flag: the state is that prefix of that key
       aha_ac *m = const_cast<aha_ac *>(ac);
@@ -1267,7 +1319,8 @@ int32_t aha_ac_last_timing(const aha_ac *ac, aha_timing *t) {
     full = ac->last;
   }
   full.struct_size = sizeof(full);
-  copy_sized(t, &full, t->struct_size, sizeof(full), sizeof(full) - 8);
+  static const size_t kTimingSizes[] = {offsetof(aha_timing, repeats) /* ABI 5 */, sizeof(aha_timing), 0};
+  copy_sized(t, &full, t->struct_size, kTimingSizes);
   return AHA_OK;
 }
 

@@ -152,6 +152,18 @@ void unit_launch_expand(const uint2 *uend, const DevAut &A, const V2Args &M, uin
 void v2_launch_hit_scan(const V2Args &M, void *stream);   // chunk_hits -> hit_base, totals[0]
 void v2_launch_lead_scan(const V2Args &M, void *stream);  // lead_cnt -> lead_base, totals[1] (char offsets)
 
+// ---- skip-ahead traversal over the unit image (scan_skip.hip; unit.hpp, MARKS)
+struct SkipDev {
+  const uint32_t *bloom;  // [1 << log2] blocked Bloom filter over the two-unit paths, keyed by raw bytes
+  uint32_t log2;
+};
+int skip_prepare(uint32_t n_syms, uint32_t log2_words);  // raises the dynamic-LDS limits; hipError_t as int
+size_t skip_bitmap_bytes(uint64_t n_bytes);             // scratch of a call: one bit per byte position, padded
+// ks_mark: text -> bitmap (bit p: a two-unit path may start at p).  ks_traverse: ku_traverse's walk and outputs (evg, ev_cnt,
+// chunk_hits, doc_*_rank), started only at marked positions.
+void skip_launch_mark(const SkipDev &K, const V2Args &M, void *bitmap, uint32_t grid, void *stream);
+void skip_launch_traverse(const UnitDev &U, const V2Args &M, const void *bitmap, uint32_t grid, void *stream);
+
 // ---- prefix-filter engine (scan_filter.hip): byte-level, for batches where few positions can start a key
 constexpr uint32_t kFilterMul = 0x9E3779B1u;  // an entry of the filter: scan_filter.hip kf_filter, capi.cpp filter_entry
 constexpr uint32_t kFilterLog2 = 14;  // 2^14 words = 64 KiB: blocked Bloom filter over the keys' first D bytes

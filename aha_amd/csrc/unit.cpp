@@ -14,6 +14,7 @@ namespace {
 struct UTrans {
   uint32_t sym;    // while collecting: class << 16 | payload; afterwards the symbol
   uint32_t child;  // byte-level state id (at a unit boundary)
+  uint32_t raw;    // the unit's bytes as a little-endian integer (unit.hpp, MARKS)
 };
 
 }  // namespace
@@ -89,7 +90,7 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
       const uint32_t c1 = a.first_child[s] + j;
       const uint32_t b0 = a.in_label[c1];
       if (need[c1] == 0) {
-        tr.push_back({(1u << 16) | b0, c1});
+        tr.push_back({(1u << 16) | b0, c1, b0});
         continue;
       }
       for (uint32_t j2 = 0; j2 < a.n_child[c1]; j2++) {
@@ -99,7 +100,7 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
           const uint32_t p = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
           lo2 = std::min(lo2, p);
           hi2 = std::max(hi2, p + 1);
-          tr.push_back({(2u << 16) | p, c2});
+          tr.push_back({(2u << 16) | p, c2, b0 | b1 << 8});
           continue;
         }
         for (uint32_t j3 = 0; j3 < a.n_child[c2]; j3++) {
@@ -108,7 +109,7 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
           const uint32_t p = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
           lo3 = std::min(lo3, p);
           hi3 = std::max(hi3, p + 1);
-          tr.push_back({(3u << 16) | p, c3});
+          tr.push_back({(3u << 16) | p, c3, b0 | b1 << 8 | b2 << 16});
         }
       }
     }
@@ -183,6 +184,28 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
   std::vector<uint8_t> udepth(S, 0);
   for (uint32_t s : ustates)
     for (uint32_t t = first[s]; t < first[s + 1]; t++) udepth[tr[t].child] = (uint8_t)std::min<uint32_t>(udepth[s] + 1u, 255u);
+  // ---- MARKS (unit.hpp): the two-unit paths in a blocked Bloom filter keyed by raw bytes -- the smallest of 2^10 .. 2^14
+  // words that stays under 1/16 full, else the largest
+  for (uint32_t s : ustates)
+    if (udepth[s] == 1 && a.key_of[s] >= 0) u.unit_key = true;
+  if (!u.unit_key) {
+    for (uint32_t t0 = first[0]; t0 < first[1]; t0++) u.n_pairs += first[tr[t0].child + 1] - first[tr[t0].child];
+    for (uint32_t lg = kSkipMinLog2; u.n_pairs && lg <= kSkipMaxLog2; lg++) {
+      u.mark_bloom.assign((size_t)1 << lg, 0u);
+      for (uint32_t t0 = first[0]; t0 < first[1]; t0++) {
+        const uint32_t part = sk_part(tr[t0].raw), c0 = tr[t0].child;
+        for (uint32_t t1 = first[c0]; t1 < first[c0 + 1]; t1++) {
+          const uint32_t h = sk_hash(part, tr[t1].raw);
+          u.mark_bloom[sk_word(h, lg)] |= sk_mask(h);
+        }
+      }
+      uint64_t bits = 0;
+      for (uint32_t x : u.mark_bloom) bits += (uint64_t)__builtin_popcount(x);
+      u.mark_log2 = lg;
+      u.mark_fill_permille = (uint32_t)(bits * 1000 / ((uint64_t)32 << lg));
+      if (bits * 16 <= ((uint64_t)32 << lg)) break;
+    }
+  }
   auto has_header = [&](uint32_t s) {  // the fail state is neither the root nor a one-character state: its word is kept in a slot
     return s != 0 && a.fail[s] != 0 && udepth[a.fail[s]] != 1;
   };

@@ -115,6 +115,28 @@ AHA_HD inline uint32_t u_sym(uint32_t hi) { return hi & 0xFFFFu; }
 AHA_HD inline uint32_t u_c4(uint32_t hi) { return (hi >> 16) & 255u; }
 AHA_HD inline bool u_hdr_pending(uint32_t lo) { return ((lo >> 29) & 3u) == 1u; }  // F1 without NFR: fetch the header next
 
+// MARKS (scan_skip.hip, the skip-ahead traversal).  While the automaton's state is the root or a one-unit state, its next
+// state is a function of the next two units alone: the two-unit state when they spell a trie path, else the one-unit state
+// (or the root) of the second.  So a walk in such a state may jump to the next position where a two-unit path STARTS and
+// consume that unit from the root -- provided no key is a single unit (nothing can be reported on the way).  A first,
+// stateless kernel marks those positions: every unit start p whose units at p and behind it pass a blocked Bloom filter over
+// the image's two-unit paths, keyed by the units' RAW bytes (a unit = its one to three bytes as a little-endian integer;
+// no symbol decode).  False marks cost the walk a trip, a missing one would lose hits: the filter has no false negatives.
+constexpr uint32_t kSkipKA = 0x9E3779u, kSkipKB = 0x85EBCBu;
+constexpr uint32_t kSkipMinLog2 = 10, kSkipMaxLog2 = 14;  // 4 .. 64 KiB of LDS beside ks_mark's input rows
+// low 32 bits of the product of the operands' low 24 bits (v_mul_u32_u24 on the device)
+AHA_HD inline uint32_t sk_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+AHA_HD inline uint32_t sk_part(uint32_t c0) {  // the first unit's share of the pair's hash (carried to the next unit)
+  const uint32_t g = sk_mul24(c0, kSkipKB);
+  return (g >> 11) | (g << 21);
+}
+AHA_HD inline uint32_t sk_hash(uint32_t part, uint32_t c1) {
+  const uint32_t h = sk_mul24(c1, kSkipKA) + part;
+  return h ^ (h >> 16);
+}
+AHA_HD inline uint32_t sk_word(uint32_t h, uint32_t log2_words) { return h >> (32u - log2_words); }
+AHA_HD inline uint32_t sk_mask(uint32_t h) { return (1u << (h & 31u)) | (1u << ((h >> 5) & 31u)); }
+
 struct UnitImage {
   bool ok = false;
   const char *why = "";
@@ -132,6 +154,12 @@ struct UnitImage {
   uint32_t c2lo = 0, w2 = 0, c3lo = 0, w3 = 0;
   uint32_t n_states = 0, n_trans = 0, n_nfr = 0;
   uint32_t multi_permille = 0;      // share of the key bytes that lie in two- and three-byte units
+  // MARKS: the filter over the two-unit paths (empty: a key is a single unit, or there is no two-unit path)
+  std::vector<uint32_t> mark_bloom;  // [1 << mark_log2]
+  uint32_t mark_log2 = 0;
+  uint32_t n_pairs = 0;              // two-unit paths
+  uint32_t mark_fill_permille = 0;   // set bits of the filter, per 1000
+  bool unit_key = false;             // a key of one unit: every position could report -- no skipping
 };
 
 // a: the byte-level automaton (build_automaton).  Fills u; u.ok = false + u.why when the key set is not eligible or

@@ -53,7 +53,7 @@ lib LibAhaHip
     longest : Int32 # 0 = #match, 1 = #match_longest(intersectable: false), 2 = #match_longest(intersectable: true)
   end
 
-  # aha_ac_info_t (ABI 7)
+  # aha_ac_info_t (ABI 8)
   struct Info
     struct_size : UInt32
     n_keys : UInt32
@@ -80,6 +80,8 @@ lib LibAhaHip
     unit_headers : UInt32       # ABI 7: states that own a fail header
     filter_prefix_bytes : UInt32 # ABI 7: the prefix-filter engine looks at this many first bytes of a key (0: none)
     filter_words : UInt32       # ABI 7: 32-bit words of its Bloom filter
+    skip_filter_words : UInt32  # ABI 8: words of the mark filter of the skip-ahead traversal (engine 6; 0: none)
+    skip_pairs : UInt32         # ABI 8: two-character trie paths it holds
   end
 
   # aha_timing (ABI 6): filled when profiling is on

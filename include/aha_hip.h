@@ -44,7 +44,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define AHA_ABI_VERSION 7
+#define AHA_ABI_VERSION 8
 
 /* Aha::Hit -- src/aha/matcher.cr:2-11.  Half-open [start,end) offsets
  * relative to the start of the sequence (document); value = key index in
@@ -152,6 +152,16 @@ typedef struct {
    * single-traversal engine by the call itself (aha_timing.repeats counts it). */
   uint32_t filter_prefix_bytes;
   uint32_t filter_words;
+  /* ABI 8: the skip-ahead traversal (aha_amd/csrc/scan_skip.hip; aha_timing.engine = 6) over the character-level image.
+   * While the state of src/aha/ac.cr:176-192 is the root or a one-character state, its next state depends on the next two
+   * characters alone and -- when no key is a single character -- nothing can be reported, so the walk may jump to the next
+   * position where a two-character trie path starts.  A stateless first kernel marks those positions through a blocked Bloom
+   * filter over the image's skip_pairs two-character paths (skip_filter_words 32-bit words, keyed by the characters' raw bytes;
+   * 0 = this handle has none: a one-character key, 23-bit bases, the header requested beside the probe, a filter more than
+   * half full); the second kernel is the character-level traversal, started only at marked positions.  Byte offsets, no
+   * separator filter; every other call of the handle keeps engine 4. */
+  uint32_t skip_filter_words;
+  uint32_t skip_pairs;
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded
@@ -160,15 +170,16 @@ typedef struct {
   uint32_t struct_size;
   uint32_t n_kernels;
   float ms_total;           /* first launch -> hits and offsets final in HBM */
-  float ms_count;           /* engines 4, 2: the traversal kernel; engine 5: the filter kernel; engine 1: traversal pass 1 */
+  float ms_count;           /* engines 4, 2: the traversal kernel; engine 5: the filter kernel; engine 6: the marking kernel; engine 1:
+                             * traversal pass 1 */
   float ms_scan;            /* scans of per-chunk counts (slab pipeline; the region pipelines have them in ms_aux: no event in
-                             * between); engine 5: the candidates' walks (chunk records + kf_walk) */
+                             * between); engine 5: the candidates' walks (chunk records + kf_walk); engine 6: the traversal */
   float ms_write;           /* engine 2: chain expansion + doc offsets; engine 1: traversal pass 2 */
   float ms_aux;             /* engine 2: hits per chunk + scan (regions) or event sort (slabs); engine 1: char-offset prefix pass */
   uint64_t n_chunks;
   uint64_t n_hits;
-  uint32_t engine;          /* 5 = prefix filter + candidate walks, 4 = character-level traversal, 2 = single-traversal engine,
-                             * 1 = two-pass engine */
+  uint32_t engine;          /* 6 = marks + skip-ahead character-level traversal, 5 = prefix filter + candidate walks,
+                             * 4 = character-level traversal, 2 = single-traversal engine, 1 = two-pass engine */
   uint32_t chunk_bytes;     /* bytes per lane chunk */
   /* ABI 6: passes over the batch that were thrown away before this one: 1 when a chunk's event region overflowed -- the
    * batch was denser than `cap` said -- and the match ran once more with full-size regions (the call took about twice
@@ -305,6 +316,7 @@ enum {
   AHA_IMG_UNIT_ROOT = 7,      /* uint32[unit_syms]: the root's transitions by symbol */
   AHA_IMG_UNIT_END_KEY = 8,   /* int32[unit_slots]: key id at the base of an END state, else -1 */
   AHA_IMG_UNIT_TABLES = 9,    /* uint32[2816]: the decode tables (unit.hpp, SYMBOLS) */
+  AHA_IMG_UNIT_MARKS = 10,    /* uint32[skip_filter_words]: the Bloom filter over the two-character paths (unit.hpp, MARKS) */
   AHA_IMG_STALE_ENDS = 5     /* {uint32 key id, uint32 prefix length}[]: the states (a prefix of a key each) whose node in
                                  the reference's Cedar keeps a stale END flag (src/aha/cedar.cr:642-648); match_longest
                                  treats them as ends that yield nothing (src/aha/ac.cr:126-128, 249-263) */

@@ -17,6 +17,10 @@ size_t v2_lds_bytes(uint32_t, bool) { return 0; }
 size_t unit_lds_bytes(uint32_t) { return 0; }
 int unit_prepare(uint32_t) { return 0; }
 void unit_launch_traverse(const UnitDev &, const V2Args &, uint32_t, void *) { no_gpu("unit_launch_traverse"); }
+int skip_prepare(uint32_t, uint32_t) { return 0; }
+size_t skip_bitmap_bytes(uint64_t) { return 0; }
+void skip_launch_mark(const SkipDev &, const V2Args &, void *, uint32_t, void *) { no_gpu("skip_launch_mark"); }
+void skip_launch_traverse(const UnitDev &, const V2Args &, const void *, uint32_t, void *) { no_gpu("skip_launch_traverse"); }
 int v2_prepare(bool, size_t) { return 0; }
 void v2_launch_traverse(const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("v2_launch_traverse"); }
 void v2_launch_chunk_scan(const V2Args &, void *) { no_gpu("v2_launch_chunk_scan"); }

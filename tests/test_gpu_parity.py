@@ -17,7 +17,7 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u23", "uh", "f", "auto"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u23", "uh", "k", "f", "auto"], autouse=True)
 def engine(request, monkeypatch):
     """Every parity test runs on the single-traversal engine (scan_v2.hip, byte level), on the two-pass engine
     (kernels.hip: the fallback for tiny capacities and very long keys), on the single-traversal engine with its LDS
@@ -31,7 +31,9 @@ def engine(request, monkeypatch):
     3-bit hit count in the event record; "uh" -- AHA_UNIT_HEADER_BESIDE=1 -- the traversal that requests a state's fail header
     beside its probe, ku_traverse<.., HB>, which the library picks for key sets like cfg 5's; "u" pins the header trip; "f" --
     AHA_ENGINE=filter -- the prefix-filter engine, scan_filter.hip, for every key set it takes: keys of 3 to 64 bytes, byte
-    offsets, no separator filter -- what the library picks for such key sets when they get no character-level image).  "auto" sets
+    offsets, no separator filter -- what the library picks for such key sets when they get no character-level image; "k" --
+    AHA_ENGINE=skip -- the skip-ahead traversal, scan_skip.hip: the unit image for every eligible key set like "u", its walk
+    started only at the marks of a first pass wherever no key is a single character, whatever the mark filter's fill).  "auto" sets
     no variable: the library decides per key set, which is what a caller and bench.py get.  The variables are read when a
     handle is compiled."""
     only = os.environ.get("AHA_TEST_ENGINES")  # (development: run the suite on some variants only, e.g. AHA_TEST_ENGINES=f,auto)
@@ -40,7 +42,7 @@ def engine(request, monkeypatch):
     if request.param == "auto":
         monkeypatch.delenv("AHA_ENGINE", raising=False)
     else:
-        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u23": "unit", "uh": "unit", "f": "filter"}.get(request.param, "v2"))
+        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u23": "unit", "uh": "unit", "f": "filter", "k": "skip"}.get(request.param, "v2"))
     if request.param in ("u", "uh"):
         monkeypatch.setenv("AHA_UNIT_HEADER_BESIDE", "1" if request.param == "uh" else "0")
     else:
@@ -485,7 +487,7 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
             t0 = time.perf_counter()
             assert g.match_batch_device(view, dd, out) == n
             best = min(best, time.perf_counter() - t0)
-        assert g.last_timing()["engine"] == (4 if engine in ("u", "u23", "uh") else 5 if engine == "f" else 2)
+        assert g.last_timing()["engine"] == (4 if engine in ("u", "u23", "uh") else 5 if engine == "f" else 6 if engine == "k" else 2)
         res[shift] = (best, out[:n].cpu().numpy().tobytes())
     assert res[0][1] == res[1][1]
     assert res[0][0] / res[1][0] >= 0.7, (res[0][0], res[1][0])
@@ -562,11 +564,11 @@ def test_engine_selected(engine, monkeypatch):
     ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u23", "uh", "auto") else (2, 5) if engine == "f" else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5, 6) if engine in ("u", "ur", "u23", "uh", "k", "auto") else (2, 5) if engine == "f" else (2,))
     ac = AC.compile(["ab", "ba"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"ab ba " * 60))[:3] == [(0, 2, 0), (3, 5, 1), (6, 8, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u23", "uh", "auto") else (2, 5) if engine == "f" else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5, 6) if engine in ("u", "ur", "u23", "uh", "k", "auto") else (2, 5) if engine == "f" else (2,))
     if engine in ("u", "ur", "u23", "uh"):
         # the library's own choice (no AHA_ENGINE): keys of multi-byte characters get the character-level traversal for
         # byte- and char-offset batches, ASCII keys keep the byte-level one
@@ -609,7 +611,7 @@ def test_engine_selected(engine, monkeypatch):
         assert asc.last_timing()["engine"] == 5 and [tuple(h) for h in hits.tolist()] == [(5000, 5003, 0), (5001, 5004, 1)]
     # char offsets run on the character-level engine too, the separator filter on the byte-level engines only
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5) if engine in ("u", "ur", "u23", "uh", "auto") else (2, 5) if engine == "f" else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5, 6) if engine in ("u", "ur", "u23", "uh", "k", "auto") else (2, 5) if engine == "f" else (2,))
     sep = BitArray(256)
     sep[ord(" ")] = True
     assert [tuple(h) for h in ac.match("ab ba", sep)] == [(0, 2, 0), (3, 5, 1)]
@@ -1426,3 +1428,62 @@ def test_match_leaves_the_exchange_stream(engine):
     with pytest.raises(AhaError) as e:
         g.match_batch_device(dc, dd, out, None, words=words[:64], n_words=n_words)
     assert e.value.code == N.AHA_E_CAPACITY
+
+
+def test_skip_engine_selection_and_edges(engine, monkeypatch):
+    """The skip-ahead traversal (scan_skip.hip, aha_timing.engine = 6), each case against the oracle (src/aha/ac.cr:176-192,
+    265-278): which calls it answers -- byte offsets of a key set without a one-character key --, marks hundreds of bytes apart
+    (pseudo jumps at the end of a lane's two words of marks), keys across the 124-byte limit of those words, across chunk ends
+    and document boundaries, documents of a few bytes, empty documents, malformed UTF-8, NUL bytes, batches shorter than a
+    piece of the marking pass and not a multiple of it."""
+    if engine not in ("k", "auto"):
+        pytest.skip("the skip-ahead traversal's own cases")
+    rng = random.Random(11)
+    keys = ["中国人", "ab", "abc", "bcab", "我是", "是中国", "国人民", "яж", "жя中"]
+    g = AC.compile(keys)
+    g.set_profiling(True)
+    o = orc.AC.compile(keys)
+    assert g.info["unit_enabled"] == 1 and g.info["skip_filter_words"] >= 1024 and g.info["skip_pairs"] == 8
+
+    def check(text, doc, want_engine=6, **kw):
+        t = np.frombuffer(text, dtype=np.uint8)
+        d = np.asarray(doc, dtype=np.uint64)
+        gh, gd = g.match_batch(t, d, **kw)
+        oh, od = o.match_batch(t, d, cap=len(gh) + 16, **kw)
+        assert len(gh) == len(oh) and np.array_equal(gd, od) and gh.tobytes() == oh.tobytes(), (text[:200], doc[:8])
+        if len(text):
+            assert g.last_timing()["engine"] == want_engine
+
+    text = "我是中国人民 ab abc bcab яжя中 ".encode() * 50
+    check(text, [0, len(text)])
+    check(text, [0, len(text)], want_engine=4, chars=True)  # char offsets: the walk that counts characters
+    # sparse: marks hundreds of bytes apart, keys at every distance from the window and chunk ends
+    parts = []
+    for i in range(400):
+        parts.append((" " * rng.randint(0, 300) + rng.choice("xyz々民") * rng.randint(0, 40)).encode())
+        parts.append(rng.choice(keys).encode() * rng.randint(1, 3))
+    text = b"".join(parts)
+    check(text, [0, len(text)])
+    cuts = sorted({0, len(text)} | {rng.randrange(0, len(text)) for _ in range(200)})
+    check(text, cuts + [len(text)] * 3)  # documents cut anywhere (also inside characters), empty documents at the end
+    check(text, [0, 0, 0, 5, 5, 7, len(text)])
+    # malformed UTF-8, NUL
+    bad = [b"\xe4", b"\xe4\xb8", b"\xb8", b"\xad\xad", b"\xf0\x9f\x98\x80", b"\x00", b"\xc3", b"\xff", b"\xe4\xe4\xb8\xad"]
+    parts = []
+    for i in range(3000):
+        x = rng.random()
+        parts.append(rng.choice(keys).encode() if x < 0.3 else rng.choice(bad) if x < 0.5 else rng.choice("ab中国 яж").encode())
+    text = b"".join(parts)
+    check(text, [0, len(text)])
+    cuts = sorted({0, len(text)} | {rng.randrange(0, len(text)) for _ in range(50)})
+    check(text, cuts)
+    # short batches: below a piece, one byte over a piece, empty
+    for n in (0, 1, 2, 5, 63, 64, 65, 127, 129, 4095, 4097):
+        t = ("ab中国人abc" * 500).encode()[:n]
+        check(t, [0, len(t)])
+    # a key set with a one-character key keeps the plain character-level traversal
+    uk = AC.compile(["中", "中国", "国人"])
+    uk.set_profiling(True)
+    assert uk.info["skip_filter_words"] == 0
+    t = "中国人".encode() * 100
+    assert len(uk.match_array(t)) == 300 and uk.last_timing()["engine"] == 4

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/aha_hip.h but not exported"
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
-    assert N.lib().aha_abi_version() == 7
+    assert N.lib().aha_abi_version() == 8
     # ... and nothing else (-fvisibility=hidden + aha_amd/csrc/exports.map): a drop-in linked into someone else's process
     # must not bring unprefixed helpers, C++ internals or kernel stubs into its symbol space
     import shutil, subprocess
@@ -383,9 +383,11 @@ def test_output_structs_respect_the_callers_size():
     ac = AC.compile(["ab", "abc"], host_only=True)
     L = N.lib()
     full = C.sizeof(N.aha_ac_info_t)
-    abi5 = 80  # the struct before unit_big_lo .. (ABI 6) and the filter fields (ABI 7) were appended
-    assert full == 112
-    for said, filled in ((full, full), (full - 8, full - 8), (abi5, abi5), (0, abi5), (full + 64, full), (16, 16)):
+    abi5, abi6, abi7 = 80, 104, 112  # before unit_big_lo .. (ABI 6), the filter fields (ABI 7), the skip fields (ABI 8) were appended
+    assert full == 120
+    # a size the struct has had is honoured; anything else -- 0, garbage of a caller that never set the field -- gets the ABI-5 size
+    for said, filled in ((full, full), (abi7, abi7), (abi6, abi6), (abi5, abi5), (0, abi5), (16, abi5),
+                         (full - 4, abi5), (full + 64, abi5), (0xAAAAAAAA, abi5)):
         buf = (C.c_uint8 * (full + 64))(*([0xAA] * (full + 64)))
         C.cast(buf, C.POINTER(C.c_uint32))[0] = said
         assert L.aha_ac_info(ac._h, C.cast(buf, C.POINTER(N.aha_ac_info_t))) == 0

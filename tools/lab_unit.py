@@ -19,8 +19,8 @@ ts = []
 for _ in range(7):
     h = ac.match_batch_device(dc, dd, out, None)
     tm = ac.last_timing()
-    ts.append((tm["ms_count"], tm["ms_total"], tm["ms_write"]))
+    ts.append((tm["ms_count"] + tm["ms_scan"], tm["ms_total"], tm["ms_write"], tm["ms_count"], tm["ms_scan"]))
 ts.sort()
 m = ts[len(ts) // 2]
 print(f"{os.path.basename(os.environ.get('AHA_HIP_LIB', 'libaha_hip.so'))} {os.environ.get('AHA_LAB_NOTE', '')}: engine {tm['engine']} "
-      f"traverse {m[0]:.3f} ms total {m[1]:.3f} ms expansion {sorted(t[2] for t in ts)[len(ts) // 2]:.3f} ms hits {h}", flush=True)
+      f"traverse {m[0]:.3f} ms (kernels {m[3]:.3f} + {m[4]:.3f}) total {m[1]:.3f} ms expansion {sorted(t[2] for t in ts)[len(ts) // 2]:.3f} ms hits {h}", flush=True)

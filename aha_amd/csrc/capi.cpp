@@ -372,10 +372,11 @@ int32_t fill_params(aha_ac *ac, const aha_match_params *p, MatchArgs &M, int *lo
 // ---- single-traversal engine: sizing, scratch, orchestration ----------------
 constexpr size_t kLdsPerCU = 160 * 1024;
 
-// The skip-ahead traversal (scan_skip.hip) takes a handle's plain byte-offset matches when the unit image has 22-bit bases,
-// no key is a single unit and the filter over its two-unit paths is at most half full (beyond that most positions are
-// marked and the marking pass is pure overhead: cfg 5's million keys).  AHA_ENGINE=unit keeps ku_traverse, AHA_ENGINE=skip
-// builds the unit image for every eligible key set like "unit" does; AHA_SKIP=0 / 1 overrides the fill rule.
+// The skip-ahead traversal (scan_skip.hip) can take a handle's plain byte-offset matches when the unit image has 22-bit
+// bases and no key is a single unit.  It is OPT-IN (AHA_ENGINE=skip -- the unit image for every eligible key set like "unit" --
+// or AHA_SKIP=1 beside the library's own choice): measured on cfg 3 its second kernel is bound by the scattered 16-byte text
+// requests of its free-running lanes -- 3.75 ms per GiB against 2.24 for ku_traverse (profiles/r06_skip_engine.txt, DESIGN.md
+// section 4.7) --, so no key set gets it by default.
 bool skip_eligible(const aha_ac *ac) {
   const UnitImage &u = ac->unit;
   if (!u.ok || u.base_bits != 22 || u.unit_key || u.mark_bloom.empty()) return false;
@@ -386,7 +387,7 @@ bool skip_eligible(const aha_ac *ac) {
   if (hb ? atoi(hb) != 0 : (!eng && (uint64_t)u.n_nfr * 5 >= u.n_states)) return false;  // (AHA_ENGINE=skip: the header trip)
   const char *sk = getenv("AHA_SKIP");
   if (sk) return atoi(sk) != 0;
-  return (eng != nullptr) || u.mark_fill_permille <= 500;
+  return eng != nullptr;
 }
 
 // Host-only plan: how much of the image the traversal kernel keeps in LDS.
@@ -608,7 +609,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   // byte offsets through the event regions: the character-level traversal where the key set has a unit image
   const bool unit = ac->unit_ok && direct;
   // ... started only at the marks of a first, stateless pass where the handle has the filter for it (byte offsets)
-  const bool skip = unit && ac->skip_ok && !M.chars;
+  // (not a batch below one piece of the marking pass: its lanes ask for 16-byte windows wherever they stand)
+  const bool skip = unit && ac->skip_ok && !M.chars && N >= 64;
   int32_t rc;
   size_t sizes[24] = {M.ev_cap * 16,      M.ev_cap * 16,      M.ev_cap * 4,     direct ? 0 : n_slabs * 4,
                       M.n_chunks * 4,     (M.n_docs + 1) * 4, M.n_chunks * 8,   n_blk * 8,
@@ -708,6 +710,14 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   else
     HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(ac, hipStreamSynchronize(s));
+#ifdef AHA_SK_STATS
+  if (skip) {
+    unsigned long long w[16];
+    (void)hipMemcpy(w, sc->v2buf[9].p, sizeof(w), hipMemcpyDeviceToHost);
+    fprintf(stderr, "ks_traverse: %llu lane-trips (%.4f per byte), %llu jumps, %llu fresh, %llu wave-trips (%.1f %% of the lane slots used)\n", w[8],
+            (double)w[8] / (double)N, w[9], w[11], w[10], 100.0 * (double)w[8] / (64.0 * (double)w[10]));
+  }
+#endif
   if (sc->h_v2[1] >= 16) {  // the offsets are not what the call says (k_check_docs): nothing was indexed with them
     if (sc->h_v2[1] & 1) {
       tls_err = "doc offsets: need doc_offsets[0] = 0, ascending, doc_offsets[n_docs] = n_bytes";

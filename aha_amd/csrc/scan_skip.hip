@@ -180,10 +180,11 @@ __global__ __launch_bounds__(kV2Threads) void ks_traverse(UnitDev U, V2Args M, c
   const int64_t S = (int64_t)M.S;
   const int warm = U.max_len > 1 ? (int)U.max_len - 1 : 0;
 
-  // the unit that starts `at` bytes into the window w (at <= 7: the window holds twelve bytes and more behind it);
+  // the unit that starts `at` bytes into the window w (at <= 9: a window starts at a multiple of 4 at or below a position, the
+  // units at offsets <= 3, <= 6 and <= 9 are what a trip and the jump behind it look at);
   // dend = first byte, in window coordinates, that is not the document's (scan_unit.hip decode)
   auto wdecode = [&](const sk_v4u &w, uint32_t at, int32_t dend, uint32_t &o_code, uint32_t &o_L) {
-    const uint32_t lo = at < 4u ? w.x : w.y, hi = at < 4u ? w.y : w.z;
+    const uint32_t lo = at < 4u ? w.x : (at < 8u ? w.y : w.z), hi = at < 4u ? w.y : (at < 8u ? w.z : w.w);
     const uint32_t w4 = __builtin_amdgcn_alignbyte(hi, lo, at & 3u);
     const uint32_t b0 = w4 & 0xFFu;
     const uint4 q0 = t0a[b0];
@@ -223,9 +224,10 @@ __global__ __launch_bounds__(kV2Threads) void ks_traverse(UnitDev U, V2Args M, c
         pos0 = a - min<int64_t>(a - doc_start, warm);
       }
     }
-    const int64_t org = pos0 & ~(int64_t)63;
+    const int64_t org = live ? pos0 & ~(int64_t)63 : 0;  // (a lane without a chunk asks for the text's first bytes)
     const uint8_t *tx = M.text + org;
     const int64_t Nr = N - org;                                   // text bytes from org on
+    const uint32_t lim16 = (uint32_t)min<int64_t>(max<int64_t>(Nr - 16, 0), 0x7FFFFFFF);  // last offset a 16-byte window may start at
     const unsigned long long *bmp = bitmap + (org >> 6);
     const uint32_t er = live ? (uint32_t)(e - org) : 0u;          // the lane takes the units that start below it
     const int32_t a_rel = (int32_t)(a - org);
@@ -243,9 +245,17 @@ __global__ __launch_bounds__(kV2Threads) void ks_traverse(UnitDev U, V2Args M, c
     bool fresh = true;   // no state, no unit: the lane is about to jump from r (the chunk's start, a document's start)
     bool bmok = false;   // bm0 / bm1 hold the words bw, bw + 1
 
+#ifdef AHA_SK_STATS
+    uint32_t st_trips = 0, st_wtrips = 0, st_jumps = 0, st_probes = 0, st_fresh = 0;
+#endif
     for (;;) {
       const bool act = live & r < er;
       if (!wany(act)) break;
+#ifdef AHA_SK_STATS
+      st_wtrips++;
+      st_trips += act ? 1u : 0u;
+      st_fresh += (act & fresh) ? 1u : 0u;
+#endif
       {  // rare: a document starts at r (ac.cr:177: the state is per sequence)
         const bool bnd = act & r == nbr;
         if (wany(bnd)) {
@@ -294,14 +304,28 @@ __global__ __launch_bounds__(kV2Threads) void ks_traverse(UnitDev U, V2Args M, c
       const bool tmark = (((t < 64u ? bm0 >> t : bm1 >> (t - 64u))) & 1ull) != 0ull;
       const uint32_t stop = min(nbr, er);
       const uint32_t T1 = min((bw << 6) + t, stop);
-      // ---- requests: the text at the jump target, the text behind the unit at r, the next word of marks where the lane
-      // may leave its first one, the probe
+      // ---- requests, issued by hand and waited for ONCE in front of their first use (scan_unit.hip's way with its probe:
+      // left to hipcc every load is followed by its own wait -- four memory round trips per trip, 4.0 ms per GiB instead of
+      // what is measured now): the text at the jump target, the text behind the unit at r, the next word of marks, the probe.
+      // Every lane asks (the idle ones for the chunk's first bytes); a window that would reach beyond the text is asked for
+      // 16 bytes early and put right below (rare: the last bytes of the batch).
+      // Only the lanes that need them ask, and the windows start at multiples of 4 (measured, profiles/r06_skip_engine.txt: every
+      // lane asking for all four costs 6.5 ms per GiB against 3.9; a 16-byte load from an odd address costs the memory pipeline
+      // ~8.6 cycles per lane, from a multiple of 4 ~3.6).
       sk_v4u Bw = {0, 0, 0, 0}, Aw = Bw;
       unsigned long long Cw = 0;
+      const uint32_t gB = min(T1, lim16) & ~3u, gA = min(r + Le, lim16) & ~3u;
       if (act) {
-        Bw = sk_text16(tx, (int64_t)T1, Nr);
-        if (!fresh) Aw = sk_text16(tx, (int64_t)(r + L), Nr);
-        if (t + 3u >= 64u || sfrom >= 64u) Cw = bmp[bw + 2];
+        const uint8_t *pB = tx + gB;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Bw) : "v"(pB) : "memory");
+        if (!fresh) {
+          const uint8_t *pA = tx + gA;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Aw) : "v"(pA) : "memory");
+        }
+        if (t + 3u >= 64u | sfrom >= 64u) {
+          const unsigned long long *pC = bmp + (bw + 2u);
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(Cw) : "v"(pC) : "memory");
+        }
       }
       const bool trip = act & !fresh;
       uint32_t evc = 0, endr = 0;
@@ -315,14 +339,27 @@ __global__ __launch_bounds__(kV2Threads) void ks_traverse(UnitDev U, V2Args M, c
         se = hdr ? 0u : se;
         const uint32_t fc = code & 7u;
         const bool probe = trip & good & (((E | 0x20000000u) >> ((uint32_t)BB + fc)) & 1u) != 0u & Bq != 0u;
-        uint2 en = make_uint2(0u, 0u);
-        if (probe) en = slots[Bq ^ se];
+        unsigned long long enw;
+        {
+          const uint2 *ap = slots + (probe ? (Bq ^ se) : 0u);
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(enw) : "v"(ap) : "memory");
+        }
+        uint32_t n_code = 0, n_L = 1, rt = 0, rf = 0;
         if (trip) {
-          uint32_t n_code, n_L;
-          wdecode(W, off + L, (int32_t)(nbr - r + off), n_code, n_L);  // the next unit, while the probe is in flight
-          const uint32_t rt = rl[code];
-          const uint32_t rf = rl[pc];
-          const uint32_t enx = en.x, eny = en.y;
+          wdecode(W, off + L, (int32_t)(nbr - r + off), n_code, n_L);  // the next unit, while the requests are in flight
+          rt = rl[code];
+          rf = rl[pc];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(enw), "+v"(Bw), "+v"(Aw), "+v"(Cw) : : "memory");
+        {  // rare: a window at the very end of the text was asked for up to 15 bytes early
+          const bool fixB = act & T1 > lim16, fixA = trip & r + Le > lim16;
+          if (wany(fixB | fixA)) {
+            if (fixB) Bw = sk_text16(tx, (int64_t)(T1 & ~3u), Nr);
+            if (fixA) Aw = sk_text16(tx, (int64_t)((r + Le) & ~3u), Nr);
+          }
+        }
+        if (trip) {
+          const uint32_t enx = (uint32_t)enw, eny = (uint32_t)(enw >> 32);
           const bool symhit = probe & u_sym(eny) == se & !grp;
           const bool hit = symhit & !hdr;
           const bool redir = grp & probe & ((enx >> (code & 31u)) & 1u) != 0u;
@@ -357,13 +394,16 @@ __global__ __launch_bounds__(kV2Threads) void ks_traverse(UnitDev U, V2Args M, c
             jump = (E == 0u | d1) & !(d1 & mql);
             r = endr;
             W = Aw;
-            off = 0;
+            off = endr & 3u;
             code = n_code;
             L = n_L;
           }
         }
       }
       // ---- the jump: the unit at the target comes from the root's table, the one behind it is the next trip's
+#ifdef AHA_SK_STATS
+      st_jumps += jump ? 1u : 0u;
+#endif
       if (wany(jump)) {
         if (jump) {
           r = T1;
@@ -373,15 +413,17 @@ __global__ __launch_bounds__(kV2Threads) void ks_traverse(UnitDev U, V2Args M, c
           fresh = T1 >= stop;  // the document's or the chunk's end: nothing to take (a boundary makes the lane fresh anyway)
           if (!fresh) {
             uint32_t c0, l0;
-            wdecode(Bw, 0u, (int32_t)(nbr - T1), c0, l0);
+            const uint32_t o0 = T1 & 3u;  // (the window starts at T1 & ~3)
+            const int32_t dendB = (int32_t)(nbr - T1 + o0);
+            wdecode(Bw, o0, dendB, c0, l0);
             E = rl[c0] & 0x7FFFFFFFu;  // (no key is a single unit: nothing to report)
             pc = c0;
             d1 = E != 0u;
             mql = tmark;
             r = T1 + l0;
             W = Bw;
-            off = l0;
-            wdecode(Bw, l0, (int32_t)(nbr - T1), code, L);
+            off = o0 + l0;
+            wdecode(Bw, o0 + l0, dendB, code, L);
           }
         }
       }
@@ -425,6 +467,12 @@ __global__ __launch_bounds__(kV2Threads) void ks_traverse(UnitDev U, V2Args M, c
       const v3u rr = {q[0], q[1], q[2]};
       if ((uint32_t)lane < wfill && wout + (uint32_t)lane < wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = rr;
     }
+#ifdef AHA_SK_STATS
+    atomicAdd(&M.cursor[8], (unsigned long long)st_trips);
+    atomicAdd(&M.cursor[9], (unsigned long long)st_jumps);
+    atomicAdd(&M.cursor[11], (unsigned long long)st_fresh);
+    if (lane == 0) atomicAdd(&M.cursor[10], (unsigned long long)st_wtrips);
+#endif
     if (live) {
       M.ev_cnt[chunk] = seq;
       if (seq > ev_stride) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions

@@ -157,9 +157,10 @@ typedef struct {
    * characters alone and -- when no key is a single character -- nothing can be reported, so the walk may jump to the next
    * position where a two-character trie path starts.  A stateless first kernel marks those positions through a blocked Bloom
    * filter over the image's skip_pairs two-character paths (skip_filter_words 32-bit words, keyed by the characters' raw bytes;
-   * 0 = this handle has none: a one-character key, 23-bit bases, the header requested beside the probe, a filter more than
-   * half full); the second kernel is the character-level traversal, started only at marked positions.  Byte offsets, no
-   * separator filter; every other call of the handle keeps engine 4. */
+   * 0 = this handle has none: not asked for, a one-character key, 23-bit bases, the header requested beside the probe); the
+   * second kernel is the character-level traversal, started only at marked positions.  Byte offsets, no separator filter;
+   * every other call of the handle keeps engine 4.  OPT-IN (AHA_ENGINE=skip or AHA_SKIP=1 when the handle is compiled): on
+   * BASELINE config 3 it is slower than engine 4 (its lanes' scattered text requests), so no key set gets it by default. */
   uint32_t skip_filter_words;
   uint32_t skip_pairs;
 } aha_ac_info_t;

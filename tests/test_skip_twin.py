@@ -75,6 +75,8 @@ def test_skip_walk_reference_kat(monkeypatch):
     text = "我是中国人".encode()
     assert SkipSim(ac).match_batch(text, [0, len(text)]) == oracle_hits(orc.AC.compile(keys), text, [0, len(text)])
     assert AC.compile(["我", "我是", "是中"], host_only=True).info["skip_filter_words"] == 0  # spec/ac_spec.cr:5-12: no marks
+    monkeypatch.delenv("AHA_ENGINE", raising=False)
+    assert AC.compile(keys, host_only=True).info["skip_filter_words"] == 0  # opt-in: nothing gets it by default
 
 
 def test_skip_walk_long_sparse_text_and_window_ends(monkeypatch):
@@ -100,6 +102,7 @@ def test_skip_trip_count_on_the_headline_shape(monkeypatch):
     """cfg 3's shape at a small scale: the walk takes a fraction of the trips of one trip per character"""
     from aha_amd import synth
     monkeypatch.delenv("AHA_ENGINE", raising=False)
+    monkeypatch.setenv("AHA_SKIP", "1")  # (the engine is opt-in: AHA_ENGINE=skip, or AHA_SKIP=1 beside the library's own choice)
     blob, offs, nf = synth.keys(3, K=3000)
     corpus, doc = synth.corpus(3, blob, offs, nf, n_bytes=1 << 15, doc_bytes=1 << 13)
     ac = AC.compile_packed(blob, offs, host_only=True)

@@ -1,7 +1,7 @@
-"""Audit of the hand-issued probe of ku_traverse (scan_unit.hip): an asm load is invisible to hipcc's wait insertion, and its
+"""Audit of the hand-issued loads of ku_traverse (scan_unit.hip) and ks_traverse (scan_skip.hip): an asm load is invisible to hipcc's wait insertion, and its
 destination registers count as written at the end of the asm statement -- so nothing may read, copy or overwrite them between
-the load and the hand-written s_waitcnt that names them (cdna_hip_programming.md 5.7, item 1).  Compiles scan_unit.hip to
-ISA and checks every `global_load_dwordx2` that sits inside an ASMSTART/ASMEND pair.  Exit code 1 on a violation."""
+the load and the hand-written s_waitcnt that names them (cdna_hip_programming.md 5.7, item 1).  Compiles the two files to
+ISA and checks every `global_load_dword*` that sits inside an ASMSTART/ASMEND pair.  Exit code 1 on a violation."""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,17 +43,51 @@ def audit(isa):
     return seen, bad
 
 
+def slow_selects(isa):
+    """`v_cndmask_b32_e32 ..., vcc` whose VCC was last written by the scalar unit, inside the innermost loops that hold a
+    hand-issued probe: (kernel, count) pairs.  Reported, not a violation: profiles/r06_cndmask.txt -- re-encoding them as VOP3
+    in the assembly changes nothing on ku_traverse, forcing the VOP3 form in the source costs 3-5 %."""
+    out = []
+    kernel, writer, in_loop, n = None, None, False, 0
+    for t in isa.splitlines():
+        body = t.split(";")[0].strip()
+        if re.match(r"_ZN\S+:", t):
+            if kernel and n:
+                out.append((kernel, n))
+            kernel, writer, n = t.split(":")[0], None, 0
+        if not body or body.endswith(":"):
+            continue
+        op = body.split()[0]
+        if op.startswith("v_cndmask_b32_e32") and writer and writer.startswith("s_"):
+            n += 1
+        m = re.match(r"(\S+)\s+vcc\b", body)
+        if m and not op.startswith("v_cndmask"):
+            writer = op
+    if kernel and n:
+        out.append((kernel, n))
+    return out
+
+
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    seen, bad, slow = 0, [], []
+    flags = sys.argv[1:] or ["-O3", "-std=c++17"]  # (the Makefile passes the build's own CXXFLAGS; without arguments: its defaults)
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "scan_unit.s")
-        # (the Makefile passes the build's own CXXFLAGS; without arguments: its defaults)
-        flags = sys.argv[1:] or ["-O3", "-std=c++17"]
-        subprocess.check_call([hipcc, *flags, "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
-                               "-I", os.path.join(ROOT, "aha_amd", "csrc"), "-S", "--cuda-device-only", "-w", "-o", out,
-                               os.path.join(ROOT, "aha_amd", "csrc", "scan_unit.hip")])
-        seen, bad = audit(open(out).read())
+        for src in ("scan_unit.hip", "scan_skip.hip"):  # the files with hand-issued loads
+            out = os.path.join(d, src + ".s")
+            subprocess.check_call([hipcc, *flags, "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+                                   "-I", os.path.join(ROOT, "aha_amd", "csrc"), "-S", "--cuda-device-only", "-w", "-o", out,
+                                   os.path.join(ROOT, "aha_amd", "csrc", src)])
+            isa = open(out).read()
+            n, b = audit(isa)
+            seen += n
+            bad += [(ln, f"{src}: {t}") for ln, t in b]
+            if n == 0:
+                bad.append((0, f"{src}: no hand-issued load found"))
+            slow += slow_selects(isa)
     print(f"{seen} hand-issued probes audited, {len(bad)} violations")
+    if slow:
+        print(f"  (e32 selects on an SALU-written VCC, reported only: {sum(n for _, n in slow)} in {len(slow)} kernels)")
     for ln, t in bad:
         print(f"  line {ln}: {t}")
     return 1 if bad or seen == 0 else 0

@@ -655,6 +655,8 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.chunk_hits = (uint32_t *)sc->v2buf[18].p;
   M.hit_base = (uint64_t *)sc->v2buf[19].p;
   if ((rc = ensure_h_v2(ac, sc))) return rc;
+  // the region pipelines' last kernel -- the per-document offsets -- leaves the host's five words itself
+  M.publish = (direct && M.doc_hit_off && sc->h_v2_dev) ? sc->h_v2_dev : nullptr;
 
   const bool prof = ac->profiling.load() && sc->ev_ready;
   HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
@@ -694,7 +696,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
       unit_launch_expand(M.chars ? ac->d_unit_end_chars : ac->d_unit_end, post, M, 2u * ac->v2_grid, s);
     } else {
       if (unit) unit_launch_regroup(post, M, s);  // the wave-ordered events back into the chunks' regions, counted
-      v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr, unit);
+      v2_launch_direct_post(post, M, s, prof ? (void *)sc->ev[3] : nullptr, unit || filt);  // (kf_walk counts like ku_regroup)
     }
   } else {
     v2_launch_chunk_scan(M, s);
@@ -705,10 +707,13 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   }
   if (prof) HIPCHK(ac, hipEventRecord(sc->ev[4], s));
   HIPCHK(ac, hipGetLastError());
-  if (sc->h_v2_dev)
+  if (M.publish) {
+    // (done by k2d_doc_offsets / ku_doc_offsets)
+  } else if (sc->h_v2_dev) {
     launch_publish_words((const unsigned long long *)sc->v2buf[9].p, sc->h_v2_dev, 5, s);
-  else
+  } else {
     HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(ac, hipStreamSynchronize(s));
 #ifdef AHA_SK_STATS
   if (skip) {
@@ -726,8 +731,10 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     tls_err = aha_strerror(AHA_E_TOO_LONG);
     return AHA_E_TOO_LONG;
   }
-  M1.check_docs = 0;  // (looked at: a repeated pass or the two-pass engine need not look again)
   if (sc->h_v2[1] == 3) return 3;  // the prefix-filter engine gave up (candidates too dense, nested keys): the caller repeats without it
+                                   // (check_docs stays set: the repeat validates the offsets again -- 5 us -- rather than trust
+                                   // that no plain store of a hand-back overwrote a bad verdict)
+  M1.check_docs = 0;  // (looked at: a repeated pass or the two-pass engine need not look again)
   if (sc->h_v2[1] == 2) return 2;  // a chunk's event region overflowed: the caller repeats with full-size regions
   if (sc->h_v2[1]) return 1;  // event temp exhausted (cap too small): exact count via the two-pass engine
   *n_hits = sc->h_v2[2];
@@ -914,11 +921,28 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
     if ((!eng || strcmp(eng, "filter") == 0) && !ac->unit.ok && ac->img.compact && ac->aut.n_keys > 0 && ac->aut.max_key_len <= 64) {
       uint32_t minlen = ~0u;
       for (uint32_t k = 0; k < ac->aut.n_keys; k++) minlen = std::min(minlen, ac->aut.key_len[k]);
-      if (minlen >= 3) {
+      // keys nested in one another along one trie path: a walk of kf_walk keeps four END steps (scan_filter.hip kfMaxEnds)
+      // and hands the whole call back when it meets a fifth -- after the filter and part of the walks ran.  The deepest
+      // nesting is a property of the key set: with more than four keys on one root-to-leaf path there is no filter.
+      uint32_t nest = 0;
+      {
+        const Automaton &a = ac->aut;
+        std::vector<uint8_t> ends(a.n_states, 0);  // BFS numbering: a parent comes before its children
+        for (uint32_t st = 0; st < a.n_states; st++)
+          for (uint32_t j = 0; j < a.n_child[st]; j++) {
+            const uint32_t c = a.first_child[st] + j;
+            ends[c] = (uint8_t)std::min<uint32_t>(ends[st] + (a.key_of[c] >= 0 ? 1u : 0u), 255u);
+            nest = std::max<uint32_t>(nest, ends[c]);
+          }
+      }
+      if (nest > 4 && getenv("AHA_DEBUG")) fprintf(stderr, "aha: no prefix filter: %u keys nested on one trie path\n", nest);
+      if (minlen >= 3 && nest <= 4) {
         const uint32_t D = std::min(4u, minlen);
         // the smallest filter (2^10 .. 2^kFilterLog2 words) that stays under 1/256 full (false candidates: about the square of
         // the fill; the filter's size does not show in kf_filter's time, its false candidates show in kf_walk's), or the largest
         // while it is no more than a quarter full
+        const char *fd = getenv("AHA_FILTER_FILL");  // (lab: the fill the size search stops at, as a denominator)
+        const uint64_t fill_den = fd && atoi(fd) >= 4 ? (uint64_t)atoi(fd) : 256;
         for (uint32_t lg = 10; lg <= kFilterLog2; lg++) {
           ac->pf_bloom.assign((size_t)1 << lg, 0u);
           for (uint32_t k = 0; k < ac->aut.n_keys; k++) {
@@ -929,7 +953,7 @@ int32_t aha_ac_compile(const uint8_t *key_bytes, const uint64_t *key_offsets, ui
           }
           uint64_t bits = 0;
           for (uint32_t x : ac->pf_bloom) bits += (uint64_t)__builtin_popcount(x);
-          if (bits * (lg < kFilterLog2 ? 256 : 4) <= ((uint64_t)32 << lg)) {
+          if (bits * (lg < kFilterLog2 ? fill_den : 4) <= ((uint64_t)32 << lg)) {
             ac->pf_d = D;
             ac->pf_log2 = lg;
             break;
@@ -1532,9 +1556,11 @@ static int32_t device_impl_inner(aha_ac *ac, Scratch *sc, const uint8_t *d_corpu
     // .. 64 calls before it tries again: a batch that is handed back has paid for the filter and part of the walks
     const int pm = M.chars ? 1 : 0;  // (calls with char offsets come back for another reason -- text that is not ASCII -- and keep
                                      // their own count)
-    if (ac->pf_ok && ac->pf_skip[pm].load(std::memory_order_relaxed) > 0) {
-      ac->pf_skip[pm].fetch_sub(1, std::memory_order_relaxed);
-      M.no_filter = 1;
+    if (ac->pf_ok) {  // (calls on one handle may run side by side: the count goes down by compare-exchange, never below 0)
+      uint32_t v = ac->pf_skip[pm].load(std::memory_order_relaxed);
+      while (v && !ac->pf_skip[pm].compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) {
+      }
+      if (v) M.no_filter = 1;
     }
     const bool tried = ac->pf_ok && !M.no_filter;
     rc = match_v2(ac, sc, M, s, n_hits, kRegions);

@@ -126,6 +126,9 @@ struct V2Args {
   aha_hit *out;
   uint64_t cap;
   uint64_t *doc_hit_off;
+  // region pipelines: where the call's last kernel -- the per-document offsets -- leaves the five words the host reads
+  // (cursor[0..1], totals[0..2]: k_publish_words as a launch of its own costs ~5 us of a 64 MiB call); null: nobody publishes
+  unsigned long long *publish;
 };
 
 // ---- character-level engine (scan_unit.hip, unit.hpp) ---------------------------

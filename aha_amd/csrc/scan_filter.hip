@@ -98,7 +98,7 @@ __global__ __launch_bounds__(1024) void kf_filter(FilterDev F, const uint8_t *__
       if (!D4) w &= dmask;
       const uint32_t h = w * kFilterMul;
       const uint32_t word = bl[h >> hs];
-      bits |= ((word >> (h >> (hs - 5u))) & (word >> (h >> (hs - 10u))) & 1u) << k;  // (a shift takes its count's low 5 bits)
+      bits |= ((word >> ((h >> (hs - 5u)) & 31u)) & (word >> ((h >> (hs - 10u)) & 31u)) & 1u) << k;  // (the masks fold into the shifts)
     }
     bitmap[p] = (uint16_t)bits;
     seen |= d[0] | d[1] | d[2] | d[3];
@@ -138,6 +138,9 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
                                                              const KfChunk *__restrict__ chunk_rec,
                                                              const unsigned long long *non_ascii) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // the doc offsets are not what the call says (k_check_docs ran in front): index nothing -- and say nothing: every store to
+  // cursor[1] below is a plain one, and the verdict must reach the host (block-uniform, like the hand-back under it)
+  if (M.cursor[1] >= 16ull) return;
   // a call with char offsets came here as a call with byte offsets: the same thing while the batch is plain ASCII (kf_filter
   // has looked at every byte); if it is not, the call goes to the engines that count characters
   if (non_ascii && *non_ascii) {
@@ -158,7 +161,9 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
     for (uint32_t i = threadIdx.x; i < A.n_slots; i += 1024) lslots[i] = gslots[i];
     __syncthreads();
   }
-  if (M.cursor[1] >= 16ull) return;  // the doc offsets are not what the call says (k_check_docs ran in front)
+  // (cursor[1] holds 2 or 3 at most from here on: "repeat with larger regions" / "not this engine's batch", written with plain
+  // stores by whichever waves find out -- either value makes capi.cpp repeat the call, and 3 wins there when both were
+  // written, whatever their order)
   const int64_t N = (int64_t)M.n_bytes;
   const uint64_t D = M.n_docs;
   const int warm = A.max_len > 1 ? (int)min(A.max_len - 1u, (uint32_t)(kfWarm - 1)) : 0;
@@ -218,16 +223,22 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
         }
       }
     }
+    // (list[] and bnd[] go from lane to lane through LDS inside one wave: the stores must be out before another lane reads)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const uint32_t nb = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bv < e + kfAhead));
     const uint32_t n_in = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bv < e));  // documents that start inside the chunk
     const bool many = nb >= 64u;
     if ((uint32_t)lane < nb) bnd[lane] = (uint32_t)(bv - g0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     uint32_t before_doc = 0;  // lane i < n_in: events of the chunk that end at or before the first byte of document dn + i
     if (many) {  // their events-before counts start at 0
       for (uint64_t d = dn + (uint64_t)lane; d <= D && (int64_t)M.doc_off[d] < e; d += 64) M.doc_ev_rank[d] = 0;
     }
     uint32_t carry = 0;  // furthest offset (exclusive) an earlier start's walk is alive at
     uint32_t seq = 0;    // events of the chunk so far (wave-uniform)
+    uint32_t hsum = 0;   // hits of this lane's events
     uint2 *reg = M.evd + chunk * (uint64_t)M.ev_stride;
     bool give_up = false;
     // (the text of a batch's candidates, 16 bytes each straight from memory -- they are too few to stage the chunk for
@@ -327,7 +338,12 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
 #pragma unroll
       for (int k = 0; k < kfMaxEnds; k++)
         if (val[k]) {
-          if (at < M.ev_stride) reg[at] = make_uint2(eb[k], (uint32_t)((int32_t)ej[k] - ds));  // {END state, end offset in the document}
+          // {key id or offset of its flattened chain | chain length << 24, end offset in the document}: what k2d_count makes of
+          // {END state, ..} -- one gather per event here saves its launch (4.4 us + the gap of a 64 MiB call) and its pass
+          uint32_t x = A.end_info[eb[k]], cnt = x >> 24;
+          if (cnt == 255u) cnt = A.key_cnt[A.chain ? A.chain[x & 0xFFFFFFu].y : (x & 0xFFFFFFu)];
+          hsum += cnt;
+          if (at < M.ev_stride) reg[at] = make_uint2(x, (uint32_t)((int32_t)ej[k] - ds));
           at++;
         }
       // documents that start inside the chunk: the events that end at or before their first byte
@@ -352,8 +368,10 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
     }
     if (give_up) break;
     if (!many && (uint32_t)lane < n_in) M.doc_ev_rank[dn + (uint64_t)lane] = before_doc;
+    hsum = wave_last(wave_incl_scan(hsum));
     if (lane == 0) {
       M.ev_cnt[chunk] = seq;
+      M.chunk_hits[chunk] = hsum;
       if (seq > M.ev_stride) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
     }
   }

@@ -667,6 +667,8 @@ __global__ __launch_bounds__(256) void ku_chunk_adj(V2Args M) {
 // doc_hit_off[d] = hits before the document's first event: the chunk's hit base + the hits of the chunk before the
 // document start, which the traversal noted at the boundary
 __global__ __launch_bounds__(256) void ku_doc_offsets(V2Args M) {
+  // (the call's last kernel: every word the host reads is final -- this kernel changes none of them)
+  if (M.publish && blockIdx.x == 0 && threadIdx.x < 5) M.publish[threadIdx.x] = M.cursor[threadIdx.x];
   if (M.cursor[1] || !M.doc_hit_off) return;
   const uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (d > M.n_docs) return;

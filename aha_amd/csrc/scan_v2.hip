@@ -939,6 +939,8 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
 // chunk); LANES = 1: a thread per document, for batches of many small documents (few events before each).
 template <int LANES>
 __global__ __launch_bounds__(256) void k2d_doc_offsets(DevAut A, V2Args M) {
+  // (the call's last kernel: every word the host reads is final -- this kernel changes none of them)
+  if (M.publish && blockIdx.x == 0 && threadIdx.x < 5) M.publish[threadIdx.x] = M.cursor[threadIdx.x];
   if (M.cursor[1] || !M.doc_hit_off) return;
   const uint64_t d = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / LANES;
   const uint32_t j = threadIdx.x & (uint32_t)(LANES - 1);

@@ -552,10 +552,12 @@ def test_prefix_filter_engine_edges(engine, monkeypatch, chunk):
     # a batch shorter than the filter's window, an empty one, one of exactly a key
     for t in (b"", b"ab", b"abc", b"zabcd", long):
         run(keys, t, None, None)
-    # five keys end on one walk: more than a lane keeps -- the call comes back and the byte-level engine answers it
+    # six keys nested on one trie path: more END steps than a walk keeps -- compile looks at the deepest nesting and builds no
+    # filter for such a key set (round 5 found out in kf_walk, after the filter had run, call after call)
     nest = [b"abc", b"abcd", b"abcde", b"abcdef", b"abcdefg", b"abcdefgh"]
     t = (b"-" * 50 + b"abcdefgh") * 200
     assert run(nest, t, None, 2) == 6 * 200
+    assert AC.compile(nest, host_only=True).info["filter_prefix_bytes"] == 0
     # ... four still fit
     assert run(nest[:4], t, None, 5) == 4 * 200
 
@@ -1331,6 +1333,31 @@ def test_device_entry_validates_its_offsets():
             ac.match_batch_device(big, torch.tensor(bad, dtype=torch.int64).cuda(), out2)
         assert e.value.code == N.AHA_E_INVALID
     assert ac.match_batch_device(big, good, out2) == 1 << 19
+
+
+def test_bad_offsets_reach_the_host_through_the_prefix_filter_engines_hand_back(engine):
+    """A char-offset call over text that is not plain ASCII is handed back by kf_walk with a plain store to the same word that
+    holds k_check_docs' verdict: the verdict must win -- the call is refused with AHA_E_INVALID instead of being repeated on the
+    byte-level engine with offsets nobody validated (round-5 advice; src/aha/matcher.cr:34-39 is the overload)."""
+    if engine not in ("f", "auto"):
+        pytest.skip("the prefix-filter engine's hand-back")
+    import torch
+
+    ac = AC.compile(["abcd", "wxyz"])
+    assert ac.info["filter_prefix_bytes"] == 4
+    text = ("é" * 50 + "abcd wxyz ").encode() * 40
+    t = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).cuda()
+    n = t.numel()
+    out = torch.zeros((4096, 3), dtype=torch.int32, device="cuda")
+    good = torch.tensor([0, n // 2, n], dtype=torch.int64).cuda()
+    want = ac.match_batch_device(t, good, out, chars=True)
+    assert want == 80
+    for bad in ([1, n // 2, n], [0, n // 2, n - 1], [0, n, n // 2, n], [0, n // 2, n + 44], [0, 1 << 40, n]):
+        for chars in (True, False):
+            with pytest.raises(AhaError) as e:
+                ac.match_batch_device(t, torch.tensor(bad, dtype=torch.int64).cuda(), out, chars=chars)
+            assert e.value.code == N.AHA_E_INVALID
+        assert ac.match_batch_device(t, good, out, chars=True) == want
 
 
 def test_sequence_longer_than_int32_is_rejected():

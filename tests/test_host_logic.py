@@ -410,6 +410,11 @@ def test_prefix_filter_is_built_for_keyword_lists_only():
     assert AC.compile(["abc", "alpha"], host_only=True).info["filter_prefix_bytes"] == 3      # min(4, shortest key)
     assert AC.compile(["ab", "alpha"], host_only=True).info["filter_prefix_bytes"] == 0       # a key of two bytes: no filter
     assert AC.compile(["x" * 65, "alpha"], host_only=True).info["filter_prefix_bytes"] == 0   # ... of more than 64
+    # keys nested in one another: a walk of kf_walk keeps four END steps -- a key set with five keys on one trie path gets no filter
+    nest = ["abc", "abcd", "abcde", "abcdef", "abcdefg"]
+    assert AC.compile(nest[:4] + ["wxyz"], host_only=True).info["filter_prefix_bytes"] == 3
+    assert AC.compile(nest, host_only=True).info["filter_prefix_bytes"] == 0
+    assert AC.compile(["abc", "abcd", "xabcde", "abcdef", "abcdefg", "zzz"], host_only=True).info["filter_prefix_bytes"] == 3  # (four on the path)
     cjk = AC.compile(["中国人", "我是中"], host_only=True).info                                # a character-level image instead
     assert cjk["unit_enabled"] == 1 and cjk["filter_prefix_bytes"] == 0
     rng = random.Random(3)

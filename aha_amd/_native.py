@@ -32,7 +32,7 @@ AHA_OPT_FORCE_WIDE = 2
 AHA_IMG_SLOTS, AHA_IMG_END_KEY, AHA_IMG_KEY_LN, AHA_IMG_KEY_CNT, AHA_IMG_KEY_KC = 0, 1, 2, 3, 4
 AHA_IMG_STALE_ENDS = 5
 AHA_IMG_UNIT_SLOTS, AHA_IMG_UNIT_ROOT, AHA_IMG_UNIT_END_KEY, AHA_IMG_UNIT_TABLES = 6, 7, 8, 9
-AHA_IMG_UNIT_MARKS = 10
+AHA_IMG_UNIT_MARKS, AHA_IMG_UNIT_PAIRS, AHA_IMG_UNIT_PAIR_DISP = 10, 11, 12
 
 
 class aha_options(C.Structure):
@@ -55,7 +55,9 @@ class aha_ac_info_t(C.Structure):
                 ("unit_big_block", C.c_uint32), ("unit_n_low", C.c_uint32), ("unit_n_big", C.c_uint32),
                 ("unit_base_bits", C.c_uint32), ("unit_headers", C.c_uint32),
                 ("filter_prefix_bytes", C.c_uint32), ("filter_words", C.c_uint32),
-                ("skip_filter_words", C.c_uint32), ("skip_pairs", C.c_uint32)]
+                ("skip_filter_words", C.c_uint32), ("skip_pairs", C.c_uint32),
+                ("pair_hash_k1", C.c_uint32), ("pair_table_log2", C.c_uint32), ("pair_groups", C.c_uint32),
+                ("pair_engine", C.c_uint32)]
 
 
 class aha_timing(C.Structure):

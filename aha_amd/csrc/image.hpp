@@ -52,6 +52,7 @@ struct MatchArgs {
   uint32_t sep_block[8];     // bit c set <=> (c < sep.size && !sep[c])
   int32_t has_nul;           // match_longest, chunked form: the batch holds NUL bytes (the warm-ups look for them)
   int32_t no_filter;         // host side: this call has been handed back by the prefix-filter engine (scan_filter.hip)
+  int32_t no_pair;           // ... by the pair engine (scan_pair.hip)
   int32_t check_docs;        // host side: the device-resident doc offsets have not been validated yet -- the single-traversal
                              // pipelines do it on the device, in front of the traversal, without a round trip to the host
   // scratch
@@ -159,6 +160,7 @@ void v2_launch_lead_scan(const V2Args &M, void *stream);  // lead_cnt -> lead_ba
 struct SkipDev {
   const uint32_t *bloom;  // [1 << log2] blocked Bloom filter over the two-unit paths, keyed by raw bytes
   uint32_t log2;
+  uint32_t k1;            // the second unit's multiplier of the pair hash (UnitImage::pair_k1)
 };
 int skip_prepare(uint32_t n_syms, uint32_t log2_words);  // raises the dynamic-LDS limits; hipError_t as int
 size_t skip_bitmap_bytes(uint64_t n_bytes);             // scratch of a call: one bit per byte position, padded
@@ -166,6 +168,23 @@ size_t skip_bitmap_bytes(uint64_t n_bytes);             // scratch of a call: on
 // chunk_hits, doc_*_rank), started only at marked positions.
 void skip_launch_mark(const SkipDev &K, const V2Args &M, void *bitmap, uint32_t grid, void *stream);
 void skip_launch_traverse(const UnitDev &U, const V2Args &M, const void *bitmap, uint32_t grid, void *stream);
+
+// ---- pair engine (scan_pair.hip; unit.hpp, PAIR TABLE)
+struct PairDev {
+  const uint32_t *bloom;   // the marks' filter
+  const uint4 *tab;        // [1 << log2] {raw0 | hits << 24, raw1, event payload (0: none), child filter}
+  const uint8_t *disp;     // [groups]
+  uint32_t bloom_log2, k1, log2, groups;
+};
+
+int pair_prepare(uint32_t n_syms, uint32_t bloom_log2, uint32_t groups);  // raises the dynamic-LDS limits; hipError_t as int
+uint32_t pair_tile_bytes();                 // a tile of kp_pairs = a chunk of the event regions (V2Args.S)
+size_t pair_cand_bytes(uint64_t cap);       // scratch: the deep candidates' list and what kp_walk finds for each
+size_t pair_walk_bytes(uint64_t cap);
+// tile_dn: n_chunks words; V2Args.lead_cnt / chunk_doc0 (free with byte offsets): a tile's first candidate and their number;
+// cursor[7]: the list's length.  mid_event (nullable): recorded behind kp_pairs.
+void pair_launch(const PairDev &P, const UnitDev &U, const DevAut &A, const V2Args &M, void *tile_dn, void *cand, void *wres,
+                 uint64_t cand_cap, uint32_t grid, void *mid_event, void *stream);
 
 // ---- prefix-filter engine (scan_filter.hip): byte-level, for batches where few positions can start a key
 constexpr uint32_t kFilterMul = 0x9E3779B1u;  // an entry of the filter: scan_filter.hip kf_filter, capi.cpp filter_entry

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kV2Threads) void ks_mark(SkipDev K, V2Args M, unsig
       const uint32_t cm = e & 0xFFFF00u;
       const uint32_t s = (x & cm) == (cm & 0x808080u) ? (e & 0xFFu) : 8u;
       const uint32_t c = __builtin_amdgcn_ubfe(x, 0u, s);
-      uint32_t h = __umul24(c, kSkipKA) + gp;
+      uint32_t h = __umul24(c, K.k1) + gp;
       const uint32_t g = __umul24(c, kSkipKB);
       gp = __builtin_amdgcn_alignbit(g, g, 11);
       h ^= h >> 16;

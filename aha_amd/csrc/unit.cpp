@@ -184,21 +184,106 @@ static void build_unit_bits(const Automaton &a, UnitImage &u, bool force, uint32
   std::vector<uint8_t> udepth(S, 0);
   for (uint32_t s : ustates)
     for (uint32_t t = first[s]; t < first[s + 1]; t++) udepth[tr[t].child] = (uint8_t)std::min<uint32_t>(udepth[s] + 1u, 255u);
-  // ---- MARKS (unit.hpp): the two-unit paths in a blocked Bloom filter keyed by raw bytes -- the smallest of 2^10 .. 2^14
-  // words that stays under 1/16 full, else the largest
+  // ---- MARKS and PAIR TABLE (unit.hpp): the two-unit paths keyed by raw bytes -- a blocked Bloom filter (the smallest of
+  // 2^10 .. 2^14 words that stays under 1/16 full, else the largest) and a perfect hash table behind it
   for (uint32_t s : ustates)
     if (udepth[s] == 1 && a.key_of[s] >= 0) u.unit_key = true;
+  {  // END states of three units or more along one trie path (BFS order: parents first)
+    std::vector<uint8_t> de(S, 0);
+    for (uint32_t s : ustates)
+      for (uint32_t t = first[s]; t < first[s + 1]; t++) {
+        const uint32_t c = tr[t].child;
+        de[c] = (uint8_t)std::min<uint32_t>(de[s] + ((udepth[c] >= 3 && a.key_of[c] >= 0) ? 1u : 0u), 255u);
+        u.deep_ends_max = std::max<uint32_t>(u.deep_ends_max, de[c]);
+      }
+  }
   if (!u.unit_key) {
-    for (uint32_t t0 = first[0]; t0 < first[1]; t0++) u.n_pairs += first[tr[t0].child + 1] - first[tr[t0].child];
-    for (uint32_t lg = kSkipMinLog2; u.n_pairs && lg <= kSkipMaxLog2; lg++) {
-      u.mark_bloom.assign((size_t)1 << lg, 0u);
-      for (uint32_t t0 = first[0]; t0 < first[1]; t0++) {
-        const uint32_t part = sk_part(tr[t0].raw), c0 = tr[t0].child;
-        for (uint32_t t1 = first[c0]; t1 < first[c0 + 1]; t1++) {
-          const uint32_t h = sk_hash(part, tr[t1].raw);
-          u.mark_bloom[sk_word(h, lg)] |= sk_mask(h);
+    struct Pair {
+      uint32_t raw0, raw1, child, h;
+    };
+    std::vector<Pair> pairs;
+    for (uint32_t t0 = first[0]; t0 < first[1]; t0++) {
+      const uint32_t c0 = tr[t0].child;
+      for (uint32_t t1 = first[c0]; t1 < first[c0 + 1]; t1++) pairs.push_back({tr[t0].raw, tr[t1].raw, tr[t1].child, 0u});
+    }
+    u.n_pairs = (uint32_t)pairs.size();
+    // the second unit's multiplier: no two pairs may share the 32-bit hash (they would share every slot of the table)
+    static const uint32_t k1s[] = {kSkipKA, 0xC2B2AFu, 0x27D4EBu, 0x165667u, 0xD3A264u, 0xFD7047u, 0xB55A4Fu, 0x7FEB35u};
+    bool placed = false;
+    for (uint32_t k1 : k1s) {
+      if (pairs.empty() || pairs.size() > (size_t)kPairMaxGroups * 8) break;
+      for (Pair &p : pairs) p.h = sk_hash(sk_part(p.raw0), p.raw1, k1);
+      std::vector<uint32_t> sorted(pairs.size());
+      for (size_t i = 0; i < pairs.size(); i++) sorted[i] = pairs[i].h;
+      std::sort(sorted.begin(), sorted.end());
+      if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) continue;
+      uint32_t G = 256;
+      while (G < kPairMaxGroups && G * 4u < pairs.size()) G <<= 1;
+      std::vector<std::vector<uint32_t>> groups(G);
+      for (uint32_t i = 0; i < pairs.size(); i++) groups[pt_group(pairs[i].h, G)].push_back(i);
+      std::vector<uint32_t> order(G);
+      for (uint32_t g = 0; g < G; g++) order[g] = g;
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return groups[x].size() > groups[y].size(); });
+      uint32_t lg = 8;
+      while (((size_t)1 << lg) * 2u < pairs.size() * 3u) lg++;  // load <= 2/3
+      for (; lg <= 21 && !placed; lg++) {
+        std::vector<uint32_t> tab((size_t)4 << lg, 0u);
+        std::vector<uint8_t> disp(G, 0);
+        bool okp = true;
+        std::vector<uint32_t> slots;
+        for (uint32_t gi = 0; okp && gi < G; gi++) {
+          const std::vector<uint32_t> &grp = groups[order[gi]];
+          if (grp.empty()) break;
+          uint32_t d = 0;
+          for (; d < 256; d++) {
+            slots.clear();
+            bool fits = true;
+            for (uint32_t i : grp) {
+              const uint32_t sl = pt_slot(pairs[i].h, d, lg);
+              if (tab[4 * (size_t)sl] != 0 || std::find(slots.begin(), slots.end(), sl) != slots.end()) {
+                fits = false;
+                break;
+              }
+              slots.push_back(sl);
+            }
+            if (fits) break;
+          }
+          if (d == 256) {
+            okp = false;
+            break;
+          }
+          disp[order[gi]] = (uint8_t)d;
+          for (size_t j = 0; j < grp.size(); j++) {
+            const Pair &p = pairs[grp[j]];
+            uint32_t cf = 0;
+            for (uint32_t t2 = first[p.child]; t2 < first[p.child + 1]; t2++) cf |= pt_cls(tr[t2].raw);
+            const int32_t key = a.key_of[p.child];
+            const uint32_t c4 = key >= 0 ? std::min<uint32_t>(a.key_cnt[key], kUMaxC4) : 0u;
+            uint32_t *e = &tab[4 * (size_t)slots[j]];
+            e[0] = p.raw0 | c4 << 24;
+            e[1] = p.raw1;
+            e[2] = (uint32_t)key;
+            e[3] = cf;
+          }
+        }
+        if (okp) {
+          u.pair_tab.swap(tab);
+          u.pair_disp.swap(disp);
+          u.pair_log2 = lg;
+          u.pair_groups = G;
+          u.pair_k1 = k1;
+          placed = true;
         }
       }
+      if (placed) break;
+    }
+    if (!placed) {  // (the marks alone need no table: the first multiplier)
+      u.pair_k1 = kSkipKA;
+      for (Pair &p : pairs) p.h = sk_hash(sk_part(p.raw0), p.raw1, u.pair_k1);
+    }
+    for (uint32_t lg = kSkipMinLog2; !pairs.empty() && lg <= kSkipMaxLog2; lg++) {
+      u.mark_bloom.assign((size_t)1 << lg, 0u);
+      for (const Pair &p : pairs) u.mark_bloom[sk_word(p.h, lg)] |= sk_mask(p.h);
       uint64_t bits = 0;
       for (uint32_t x : u.mark_bloom) bits += (uint64_t)__builtin_popcount(x);
       u.mark_log2 = lg;

@@ -122,7 +122,7 @@ AHA_HD inline bool u_hdr_pending(uint32_t lo) { return ((lo >> 29) & 3u) == 1u; 
 // stateless kernel marks those positions: every unit start p whose units at p and behind it pass a blocked Bloom filter over
 // the image's two-unit paths, keyed by the units' RAW bytes (a unit = its one to three bytes as a little-endian integer;
 // no symbol decode).  False marks cost the walk a trip, a missing one would lose hits: the filter has no false negatives.
-constexpr uint32_t kSkipKA = 0x9E3779u, kSkipKB = 0x85EBCBu;
+constexpr uint32_t kSkipKA = 0x9E3779u, kSkipKB = 0x85EBCBu;  // (kSkipKA: the default of UnitImage::pair_k1)
 constexpr uint32_t kSkipMinLog2 = 10, kSkipMaxLog2 = 14;  // 4 .. 64 KiB of LDS beside ks_mark's input rows
 // low 32 bits of the product of the operands' low 24 bits (v_mul_u32_u24 on the device)
 AHA_HD inline uint32_t sk_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
@@ -130,12 +130,33 @@ AHA_HD inline uint32_t sk_part(uint32_t c0) {  // the first unit's share of the 
   const uint32_t g = sk_mul24(c0, kSkipKB);
   return (g >> 11) | (g << 21);
 }
-AHA_HD inline uint32_t sk_hash(uint32_t part, uint32_t c1) {
-  const uint32_t h = sk_mul24(c1, kSkipKA) + part;
+AHA_HD inline uint32_t sk_hash(uint32_t part, uint32_t c1, uint32_t k1 = kSkipKA) {
+  const uint32_t h = sk_mul24(c1, k1) + part;
   return h ^ (h >> 16);
 }
 AHA_HD inline uint32_t sk_word(uint32_t h, uint32_t log2_words) { return h >> (32u - log2_words); }
 AHA_HD inline uint32_t sk_mask(uint32_t h) { return (1u << (h & 31u)) | (1u << ((h >> 5) & 31u)); }
+
+// PAIR TABLE (scan_pair.hip, the pair engine).  The two-unit paths once more, as a perfect hash table keyed by the units' raw
+// bytes: what a stateless pass needs to turn "these two units pass the filter" into "this is the two-unit state X" with ONE
+// 16-byte load -- {raw0 | hits of an event there << 24, raw1, event payload (0: the state ends no key), child filter}.  The
+// slot of a pair: its hash (sk_hash with pair_k1, chosen so that no two pairs share the 32-bit value) picks a group, the
+// group's displacement byte (LDS) the slot (hash-displace: groups in descending size, each displaced by the first byte that
+// puts all its keys on free slots).  child filter: bit pt_cls(raw2) for every transition of the two-unit state -- a third
+// unit whose bit is clear cannot continue it (no probe), one whose bit is set makes the position a DEEP CANDIDATE.
+constexpr uint32_t kPairMix = 0x2545F491u, kPairKC = 0xC2B2AFu;
+constexpr uint32_t kPairMaxGroups = 16384;  // displacement bytes in LDS
+constexpr uint32_t kPairMaxDeepEnds = 3;    // END states of three units or more on one trie path that the pair engine has room for
+AHA_HD inline uint32_t pt_group(uint32_t h, uint32_t n_groups) { return (h >> 7) & (n_groups - 1u); }
+AHA_HD inline uint32_t pt_slot(uint32_t h, uint32_t d, uint32_t log2_slots) {
+  const uint32_t t = h * kPairMix;
+  return ((t >> (32u - log2_slots)) + d * ((t << 1) | 1u)) & ((1u << log2_slots) - 1u);
+}
+// child filter: two of 32 bits per third unit (a two-unit state with n transitions lets ~(2n / 32)^2 of the other units through)
+AHA_HD inline uint32_t pt_cls(uint32_t raw) {
+  const uint32_t g = sk_mul24(raw, kPairKC);
+  return (1u << (g >> 27)) | (1u << ((g >> 22) & 31u));
+}
 
 struct UnitImage {
   bool ok = false;
@@ -160,6 +181,13 @@ struct UnitImage {
   uint32_t n_pairs = 0;              // two-unit paths
   uint32_t mark_fill_permille = 0;   // set bits of the filter, per 1000
   bool unit_key = false;             // a key of one unit: every position could report -- no skipping
+  uint32_t pair_k1 = kSkipKA;        // the second unit's multiplier in sk_hash (marks and pair table use the same hash)
+  // PAIR TABLE (empty: no marks, a displacement that does not fit a byte, more pairs than the groups serve)
+  std::vector<uint32_t> pair_tab;    // [4 << pair_log2]: {raw0 | c4 << 24, raw1, key id of the END state or ~0 (capi.cpp turns it into
+                                     // the event payload), child filter}; a free slot is all zero (no unit is 0)
+  std::vector<uint8_t> pair_disp;    // [pair_groups]
+  uint32_t pair_log2 = 0, pair_groups = 0;
+  uint32_t deep_ends_max = 0;        // most END states of three units or more on one trie path
 };
 
 // a: the byte-level automaton (build_automaton).  Fills u; u.ok = false + u.why when the key set is not eligible or

@@ -82,6 +82,10 @@ lib LibAhaHip
     filter_words : UInt32       # ABI 7: 32-bit words of its Bloom filter
     skip_filter_words : UInt32  # ABI 8: words of the mark filter of the skip-ahead traversal (engine 6; 0: none)
     skip_pairs : UInt32         # ABI 8: two-character trie paths it holds
+    pair_hash_k1 : UInt32       # ABI 8: multiplier of the second character in the pair hash
+    pair_table_log2 : UInt32    # ABI 8: log2 of the pair table's 16-byte slots (0: none)
+    pair_groups : UInt32        # ABI 8: its displacement bytes
+    pair_engine : UInt32        # ABI 8: 1 = byte-offset matches run the pair engine (engine 7)
   end
 
   # aha_timing (ABI 6): filled when profiling is on

@@ -163,6 +163,19 @@ typedef struct {
    * BASELINE config 3 it is slower than engine 4 (its lanes' scattered text requests), so no key set gets it by default. */
   uint32_t skip_filter_words;
   uint32_t skip_pairs;
+  /* ABI 8: the pair engine (aha_amd/csrc/scan_pair.hip; aha_timing.engine = 7).  The same two-character paths behind the same
+   * filter, once more as a perfect hash table keyed by the characters' raw bytes (pair_table_log2: log2 of its 16-byte slots, 0 =
+   * none; pair_groups displacement bytes; pair_hash_k1 the multiplier of the second character in the pair hash -- chosen so that
+   * no two pairs share the 32-bit value; marks and table use the same hash).  A stateless pass over every character resolves
+   * the two-character states itself -- one 16-byte load per filter-positive pair -- and writes their events in position order;
+   * only the positions where a THIRD character can continue a path (a few per cent) are walked, by a second kernel that voids
+   * the events its walks cover and fills its own into slots the first pass left for them.  pair_engine = 1: this handle's
+   * matches with byte offsets and without a separator filter run it (no one-character key, at most three END states of three
+   * characters or more on one trie path); every other call keeps the engine it had. */
+  uint32_t pair_hash_k1;
+  uint32_t pair_table_log2;
+  uint32_t pair_groups;
+  uint32_t pair_engine;
 } aha_ac_info_t;
 
 /* Timing of the most recent device match on this handle (HIP events recorded
@@ -179,7 +192,8 @@ typedef struct {
   float ms_aux;             /* engine 2: hits per chunk + scan (regions) or event sort (slabs); engine 1: char-offset prefix pass */
   uint64_t n_chunks;
   uint64_t n_hits;
-  uint32_t engine;          /* 6 = marks + skip-ahead character-level traversal, 5 = prefix filter + candidate walks,
+  uint32_t engine;          /* 7 = pair engine (stateless pair pass + deep walks), 6 = marks + skip-ahead character-level traversal,
+                             * 5 = prefix filter + candidate walks,
                              * 4 = character-level traversal, 2 = single-traversal engine, 1 = two-pass engine */
   uint32_t chunk_bytes;     /* bytes per lane chunk */
   /* ABI 6: passes over the batch that were thrown away before this one: 1 when a chunk's event region overflowed -- the
@@ -318,6 +332,8 @@ enum {
   AHA_IMG_UNIT_END_KEY = 8,   /* int32[unit_slots]: key id at the base of an END state, else -1 */
   AHA_IMG_UNIT_TABLES = 9,    /* uint32[2816]: the decode tables (unit.hpp, SYMBOLS) */
   AHA_IMG_UNIT_MARKS = 10,    /* uint32[skip_filter_words]: the Bloom filter over the two-character paths (unit.hpp, MARKS) */
+  AHA_IMG_UNIT_PAIRS = 11,    /* uint32[4 << pair_table_log2]: the pair table {raw0 | hits << 24, raw1, event payload, child filter} */
+  AHA_IMG_UNIT_PAIR_DISP = 12, /* uint8[pair_groups]: its displacement bytes (unit.hpp, PAIR TABLE) */
   AHA_IMG_STALE_ENDS = 5     /* {uint32 key id, uint32 prefix length}[]: the states (a prefix of a key each) whose node in
                                  the reference's Cedar keeps a stale END flag (src/aha/cedar.cr:642-648); match_longest
                                  treats them as ends that yield nothing (src/aha/ac.cr:126-128, 249-263) */

@@ -21,6 +21,11 @@ int skip_prepare(uint32_t, uint32_t) { return 0; }
 size_t skip_bitmap_bytes(uint64_t) { return 0; }
 void skip_launch_mark(const SkipDev &, const V2Args &, void *, uint32_t, void *) { no_gpu("skip_launch_mark"); }
 void skip_launch_traverse(const UnitDev &, const V2Args &, const void *, uint32_t, void *) { no_gpu("skip_launch_traverse"); }
+int pair_prepare(uint32_t, uint32_t, uint32_t) { return 0; }
+uint32_t pair_tile_bytes() { return 2048; }
+size_t pair_cand_bytes(uint64_t) { return 0; }
+size_t pair_walk_bytes(uint64_t) { return 0; }
+void pair_launch(const PairDev &, const UnitDev &, const DevAut &, const V2Args &, void *, void *, void *, uint64_t, uint32_t, void *, void *) { no_gpu("pair_launch"); }
 int v2_prepare(bool, size_t) { return 0; }
 void v2_launch_traverse(const DevAut &, const V2Args &, uint32_t, void *) { no_gpu("v2_launch_traverse"); }
 void v2_launch_chunk_scan(const V2Args &, void *) { no_gpu("v2_launch_chunk_scan"); }

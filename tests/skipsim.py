@@ -23,8 +23,8 @@ def sk_part(c0):
     return ((g >> 11) | (g << 21)) & M32
 
 
-def sk_hash(part, c1):
-    h = (mul24(c1, KA) + part) & M32
+def sk_hash(part, c1, k1=KA):
+    h = (mul24(c1, k1) + part) & M32
     return h ^ (h >> 16)
 
 
@@ -37,6 +37,7 @@ class SkipSim(UnitSim):
         self.log2 = int(self.bloom.size).bit_length() - 1
         assert self.bloom.size == info["skip_filter_words"] == 1 << self.log2
         assert self.bb == 22
+        self.k1 = info["pair_hash_k1"] or KA
         self.warm = max(int(info["max_key_len"]) - 1, 0)
 
     # ---- ks_mark: one bit per byte position
@@ -56,7 +57,7 @@ class SkipSim(UnitSim):
                 if (x & cm) != (cm & 0x808080):  # a lead byte without its continuation bytes: a one-byte unit
                     s = 1
                 c = x & ((1 << (8 * s)) - 1)
-                h = sk_hash(gp, c)
+                h = sk_hash(gp, c, self.k1)
                 gp = sk_part(c)
                 w = int(self.bloom[h >> (32 - self.log2)])
                 m = (1 << (h & 31)) | (1 << ((h >> 5) & 31))

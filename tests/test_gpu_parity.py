@@ -17,7 +17,7 @@ from test_oracle_vs_model import as_list, rand_keys
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u23", "uh", "k", "f", "auto"], autouse=True)
+@pytest.fixture(params=["v2", "v1", "v2p", "u", "ur", "u23", "uh", "k", "p", "f", "auto"], autouse=True)
 def engine(request, monkeypatch):
     """Every parity test runs on the single-traversal engine (scan_v2.hip, byte level), on the two-pass engine
     (kernels.hip: the fallback for tiny capacities and very long keys), on the single-traversal engine with its LDS
@@ -33,7 +33,9 @@ def engine(request, monkeypatch):
     AHA_ENGINE=filter -- the prefix-filter engine, scan_filter.hip, for every key set it takes: keys of 3 to 64 bytes, byte
     offsets, no separator filter -- what the library picks for such key sets when they get no character-level image; "k" --
     AHA_ENGINE=skip -- the skip-ahead traversal, scan_skip.hip: the unit image for every eligible key set like "u", its walk
-    started only at the marks of a first pass wherever no key is a single character, whatever the mark filter's fill).  "auto" sets
+    started only at the marks of a first pass wherever no key is a single character, whatever the mark filter's fill; "p" --
+    AHA_ENGINE=pair -- the pair engine, scan_pair.hip: the unit image likewise, byte-offset calls answered by the stateless pair
+    pass + deep walks wherever the key set admits it).  "auto" sets
     no variable: the library decides per key set, which is what a caller and bench.py get.  The variables are read when a
     handle is compiled."""
     only = os.environ.get("AHA_TEST_ENGINES")  # (development: run the suite on some variants only, e.g. AHA_TEST_ENGINES=f,auto)
@@ -42,7 +44,7 @@ def engine(request, monkeypatch):
     if request.param == "auto":
         monkeypatch.delenv("AHA_ENGINE", raising=False)
     else:
-        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u23": "unit", "uh": "unit", "f": "filter", "k": "skip"}.get(request.param, "v2"))
+        monkeypatch.setenv("AHA_ENGINE", {"v1": "v1", "u": "unit", "ur": "unit", "u23": "unit", "uh": "unit", "f": "filter", "k": "skip", "p": "pair"}.get(request.param, "v2"))
     if request.param in ("u", "uh"):
         monkeypatch.setenv("AHA_UNIT_HEADER_BESIDE", "1" if request.param == "uh" else "0")
     else:
@@ -363,6 +365,51 @@ def test_capacity_error_when_event_temp_overflows():
     assert gpu_list(out) == [(0, 1, 0), (0, 2, 1), (1, 2, 0), (1, 3, 1)]
 
 
+def test_config5_at_full_size(engine):
+    """BASELINE config 5 at its full size -- 1 M keys, 256 MiB of hit-dense text, ~950 M hits (11 GB of triples) -- on the
+    library's own choice of engine.  The oracle needs minutes for that, so the whole batch is checked through properties
+    computed on the device (every hit's length is its key's, ends ascend inside a document, the per-document offsets cut the
+    hit list where the documents change, their last entry is the count) and sampled documents from the front, the middle and
+    the end of the batch against the oracle (src/aha/ac.cr:176-192, 265-278)."""
+    if engine != "auto":
+        pytest.skip("once, on the library's own choice")
+    import torch
+
+    blob, offs, nf = synth.keys(5)
+    corpus, doc = synth.corpus(5, blob, offs, nf, n_bytes=1 << 28, doc_bytes=1 << 20)
+    g = AC.compile_packed(blob, offs)
+    g.set_profiling(True)
+    dc = torch.from_numpy(corpus).cuda()
+    dd = torch.from_numpy(doc.astype(np.int64)).cuda()
+    D = doc.size - 1
+    dho = torch.zeros(D + 1, dtype=torch.int64, device="cuda")
+    cap = 4 * corpus.size
+    out = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+    n = g.match_batch_device(dc, dd, out, dho)
+    assert g.last_timing()["engine"] == 4 and n > 3 * corpus.size
+    hits = out[:n]
+    klen = torch.from_numpy((offs[1:] - offs[:-1]).astype(np.int32)).cuda()
+    assert bool(((hits[:, 1] - hits[:, 0]) == klen[hits[:, 2].long()]).all())          # Hit(idx - len + 1, idx + 1, value)
+    assert int(dho[0]) == 0 and int(dho[D]) == n and bool((dho[1:] >= dho[:-1]).all())
+    # ends ascend inside a document: the only places where end[i + 1] < end[i] are document changes
+    drop = torch.nonzero(hits[1:, 1] < hits[:-1, 1]).flatten() + 1
+    cuts = torch.unique(dho[1:D])
+    assert bool(torch.isin(drop, cuts).all())
+    # every hit lies inside its document
+    doc_of_hit = torch.searchsorted(dho[1:].contiguous(), torch.arange(n, device="cuda", dtype=torch.int64), right=True)
+    dlen = (dd[1:] - dd[:-1])[doc_of_hit]
+    assert bool((hits[:, 0] >= 0).all()) and bool((hits[:, 1].long() <= dlen).all())
+    del doc_of_hit, dlen, drop
+    # sampled documents against the oracle
+    o = orc.AC.compile_packed(blob, offs)
+    h_dho = dho.cpu().numpy()
+    for d in (0, 1, D // 2, D - 2, D - 1):
+        a, e = int(doc[d]), int(doc[d + 1])
+        oh, _ = o.match_batch(corpus[a:e], np.array([0, e - a], dtype=np.uint64), cap=8 * (e - a))
+        got = hits[int(h_dho[d]):int(h_dho[d + 1])].cpu().numpy()
+        assert got.shape[0] == len(oh) and got.tobytes() == oh.tobytes(), d
+
+
 def test_a_repeated_pass_is_reported(engine):
     """A batch denser than the capacity said overflows a chunk's event region: the match runs once more with full-size
     regions, bit-exact -- and aha_timing.repeats tells the caller that the call cost two passes."""
@@ -487,7 +534,7 @@ def test_unaligned_device_corpus_keeps_the_fast_engine(engine):
             t0 = time.perf_counter()
             assert g.match_batch_device(view, dd, out) == n
             best = min(best, time.perf_counter() - t0)
-        assert g.last_timing()["engine"] == (4 if engine in ("u", "u23", "uh") else 5 if engine == "f" else 6 if engine == "k" else 2)
+        assert g.last_timing()["engine"] == (4 if engine in ("u", "u23", "uh") else 5 if engine == "f" else 6 if engine == "k" else 7 if engine == "p" else 2)
         res[shift] = (best, out[:n].cpu().numpy().tobytes())
     assert res[0][1] == res[1][1]
     assert res[0][0] / res[1][0] >= 0.7, (res[0][0], res[1][0])
@@ -566,11 +613,11 @@ def test_engine_selected(engine, monkeypatch):
     ac = AC.compile(["ab", "b"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"abab" * 100))[:3] == [(0, 2, 0), (1, 2, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5, 6) if engine in ("u", "ur", "u23", "uh", "k", "auto") else (2, 5) if engine == "f" else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5, 6, 7) if engine in ("u", "ur", "u23", "uh", "k", "p", "auto") else (2, 5) if engine == "f" else (2,))
     ac = AC.compile(["ab", "ba"])
     ac.set_profiling(True)
     assert gpu_list(ac.match_array(b"ab ba " * 60))[:3] == [(0, 2, 0), (3, 5, 1), (6, 8, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5, 6) if engine in ("u", "ur", "u23", "uh", "k", "auto") else (2, 5) if engine == "f" else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5, 6, 7) if engine in ("u", "ur", "u23", "uh", "k", "p", "auto") else (2, 5) if engine == "f" else (2,))
     if engine in ("u", "ur", "u23", "uh"):
         # the library's own choice (no AHA_ENGINE): keys of multi-byte characters get the character-level traversal for
         # byte- and char-offset batches, ASCII keys keep the byte-level one
@@ -613,7 +660,7 @@ def test_engine_selected(engine, monkeypatch):
         assert asc.last_timing()["engine"] == 5 and [tuple(h) for h in hits.tolist()] == [(5000, 5003, 0), (5001, 5004, 1)]
     # char offsets run on the character-level engine too, the separator filter on the byte-level engines only
     assert [tuple(h) for h in ac.match("abab")] == [(0, 2, 0), (1, 3, 1), (2, 4, 0)]
-    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5, 6) if engine in ("u", "ur", "u23", "uh", "k", "auto") else (2, 5) if engine == "f" else (2,))
+    assert ac.last_timing()["engine"] in ((1,) if engine == "v1" else (2, 4, 5, 6, 7) if engine in ("u", "ur", "u23", "uh", "k", "p", "auto") else (2, 5) if engine == "f" else (2,))
     sep = BitArray(256)
     sep[ord(" ")] = True
     assert [tuple(h) for h in ac.match("ab ba", sep)] == [(0, 2, 0), (3, 5, 1)]
@@ -1463,25 +1510,35 @@ def test_skip_engine_selection_and_edges(engine, monkeypatch):
     (pseudo jumps at the end of a lane's two words of marks), keys across the 124-byte limit of those words, across chunk ends
     and document boundaries, documents of a few bytes, empty documents, malformed UTF-8, NUL bytes, batches shorter than a
     piece of the marking pass and not a multiple of it."""
-    if engine != "k":
-        pytest.skip("the skip-ahead traversal's own cases (opt-in: AHA_ENGINE=skip)")
+    if engine not in ("k", "p"):
+        pytest.skip("the skip-ahead traversal's and the pair engine's own cases")
+    E = 6 if engine == "k" else 7
     rng = random.Random(11)
     keys = ["中国人", "ab", "abc", "bcab", "我是", "是中国", "国人民", "яж", "жя中"]
     g = AC.compile(keys)
     g.set_profiling(True)
     o = orc.AC.compile(keys)
     assert g.info["unit_enabled"] == 1 and g.info["skip_filter_words"] >= 1024 and g.info["skip_pairs"] == 8
+    assert g.info["pair_engine"] == (1 if engine == "p" else 0)
 
-    def check(text, doc, want_engine=6, **kw):
+    gave_up = [False]
+
+    def check(text, doc, want_engine=None, **kw):
+        want_engine = E if want_engine is None else want_engine
         t = np.frombuffer(text, dtype=np.uint8)
         d = np.asarray(doc, dtype=np.uint64)
         gh, gd = g.match_batch(t, d, **kw)
         oh, od = o.match_batch(t, d, cap=len(gh) + 16, **kw)
         assert len(gh) == len(oh) and np.array_equal(gd, od) and gh.tobytes() == oh.tobytes(), (text[:200], doc[:8])
         if len(text):
-            assert g.last_timing()["engine"] == want_engine
+            # (the pair engine gives a batch with documents of a few bytes -- two boundaries in one 32-byte piece -- to engine 4,
+            # and stops trying on a handle that made it give up three times)
+            ok = (want_engine, 4) if (engine == "p" and (len(doc) > 2 or gave_up[0])) else (want_engine,)
+            assert g.last_timing()["engine"] in ok
+            gave_up[0] = gave_up[0] or (engine == "p" and want_engine == 7 and g.last_timing()["engine"] == 4)
 
-    text = "我是中国人民 ab abc bcab яжя中 ".encode() * 50
+    # (a hit per ~8 bytes: the pair engine keeps up to 320 events per tile of 2 KiB, a denser batch is engine 4's)
+    text = "我是中国人民 -- ab 国々 abc ･･･ bcab 民民民 яжя中 ".encode() * 50
     check(text, [0, len(text)])
     check(text, [0, len(text)], want_engine=4, chars=True)  # char offsets: the walk that counts characters
     # sparse: marks hundreds of bytes apart, keys at every distance from the window and chunk ends
@@ -1507,7 +1564,7 @@ def test_skip_engine_selection_and_edges(engine, monkeypatch):
     # short batches: below a piece, one byte over a piece, empty
     for n in (0, 1, 2, 5, 63, 64, 65, 127, 129, 4095, 4097):
         t = ("ab中国人abc" * 500).encode()[:n]
-        check(t, [0, len(t)], want_engine=6 if n >= 64 else 4)
+        check(t, [0, len(t)], want_engine=E if n >= 64 else 4)
     # a key set with a one-character key keeps the plain character-level traversal
     uk = AC.compile(["中", "中国", "国人"])
     uk.set_profiling(True)

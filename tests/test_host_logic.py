@@ -384,7 +384,7 @@ def test_output_structs_respect_the_callers_size():
     L = N.lib()
     full = C.sizeof(N.aha_ac_info_t)
     abi5, abi6, abi7 = 80, 104, 112  # before unit_big_lo .. (ABI 6), the filter fields (ABI 7), the skip fields (ABI 8) were appended
-    assert full == 120
+    assert full == 136
     # a size the struct has had is honoured; anything else -- 0, garbage of a caller that never set the field -- gets the ABI-5 size
     for said, filled in ((full, full), (abi7, abi7), (abi6, abi6), (abi5, abi5), (0, abi5), (16, abi5),
                          (full - 4, abi5), (full + 64, abi5), (0xAAAAAAAA, abi5)):

@@ -18,7 +18,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
 ALPHABETS = [b"ab", b"abc", b"abcd", b"ab\xe4\xb8\x80", b"abcdefgh", b"xyz\xd0\xb0\xd1\x8f\xe4\xb8\xad\xe5\x9b\xbd",
              bytes(range(0x61, 0x7b)), bytes(range(1, 256))]
-n_cases = n_hits = n_long = n_group = n_filter = 0
+n_cases = n_hits = n_long = n_group = n_filter = n_skip = 0
 seed = seed0
 while time.time() < t_end:
     rng = random.Random(seed)
@@ -80,7 +80,7 @@ while time.time() < t_end:
             keys.append(k)
     env = {"AHA_LDS_SLOTS": rng.choice([None, None, "512", "1024", "4096"]),
            "AHA_SHADOW_FAIL": rng.choice([None, None, None, "0"]),
-           "AHA_ENGINE": rng.choice([None, None, "unit", "unit", "v2", "v1"]),
+           "AHA_ENGINE": rng.choice([None, None, "unit", "unit", "skip", "skip", "v2", "v1"]),  # (skip: scan_skip.hip where no key is a single character)
            "AHA_UNIT_POST": rng.choice([None, None, "regroup"]),
            "AHA_UNIT_HEADER_BESIDE": rng.choice([None, "0", "1"]),
            "AHA_UNIT_BASE_BITS": rng.choice([None, None, "23"]),
@@ -143,6 +143,7 @@ while time.time() < t_end:
         n_cases += 1
         n_hits += len(gh)
         n_filter += 1 if text.size and ac.last_timing()["engine"] == 5 else 0
+        n_skip += 1 if text.size and ac.last_timing()["engine"] == 6 else 0
         if grp is not None and text.size <= 300000:
             # the group API over shards on this one device: partition, shards in turn through the pipelined host entry, the
             # 4-byte exchange stream (or triples), the rebuild -- the caller's copy and every shard's gathered copy
@@ -180,4 +181,4 @@ while time.time() < t_end:
     seed += 1
     if seed % 5 == 0:
         print(f"[fuzz] {seed - seed0} automata, {n_cases} batches, {n_hits} hits ok", flush=True)
-print(f"fuzz ok: {n_filter} batches on the prefix-filter engine, {n_group} group batches, {n_long} match_longest documents, {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")
+print(f"fuzz ok: {n_filter} batches on the prefix-filter engine, {n_skip} on the skip-ahead traversal, {n_group} group batches, {n_long} match_longest documents, {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")

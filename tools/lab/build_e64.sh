@@ -16,7 +16,7 @@ $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $T/su.s -o $T
 $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $T/su.out $T/su.dev.obj
 $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$T/su.out -output=$T/su.hipfb
 /opt/rocm/bin/hipcc $FL --offload-arch=gfx950 -I ../../include --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang $T/su.hipfb -c scan_unit.hip -o $T/su_host.o
-for f in automaton.cpp cedar_replay.cpp unit.cpp capi.cpp group.cpp kernels.hip scan_v2.hip scan_filter.hip; do
+for f in automaton.cpp cedar_replay.cpp unit.cpp capi.cpp engine.cpp group.cpp kernels.hip scan_v2.hip scan_filter.hip; do
   /opt/rocm/bin/hipcc $FL --offload-arch=gfx950 -I ../../include -c $f -o $T/${f%.*}.o &
 done
 wait

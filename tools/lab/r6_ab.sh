@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 6 A/B leg: tools/lab_unit.py (cfg 3, 1 GiB, HIP events inside the library) over the product library -- with the skip-ahead
-# traversal (engine 6) and with AHA_SKIP=0 (engine 4, ku_traverse) -- and every lab build present (aha_amd/libaha_hip_lab_*.so), in
+# Round 6 A/B leg: tools/lab_unit.py (cfg 3, 1 GiB, HIP events inside the library) over the product library -- engine 4 (ku_traverse),
+# the pair engine (AHA_PAIR=1), with AB_SKIP=1 also the skip-ahead traversal (AHA_SKIP=1) -- and every lab build present (aha_amd/libaha_hip_lab_*.so), in
 # ONE call: the boxes of the pool differ by up to 12 %.  tools/lab/r6_ab.sh <tag> [reps]
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -13,8 +13,10 @@ run() {  # lib, note, env...
   tail -1 $log
 }
 for rep in $(seq 1 ${2:-2}); do
-  run aha_amd/libaha_hip.so "AHA_SKIP=0" AHA_SKIP=0
-  run aha_amd/libaha_hip.so "" AHA_X=0
+  run aha_amd/libaha_hip.so "engine 4" AHA_PAIR=0 AHA_SKIP=0
+  run aha_amd/libaha_hip.so "AHA_PAIR=1" AHA_PAIR=1
+  export AHA_PAIR=1
+  [ -n "$AB_SKIP" ] && run aha_amd/libaha_hip.so "AHA_SKIP=1" AHA_SKIP=1 AHA_PAIR=0
   for lib in aha_amd/libaha_hip_lab_*.so; do
     [ -f "$lib" ] || continue
     run $lib "" AHA_X=0

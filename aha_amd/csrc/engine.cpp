@@ -228,13 +228,13 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   // the fuller its batches of 64 candidates and the fewer chunks the post passes see (cfg 2 at 64 MiB: 0.136 ms with 4 KiB,
   // 0.117 with 16 KiB) -- while every wave of the device still has one, and while the image, if it fits LDS at all, still
   // fits beside the longer candidate lists.
-  // (a call with char offsets enters as a call with byte offsets: the same hits while the batch is plain ASCII, which
-  // kf_filter finds out on its way; a batch that is not comes back with rc 3 like a dense one)
+  // (a call with char offsets: kf_filter finds out on its way whether the batch is plain ASCII -- then a character count is a
+  // byte count --, otherwise kf_walk counts the continuation bytes of its chunk; the table it keeps for that counts against LDS)
   const bool filt = ac->pf_ok && !ac->unit_ok && !M1.sep && !M1.no_filter && mode != kSlabs && !(de && strcmp(de, "0") == 0);
   if (filt) {
     S = 4096;
     while (S < kV2MaxS && N / (2 * S) >= (uint64_t)ac->pf_cus * 16 &&
-           (filter_image_in_lds(ac->n_slots, (uint32_t)(2 * S)) || !filter_image_in_lds(ac->n_slots, 4096)))
+           (filter_image_in_lds(ac->n_slots, (uint32_t)(2 * S), M1.chars != 0) || !filter_image_in_lds(ac->n_slots, 4096, M1.chars != 0)))
       S *= 2;
     if (const char *fc = getenv("AHA_FILTER_CHUNK")) {  // the tests' way to the larger chunks without a batch of 128+ MiB
       const long v = atol(fc);
@@ -254,7 +254,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.n_chunks = (N + S - 1) / S;
   if (M.n_chunks > 0xFFFFFFFFull) return 1;
   M.lds_slots = ac->v2_lds_slots;
-  M.chars = filt ? 0 : M1.chars;
+  M.chars = M1.chars;
   M.sep = M1.sep;
   memcpy(M.sep_block, M1.sep_block, sizeof(M.sep_block));
   M.out = M1.out;
@@ -590,8 +590,7 @@ int32_t device_match(aha_ac *ac, Scratch *sc, const uint8_t *d_corpus, const uin
   if (ac->v2_ok) {
     // a handle whose batches keep coming back from the prefix-filter engine (text dense with key starts) skips it for 2, 4,
     // .. 64 calls before it tries again: a batch that is handed back has paid for the filter and part of the walks
-    const int pm = M.chars ? 1 : 0;  // (calls with char offsets come back for another reason -- text that is not ASCII -- and keep
-                                     // their own count)
+    const int pm = M.chars ? 1 : 0;  // (calls with char offsets keep their own count)
     if (ac->pf_ok) {  // (calls on one handle may run side by side: the count goes down by compare-exchange, never below 0)
       uint32_t v = ac->pf_skip[pm].load(std::memory_order_relaxed);
       while (v && !ac->pf_skip[pm].compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) {

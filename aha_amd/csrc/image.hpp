@@ -195,7 +195,7 @@ struct FilterDev {
   uint32_t log2;  // the filter has 2^log2 words (10 .. kFilterLog2)
 };
 // kf_walk keeps the image in LDS, beside its 16 waves' candidate lists, when both fit (chunks of 32 KiB: 57 KiB of image, 4 KiB: 115)
-bool filter_image_in_lds(uint32_t n_slots, uint32_t chunk_bytes);
+bool filter_image_in_lds(uint32_t n_slots, uint32_t chunk_bytes, bool chars = false);
 int filter_prepare();  // once per process, before the first launch (LDS beyond 64 KiB is opt-in)
 // filter_launch_filter: bitmap (one bit per byte position of M.text) and -- on the same launch -- the chunk records of chunks
 // of M.S bytes (4, 8, 16 or 32 KiB; chunk_rec: n_chunks * filter_chunk_rec_bytes() of scratch).  non_ascii (nullable): set

@@ -41,7 +41,10 @@ constexpr int kfMaxEnds = 4;  // END steps a walk keeps; a walk with more hands 
 
 // LDS of a wave of kf_walk with chunks of W * 4 KiB: its candidate list (2 bytes an entry), the document boundaries near
 // its chunk, the END steps of a batch's walks
-__host__ __device__ constexpr uint32_t kf_wave_lds(uint32_t W) { return kfListPer4K * W * 2 + 64 * 4 + 64 * kfMaxEnds * 8; }
+// (+ for calls with char offsets the chunk's continuation bytes: a 64-bit mask and a running count per 64 text bytes)
+__host__ __device__ constexpr uint32_t kf_wave_lds(uint32_t W, bool chars = false) {
+  return kfListPer4K * W * 2 + 64 * 4 + 64 * kfMaxEnds * 8 + (chars ? W * 64 * (8 + 2) : 0);
+}
 
 // per chunk: the first d with doc_off[d] >= chunk start and the boundary before it (kf_walk reads one record per chunk, a
 // chunk ahead, instead of searching).  Written by the blocks of kf_filter's launch that stand behind the filter's own.
@@ -133,7 +136,12 @@ __device__ __forceinline__ kf_v4u kf_text16(const uint8_t *__restrict__ text, in
 // ---- the walks.  A wave takes a chunk of M.S bytes (a multiple of 4 KiB: kfWords * 64 words of the bitmap, lane l the
 // kfWords consecutive words l * W ..): offsets below are relative to chunk start - kfWarm.  IMG: the whole image in LDS
 // (a keyword list's automaton is a few tens of KiB), the block's 16 waves share it; otherwise the slots come through L1/L2.
-template <bool IMG>
+// CHARS (String overload, matcher.cr:34-39): the events carry the lead-byte count of their end (<< 1 | "counted from the
+// document's start") in place of the byte offset, the chunk leaves lead_cnt / chunk_doc0 / doc_lead_rank -- what k2_traverse
+// leaves for k2d_expand<.., true>.  A character = a byte that is no continuation byte (10xxxxxx), as there.  While the batch
+// is plain ASCII (kf_filter has looked at every byte: *non_ascii) the count IS the offset; otherwise the wave reads its chunk
+// once more, coalesced, and keeps the continuation bytes' mask and running count per 64 bytes in LDS.
+template <bool IMG, bool CHARS>
 __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, const unsigned long long *__restrict__ bitmap,
                                                              const KfChunk *__restrict__ chunk_rec,
                                                              const unsigned long long *non_ascii) {
@@ -141,21 +149,25 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
   // the doc offsets are not what the call says (k_check_docs ran in front): index nothing -- and say nothing: every store to
   // cursor[1] below is a plain one, and the verdict must reach the host (block-uniform, like the hand-back under it)
   if (M.cursor[1] >= 16ull) return;
-  // a call with char offsets came here as a call with byte offsets: the same thing while the batch is plain ASCII (kf_filter
-  // has looked at every byte); if it is not, the call goes to the engines that count characters
-  if (non_ascii && *non_ascii) {
-    if (threadIdx.x == 0) M.cursor[1] = 3ull;
-    return;
-  }
+  const bool asc = !CHARS || !*non_ascii;  // (block-uniform)
   constexpr int WPB = IMG ? 16 : 4;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t W = M.S / 4096u;  // bitmap words per lane (1, 2, 4 or 8)
   const uint32_t list_cap = kfDensePer4K * W;
-  uint8_t *mine = smem + (size_t)wave * kf_wave_lds(W);
+  uint8_t *mine = smem + (size_t)wave * kf_wave_lds(W, CHARS);
   uint16_t *list = reinterpret_cast<uint16_t *>(mine);
   uint32_t *bnd = reinterpret_cast<uint32_t *>(mine + kfListPer4K * W * 2);
   uint2 *ends = reinterpret_cast<uint2 *>(mine + kfListPer4K * W * 2 + 256);
-  uint32_t *lslots = reinterpret_cast<uint32_t *>(smem + (size_t)WPB * kf_wave_lds(W));
+  unsigned long long *cmask = reinterpret_cast<unsigned long long *>(mine + kf_wave_lds(W, false));  // CHARS: W * 64 words
+  uint16_t *cpre = reinterpret_cast<uint16_t *>(mine + kf_wave_lds(W, false) + W * 64 * 8);          // continuation bytes before each
+  uint32_t *lslots = reinterpret_cast<uint32_t *>(smem + (size_t)WPB * kf_wave_lds(W, CHARS));
+  // characters that start in [chunk start, chunk start + o), o <= M.S
+  auto lead = [&](uint32_t o) -> uint32_t {
+    if (asc) return o;
+    const uint32_t w = min(o >> 6, W * 64u - 1u), bit = o - w * 64u;
+    const unsigned long long low = bit >= 64u ? ~0ull : ((1ull << bit) - 1ull);
+    return o - ((uint32_t)cpre[w] + (uint32_t)__popcll(cmask[w] & low));
+  };
   const uint32_t *gslots = reinterpret_cast<const uint32_t *>(A.slots);
   if (IMG) {
     for (uint32_t i = threadIdx.x; i < A.n_slots; i += 1024) lslots[i] = gslots[i];
@@ -192,6 +204,33 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
     const int64_t a = (int64_t)chunk * M.S;
     const int64_t e = min(a + (int64_t)M.S, N);
     const int64_t g0 = a - kfWarm;  // text position of offset 0
+    if (CHARS && !asc) {
+      // piece P = 16 bytes: its continuation bytes as 16 bits (bit 7 set, bit 6 clear; four of them gathered by a multiply)
+      uint16_t *cm16 = reinterpret_cast<uint16_t *>(cmask);
+      for (uint32_t j = 0; j < M.S / 1024u; j++) {
+        const uint32_t P = j * 64u + (uint32_t)lane;
+        const int64_t g = a + (int64_t)P * 16;
+        const kf_v4u v = g < N ? kf_text16(M.text, g, N) : kf_v4u{0u, 0u, 0u, 0u};
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t c = ((v[k] & (~v[k] << 1)) >> 7) & 0x01010101u;
+          bits |= ((c * 0x01020408u) >> 24 & 0xFu) << (4 * k);
+        }
+        cm16[P] = (uint16_t)bits;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      uint32_t mine_cnt = 0;
+      for (uint32_t k = 0; k < W; k++) mine_cnt += (uint32_t)__popcll(cmask[(uint32_t)lane * W + k]);
+      uint32_t run = wave_incl_scan(mine_cnt) - mine_cnt;
+      for (uint32_t k = 0; k < W; k++) {
+        cpre[(uint32_t)lane * W + k] = (uint16_t)run;
+        run += (uint32_t)__popcll(cmask[(uint32_t)lane * W + k]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
     // ---- documents: dn = first boundary at or behind the chunk start.  Lane i looks at boundary dn + i: those below
     // e + kfAhead are the ones a walk of this chunk can meet (usually none or one); their offsets go to LDS, a candidate
     // counts the ones at or before it.  64 of them or more (documents of a few bytes): the general way, from memory.
@@ -234,7 +273,10 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
     __builtin_amdgcn_wave_barrier();
     uint32_t before_doc = 0;  // lane i < n_in: events of the chunk that end at or before the first byte of document dn + i
     if (many) {  // their events-before counts start at 0
-      for (uint64_t d = dn + (uint64_t)lane; d <= D && (int64_t)M.doc_off[d] < e; d += 64) M.doc_ev_rank[d] = 0;
+      for (uint64_t d = dn + (uint64_t)lane; d <= D && (int64_t)M.doc_off[d] < e; d += 64) {
+        M.doc_ev_rank[d] = 0;
+        if (CHARS) M.doc_lead_rank[d] = lead((uint32_t)((int64_t)M.doc_off[d] - a));
+      }
     }
     uint32_t carry = 0;  // furthest offset (exclusive) an earlier start's walk is alive at
     uint32_t seq = 0;    // events of the chunk so far (wave-uniform)
@@ -343,7 +385,12 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
           uint32_t x = A.end_info[eb[k]], cnt = x >> 24;
           if (cnt == 255u) cnt = A.key_cnt[A.chain ? A.chain[x & 0xFFFFFFu].y : (x & 0xFFFFFFu)];
           hsum += cnt;
-          if (at < M.ev_stride) reg[at] = make_uint2(x, (uint32_t)((int32_t)ej[k] - ds));
+          uint32_t y = (uint32_t)((int32_t)ej[k] - ds);
+          if (CHARS) {  // the document starts inside the chunk: counted from there, exactly; else from the chunk start
+            const bool exact = ds >= kfWarm;
+            y = ((lead(ej[k] - (uint32_t)kfWarm) - (exact ? lead((uint32_t)(ds - kfWarm)) : 0u)) << 1) | (exact ? 1u : 0u);
+          }
+          if (at < M.ev_stride) reg[at] = make_uint2(x, y);
           at++;
         }
       // documents that start inside the chunk: the events that end at or before their first byte
@@ -367,11 +414,18 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
       seq += vtot;
     }
     if (give_up) break;
-    if (!many && (uint32_t)lane < n_in) M.doc_ev_rank[dn + (uint64_t)lane] = before_doc;
+    if (!many && (uint32_t)lane < n_in) {
+      M.doc_ev_rank[dn + (uint64_t)lane] = before_doc;
+      if (CHARS) M.doc_lead_rank[dn + (uint64_t)lane] = lead(bnd[lane] - (uint32_t)kfWarm);
+    }
     hsum = wave_last(wave_incl_scan(hsum));
     if (lane == 0) {
       M.ev_cnt[chunk] = seq;
       M.chunk_hits[chunk] = hsum;
+      if (CHARS) {
+        M.lead_cnt[chunk] = lead((uint32_t)(e - a));
+        M.chunk_doc0[chunk] = (uint32_t)(bv == a ? dn : dn - 1);  // the document that holds the chunk's first byte
+      }
       if (seq > M.ev_stride) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
     }
   }
@@ -383,12 +437,12 @@ size_t filter_chunk_rec_bytes() { return sizeof(KfChunk); }
 
 // LDS of a CU that a block of 16 waves may take (nothing static in kf_walk)
 constexpr size_t kfLdsBudget = 160u << 10;
-bool filter_image_in_lds(uint32_t n_slots, uint32_t chunk_bytes) {
-  return (size_t)n_slots * 4 + 16 * (size_t)kf_wave_lds(chunk_bytes / 4096u) <= kfLdsBudget;
+bool filter_image_in_lds(uint32_t n_slots, uint32_t chunk_bytes, bool chars) {
+  return (size_t)n_slots * 4 + 16 * (size_t)kf_wave_lds(chunk_bytes / 4096u, chars) <= kfLdsBudget;
 }
 
-static size_t walk_lds(bool img, uint32_t n_slots, uint32_t W) {
-  return (size_t)(img ? 16 : 4) * kf_wave_lds(W) + (img ? (size_t)n_slots * 4 : 0);
+static size_t walk_lds(bool img, uint32_t n_slots, uint32_t W, bool chars) {
+  return (size_t)(img ? 16 : 4) * kf_wave_lds(W, chars) + (img ? (size_t)n_slots * 4 : 0);
 }
 
 void filter_launch_filter(const FilterDev &F, const V2Args &M, void *bitmap, void *chunk_rec, unsigned long long *non_ascii,
@@ -409,24 +463,35 @@ void filter_launch_filter(const FilterDev &F, const V2Args &M, void *bitmap, voi
 void filter_launch_walk(const DevAut &A, const V2Args &M, const void *bitmap, const void *chunk_rec, const unsigned long long *non_ascii,
                         uint32_t cus, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  const bool img = filter_image_in_lds(A.n_slots, M.S);
+  const bool chars = M.chars != 0;
+  const bool img = filter_image_in_lds(A.n_slots, M.S, chars);
   const uint32_t W = M.S / 4096u;
   const auto *bm = (const unsigned long long *)bitmap;
+  const auto *cr = (const KfChunk *)chunk_rec;
   if (img) {
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((M.n_chunks + 15) / 16, cus));
-    hipLaunchKernelGGL(kf_walk<true>, dim3(grid), dim3(1024), walk_lds(true, A.n_slots, W), s, A, M, bm, (const KfChunk *)chunk_rec, non_ascii);
+    const size_t lds = walk_lds(true, A.n_slots, W, chars);
+    if (chars)
+      hipLaunchKernelGGL((kf_walk<true, true>), dim3(grid), dim3(1024), lds, s, A, M, bm, cr, non_ascii);
+    else
+      hipLaunchKernelGGL((kf_walk<true, false>), dim3(grid), dim3(1024), lds, s, A, M, bm, cr, non_ascii);
   } else {
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((M.n_chunks + 3) / 4, (uint64_t)cus * 5));
-    hipLaunchKernelGGL(kf_walk<false>, dim3(grid), dim3(256), walk_lds(false, 0, W), s, A, M, bm, (const KfChunk *)chunk_rec, non_ascii);
+    const size_t lds = walk_lds(false, 0, W, chars);
+    if (chars)
+      hipLaunchKernelGGL((kf_walk<false, true>), dim3(grid), dim3(256), lds, s, A, M, bm, cr, non_ascii);
+    else
+      hipLaunchKernelGGL((kf_walk<false, false>), dim3(grid), dim3(256), lds, s, A, M, bm, cr, non_ascii);
   }
 }
 
 int filter_prepare() {
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&kf_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)kfLdsBudget) != hipSuccess) {
-    (void)hipGetLastError();  // (not left for the next call's check to find)
-    return -1;
-  }
+  const void *fs[2] = {reinterpret_cast<const void *>(&kf_walk<true, false>), reinterpret_cast<const void *>(&kf_walk<true, true>)};
+  for (const void *f : fs)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kfLdsBudget) != hipSuccess) {
+      (void)hipGetLastError();  // (not left for the next call's check to find)
+      return -1;
+    }
   return 0;
 }
 

@@ -146,10 +146,10 @@ typedef struct {
   /* ABI 7: the prefix-filter engine (aha_amd/csrc/scan_filter.hip; aha_timing.engine = 5).  Built for a key set without a
    * character-level image whose keys are 3 .. 64 bytes long (a keyword list): a blocked Bloom filter over the keys' first
    * filter_prefix_bytes bytes (min(4, shortest key); 0 = this handle has none) of filter_words 32-bit words.  Matches without
-   * a separator filter -- byte offsets, or char offsets over a batch of plain ASCII -- then look at every text position
+   * a separator filter -- byte or char offsets -- then look at every text position
    * through the filter and walk the automaton only from the positions it lets through; a batch whose text is dense with
-   * such positions (more than about one in twenty), or not plain ASCII when char offsets are asked for, is handed to the
-   * single-traversal engine by the call itself (aha_timing.repeats counts it). */
+   * such positions (more than about one in twenty) is handed to the single-traversal engine by the call itself
+   * (aha_timing.repeats counts it). */
   uint32_t filter_prefix_bytes;
   uint32_t filter_words;
   /* ABI 8: the skip-ahead traversal (aha_amd/csrc/scan_skip.hip; aha_timing.engine = 6) over the character-level image.

@@ -33,7 +33,7 @@ void v2_launch_sort(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("
 void v2_launch_expand(const DevAut &, const V2Args &, uint64_t, void *) { no_gpu("v2_launch_expand"); }
 void v2_launch_direct_post(const DevAut &, const V2Args &, void *, void *, bool) { no_gpu("v2_launch_direct_post"); }
 void launch_has_nul(const uint8_t *, uint64_t, uint64_t *, void *) { no_gpu("launch_has_nul"); }
-bool filter_image_in_lds(uint32_t, uint32_t) { return false; }
+bool filter_image_in_lds(uint32_t, uint32_t, bool) { return false; }
 int filter_prepare() { return 0; }
 void filter_launch_filter(const FilterDev &, const V2Args &, void *, void *, unsigned long long *, uint32_t, void *) { no_gpu("filter_launch_filter"); }
 size_t filter_chunk_rec_bytes() { return 16; }

@@ -28,6 +28,7 @@ class FilterSim(ImageSim):
             w, m = self._word_mask(int.from_bytes(bytes(k[:self.D]), "little"))
             self.bloom[w] |= m
         self.max_len = info["max_key_len"]
+        self.keys = list(keys)
 
     def _word_mask(self, w4):
         h = (w4 * FILTER_MUL) & 0xFFFFFFFF
@@ -72,3 +73,56 @@ class FilterSim(ImageSim):
                             k = int(self.key_next[k])
                 reach = max(reach, last_alive)
         return hits
+
+    # ---- char offsets (kf_walk<.., CHARS> + k2d_expand<.., true>): a character = a byte outside 0x80..0xBF.  Per chunk of S
+    # bytes the continuation bytes as a 64-bit mask and a running count per 64 bytes; an event carries the characters counted
+    # from its document's start if that lies inside the chunk ("exact"), else from the chunk's start, and the expansion adds
+    # what lies between the document's start and the chunk: lead_base (scan of the chunks' counts), chunk_doc0, doc_lead_rank.
+    def match_batch_chars(self, text, doc, S=4096):
+        t = bytes(text)
+        n = len(t)
+        doc = [int(x) for x in doc]
+        n_chunks = (n + S - 1) // S
+        cmask, cpre, lead_cnt, chunk_doc0 = [], [], [], []
+        doc_lead_rank = {}
+
+        def lead(c, o):  # characters that start in [c * S, c * S + o)
+            w = min(o >> 6, S // 64 - 1)
+            bit = o - w * 64
+            low = (1 << 64) - 1 if bit >= 64 else (1 << bit) - 1
+            return o - (cpre[c][w] + bin(cmask[c][w] & low).count("1"))
+
+        for c in range(n_chunks):
+            a, e = c * S, min(c * S + S, n)
+            chunk = t[a:a + S].ljust(S, b"\0")
+            m = [sum(1 << i for i in range(64) if (chunk[w * 64 + i] & 0xC0) == 0x80) for w in range(S // 64)]
+            pre, run = [], 0
+            for w in range(S // 64):
+                pre.append(run)
+                run += bin(m[w]).count("1")
+            cmask.append(m)
+            cpre.append(pre)
+            lead_cnt.append(lead(c, e - a))
+            dn = next(i for i, b in enumerate(doc) if b >= a)  # first boundary at or behind the chunk start
+            chunk_doc0.append(dn if doc[dn] == a else dn - 1)
+            for d in range(dn, len(doc)):
+                if doc[d] >= e:
+                    break
+                doc_lead_rank[d] = lead(c, doc[d] - a)
+        lead_base = [sum(lead_cnt[:c]) for c in range(n_chunks)]
+        kc = [sum(1 for b in bytes(k) if (b & 0xC0) != 0x80) for k in self.keys]
+        out = []
+        for d, start, end, k in self.match_batch(text, doc):
+            pos = doc[d] + end  # the event's end (exclusive) in the batch; its chunk is that of its last byte
+            c = (pos - 1) // S
+            a = c * S
+            exact = doc[d] >= a
+            y = ((lead(c, pos - a) - (lead(c, doc[d] - a) if exact else 0)) << 1) | (1 if exact else 0)
+            # k2d_expand
+            d0 = chunk_doc0[c]
+            dchunk = doc[d0] // S
+            lead_adj = lead_base[c] - (lead_base[dchunk] + doc_lead_rank[d0])
+            end_c = (y >> 1) + (0 if y & 1 else lead_adj)
+            out.append((d, end_c - kc[k], end_c, k))
+        return out
+

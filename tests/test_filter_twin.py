@@ -61,3 +61,35 @@ def test_start_parallel_rule_on_the_truncated_chain():
     o = orc.AC.compile(keys)
     for text in (b"xabc", b"xabcz", b"abcbczz", b"xabxabcczz", b"bczabc" * 5):
         assert sim.match_batch(text, [0, len(text)]) == oracle_hits(o, text, [0, len(text)])
+
+
+def oracle_hits_chars(o, text, doc):
+    oh, od = o.match_batch(np.frombuffer(text, dtype=np.uint8), np.asarray(doc, dtype=np.uint64), cap=max(1024, 8 * len(text)), chars=True)
+    return [(d, int(h[0]), int(h[1]), int(h[2])) for d in range(len(doc) - 1) for h in oh[int(od[d]):int(od[d + 1])]]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_char_offsets_from_the_chunks_continuation_counts(seed, monkeypatch):
+    """matcher.cr:34-39 on the prefix-filter engine: what kf_walk<.., CHARS> leaves per chunk (continuation-byte masks and running
+    counts, events counted from the document's or the chunk's start, lead_cnt / chunk_doc0 / doc_lead_rank) and what
+    k2d_expand<.., true> makes of it, against the oracle's char offsets -- documents cut at character boundaries, several per
+    chunk and across chunks, chunks of 256 bytes so that a few KiB of text cross many."""
+    monkeypatch.setenv("AHA_ENGINE", "filter")
+    rng = random.Random(900 + seed)
+    keys = [k.encode() for k in ("abc", "bcd", "naïve", "日本語", "x😀y", "ключ", "éé", "end of line", "abcd")]
+    ac = AC.compile(keys, host_only=True)
+    sim = FilterSim(ac, keys)
+    o = orc.AC.compile(keys)
+    for _ in range(3):
+        chars = []
+        for _ in range(rng.randint(1, 400)):
+            x = rng.random()
+            chars += list(rng.choice(keys).decode()) if x < 0.3 else [rng.choice("è月😁я -")] * rng.randint(1, 9)
+        at = np.cumsum([0] + [len(c.encode()) for c in chars])
+        text = "".join(chars).encode()
+        cuts = sorted({0, len(chars)} | {rng.randrange(0, len(chars) + 1) for _ in range(rng.choice([0, 3, 40]))})
+        doc = [int(at[c]) for c in cuts]
+        if rng.random() < 0.5:
+            doc = sorted(doc + doc[1:3])  # empty documents
+        assert sim.match_batch_chars(text, doc, S=256) == oracle_hits_chars(o, text, doc), (text, doc)
+

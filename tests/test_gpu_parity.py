@@ -608,6 +608,44 @@ def test_prefix_filter_engine_edges(engine, monkeypatch, chunk):
     # ... four still fit
     assert run(nest[:4], t, None, 5) == 4 * 200
 
+    # ---- char offsets (matcher.cr:34-39) over text that is not ASCII: kf_walk counts its chunk's continuation bytes itself.
+    # Keys of 1-, 2-, 3- and 4-byte characters between ASCII ones, documents cut at character boundaries (several inside a
+    # chunk, some across chunks, empty ones), a document start exactly at a chunk start, a chunk of nothing but continuation
+    # bytes' owners (3-byte characters), the last chunk shorter than a chunk.
+    def run_chars(keys, text, cut_chars, want_engine=5):
+        ac = AC.compile(keys)
+        ac.set_profiling(True)
+        o = orc.AC.compile(keys)
+        raw = text.encode()
+        at = np.cumsum([0] + [len(c.encode()) for c in text])  # byte offset of every character (and of the end)
+        t = np.frombuffer(raw, dtype=np.uint8)
+        doc = np.array(sorted([0, len(raw)] + [int(at[c]) for c in cut_chars if c <= len(text)]), dtype=np.uint64)
+        for chars in (True, False):
+            gh, gd = ac.match_batch(t, doc, chars=chars)
+            oh, od = o.match_batch(t, doc, chars=chars)
+            assert np.asarray(gh).tobytes() == oh.tobytes() and np.array_equal(np.asarray(gd, dtype=np.uint64), od)
+            assert ac.last_timing()["engine"] == want_engine, "chars=%s %s" % (chars, sorted(ac.last_timing().items()))
+        return len(oh)
+
+    ukeys = ["abc", "bcd", "naïve", "日本語", "x😀y", "ключ", "éé", "end of line"]
+    assert AC.compile(ukeys, host_only=True).info["unit_enabled"] == 0
+    parts = []
+    for i in range(6000):
+        r = rng.random()
+        parts.append(rng.choice(ukeys) if r < 0.15 else rng.choice(["è", "月", "😁", "я"]) * rng.randint(1, 12) if r < 0.5
+                     else " " * rng.randint(1, 30))
+    utext = "".join(parts)
+    assert run_chars(ukeys, utext, []) > 500
+    cuts = sorted(rng.randint(0, len(utext)) for _ in range(200))
+    run_chars(ukeys, utext, cuts + cuts[3:6])
+    run_chars(ukeys, utext, list(range(0, len(utext), 5)))  # documents of five characters: the general way to a candidate's document
+    # a document that starts exactly at byte 4096 / 8192 / ..: 3-byte characters up to it
+    tri = "月" * (4096 // 3) + " " * (4096 % 3)  # (no key starts with it: a run of key starts is not this engine's text)
+    utext2 = (tri + "日本語abc") * 9 + "naïve"
+    run_chars(ukeys, utext2, [len(tri) * k + 6 * (k - 1) for k in range(1, 9)])
+    # plain ASCII with char offsets: the count is the offset
+    run_chars(ukeys, ("abc" + " " * 29) * 1500 + "end of line", [17, 1000])
+
 
 def test_engine_selected(engine, monkeypatch):
     ac = AC.compile(["ab", "b"])
@@ -648,14 +686,14 @@ def test_engine_selected(engine, monkeypatch):
         sparse_text = b"-" * 5000 + b"abcd"
         engines = [asc.match_array(sparse_text).shape[0] and asc.last_timing()["engine"] for _ in range(6)]
         assert engines[0] == 2 and engines[-1] == 5 and sorted(engines) == engines
-        # char offsets: the same engine while the batch is plain ASCII (char offsets are byte offsets then; kf_filter looks
-        # at every byte anyway), the byte-level engine as soon as it is not
+        # char offsets: the same engine -- while the batch is plain ASCII a char offset is a byte offset (kf_filter looks at
+        # every byte anyway), and when it is not kf_walk counts the characters of its chunk
         one = lambda t: (np.frombuffer(t, dtype=np.uint8), np.array([0, len(t)], dtype=np.uint64))
         hits, _ = asc.match_batch(*one(sparse_text), chars=True)
         assert asc.last_timing()["engine"] == 5 and [tuple(h) for h in hits.tolist()] == [(5000, 5003, 0), (5001, 5004, 1)]
         utf = "é".encode() * 2500 + b"abcd"
         hits, _ = asc.match_batch(*one(utf), chars=True)
-        assert asc.last_timing()["engine"] == 2 and [tuple(h) for h in hits.tolist()] == [(2500, 2503, 0), (2501, 2504, 1)]
+        assert asc.last_timing()["engine"] == 5 and [tuple(h) for h in hits.tolist()] == [(2500, 2503, 0), (2501, 2504, 1)]
         hits, _ = asc.match_batch(*one(utf))  # (byte offsets: non-ASCII text is nothing special)
         assert asc.last_timing()["engine"] == 5 and [tuple(h) for h in hits.tolist()] == [(5000, 5003, 0), (5001, 5004, 1)]
     # char offsets run on the character-level engine too, the separator filter on the byte-level engines only

@@ -18,7 +18,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
 ALPHABETS = [b"ab", b"abc", b"abcd", b"ab\xe4\xb8\x80", b"abcdefgh", b"xyz\xd0\xb0\xd1\x8f\xe4\xb8\xad\xe5\x9b\xbd",
              bytes(range(0x61, 0x7b)), bytes(range(1, 256))]
-n_cases = n_hits = n_long = n_group = n_filter = n_skip = 0
+n_cases = n_hits = n_long = n_group = n_filter = n_skip = n_pair = n_filter_chars = 0
 seed = seed0
 while time.time() < t_end:
     rng = random.Random(seed)
@@ -80,7 +80,7 @@ while time.time() < t_end:
             keys.append(k)
     env = {"AHA_LDS_SLOTS": rng.choice([None, None, "512", "1024", "4096"]),
            "AHA_SHADOW_FAIL": rng.choice([None, None, None, "0"]),
-           "AHA_ENGINE": rng.choice([None, None, "unit", "unit", "skip", "skip", "v2", "v1"]),  # (skip: scan_skip.hip where no key is a single character)
+           "AHA_ENGINE": rng.choice([None, None, "unit", "unit", "skip", "skip", "pair", "pair", "v2", "v1"]),  # (skip / pair: scan_skip.hip / scan_pair.hip where no key is a single character)
            "AHA_UNIT_POST": rng.choice([None, None, "regroup"]),
            "AHA_UNIT_HEADER_BESIDE": rng.choice([None, "0", "1"]),
            "AHA_UNIT_BASE_BITS": rng.choice([None, None, "23"]),
@@ -116,7 +116,8 @@ while time.time() < t_end:
             r = rng.random()
             if kwl and r >= p_key:  # filler: mostly bytes no key starts with, now and then the alphabet's own
                 parts.append(bytes(rng.choice(alpha) for _ in range(rng.randint(1, 9))) if r < p_key + 0.05
-                             else rng.choice([b" ", b"-- ", b"\n", b"0123456789 ", b"\x00"]) * rng.randint(1, 12))
+                             else rng.choice([b" ", b"-- ", b"\n", b"0123456789 ", b"\x00", "\u00e8".encode(), "\u6708".encode(),
+                                              "\U0001f601".encode(), b"\x80"]) * rng.randint(1, 12))  # (characters of 2, 3, 4 bytes and stray continuation bytes: char offsets on the prefix-filter engine)
             elif r < p_key and keys:
                 parts.append(rng.choice(keys))
             elif big and r < 0.7:  # characters (not bytes) of the wide alphabet: hub + any
@@ -144,6 +145,8 @@ while time.time() < t_end:
         n_hits += len(gh)
         n_filter += 1 if text.size and ac.last_timing()["engine"] == 5 else 0
         n_skip += 1 if text.size and ac.last_timing()["engine"] == 6 else 0
+        n_pair += 1 if text.size and ac.last_timing()["engine"] == 7 else 0
+        n_filter_chars += 1 if text.size and chars and ac.last_timing()["engine"] == 5 and int(text.max()) >= 0x80 else 0
         if grp is not None and text.size <= 300000:
             # the group API over shards on this one device: partition, shards in turn through the pipelined host entry, the
             # 4-byte exchange stream (or triples), the rebuild -- the caller's copy and every shard's gathered copy
@@ -181,4 +184,4 @@ while time.time() < t_end:
     seed += 1
     if seed % 5 == 0:
         print(f"[fuzz] {seed - seed0} automata, {n_cases} batches, {n_hits} hits ok", flush=True)
-print(f"fuzz ok: {n_filter} batches on the prefix-filter engine, {n_skip} on the skip-ahead traversal, {n_group} group batches, {n_long} match_longest documents, {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")
+print(f"fuzz ok: {n_filter} batches on the prefix-filter engine, {n_filter_chars} of them with char offsets over non-ASCII text, {n_skip} on the skip-ahead traversal, {n_pair} on the pair engine, {n_group} group batches, {n_long} match_longest documents, {n_cases} batches over {seed - seed0} automata, {n_hits} hits compared, seeds {seed0}..{seed - 1}")

@@ -405,6 +405,17 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
     HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
   }
   HIPCHK(ac, hipStreamSynchronize(s));
+#ifdef AHA_EXPAND_CLK
+  {  // (lab: the dense expansion's phases, clock cycles summed over the sampled chunks' waves)
+    unsigned long long w[16];
+    (void)hipMemcpy(w, sc->v2buf[9].p, sizeof(w), hipMemcpyDeviceToHost);
+    if (w[15])
+      fprintf(stderr, "k2d_expand_dense, %llu sampled chunks, %.1f windows each; cycles per window: A %.0f  B2 %.0f  wait %.0f  fill %.0f  wall-clock ticks of 10 ns per chunk %.0f; clocks per chunk %.0f\n",
+              w[15], (double)w[13] / w[15], (double)w[8] / w[13], (double)w[9] / w[13], (double)w[10] / w[13], (double)w[11] / w[13], (double)w[12] / w[15],
+              (double)w[14] / w[15]);
+    if (w[7]) fprintf(stderr, "  blocks sampled %llu: %.1f chunks each, %.0f clocks from the kernel's first instruction to its stores' acknowledgement\n", w[7], (double)w[6] / w[7], (double)w[5] / w[7]);
+  }
+#endif
 #ifdef AHA_SK_STATS
   if (skip) {
     unsigned long long w[16];

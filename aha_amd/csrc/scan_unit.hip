@@ -357,7 +357,11 @@ __global__ __launch_bounds__(kV2Threads) void ku_traverse(UnitDev U, V2Args M) {
             if (wfill + kp >= 64u) {
               const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (wbo + __umul24((uint32_t)lane, 12u)));
               const v3u r = {q[0], q[1], q[2]};
+#ifndef AHA_KU_LAB_NOFLUSH  // (lab, timing only: what the flush's store costs the trips behind it)
               if (wout + 64u <= wcap) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
+#else
+              if (wout + 64u == 0xFFFFFFF0u) *reinterpret_cast<v3u *>(wreg + (size_t)(wout + lane) * 3) = r;
+#endif
               wout += 64u;
               if (ev && my >= 64u) {
                 uint32_t *d = reinterpret_cast<uint32_t *>(smem + (wbo + __umul24(my - 64u, 12u)));

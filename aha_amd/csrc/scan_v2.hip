@@ -770,6 +770,22 @@ __global__ __launch_bounds__(256) void k2d_count(DevAut A, V2Args M) {
 // workgroups per CU to hide the table gathers) otherwise; a batch with more hits takes the direct-store path.
 // CHARS (String overload, matcher.cr:34-39): the record's second word is the lead-byte count of the position
 // (<< 1 | "counted from the document start") instead of the byte offset; hits are char offsets.
+// The block is ONE wave: what its lanes hand one another through LDS needs the order of the wave's own LDS instructions
+// (which the hardware keeps) and a compiler fence -- not __syncthreads(), whose s_waitcnt vmcnt(0) would also wait for the
+// window's stores to be acknowledged by memory before the next window's first LDS write.
+#ifndef AHA_EXPAND_LAB
+#define AHA_EXPAND_LAB 0
+#endif
+__device__ __forceinline__ void expand_sync() {
+#ifdef AHA_EXPAND_SYNCTHREADS
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 template <uint32_t kWaveStage, bool CHARS>
 __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
   __shared__ __attribute__((aligned(16))) uint32_t hbuf[kWaveStage * 3 + 4];
@@ -828,7 +844,7 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
           const uint64_t first = base + run + h0;
           const uint32_t ph = out16 ? (uint32_t)((first * 3) & 3u) : 0u;
           if (by_hit) {
-            __syncthreads();
+            expand_sync();
             // the lane's hits of the window (lane, lane + 64, ...) in three sweeps -- all event lookups, all gathers, all LDS
             // writes -- so that the window costs one LDS depth and one gather latency, not one per hit.
             // Which event a hit belongs to: the events that start inside the window mark their first hit in s_mark; a hit's event
@@ -839,10 +855,10 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
             uint2 ce[kPer];
 #pragma unroll
             for (int k = 0; k < kPer / 4; k++) reinterpret_cast<uint32_t *>(s_mark)[lane + 64 * k] = 0u;
-            __syncthreads();
+            expand_sync();
             if (live && off - h0 < nh) s_mark[off - h0] = 1;  // (off < h0 wraps around to a large number)
             uint32_t before = (uint32_t)__popcll(__ballot(live && off < h0));
-            __syncthreads();
+            expand_sync();
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
               const uint32_t j = (uint32_t)lane + 64u * (uint32_t)k;
@@ -857,7 +873,11 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
               const bool in = (uint32_t)lane + 64u * (uint32_t)k < nh;
+#if AHA_EXPAND_LAB & 2  // (lab: no gathers)
+              ce[k] = make_uint2(1u, at[k]);
+#else
               ce[k] = in ? (CHARS ? A.chain_chars : A.chain)[at[k]] : make_uint2(0, 0);
+#endif
             }
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
@@ -893,11 +913,16 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
               k = (int32_t)ln.y;
             } while (k >= 0);
           }
-          __syncthreads();
+          expand_sync();
           const uint64_t room = first < M.cap ? M.cap - first : 0;
           const uint32_t nd = (uint32_t)(nh < room ? nh : room) * 3;
           uint32_t *dst = reinterpret_cast<uint32_t *>(M.out + first);
+#if AHA_EXPAND_LAB & 1  // (lab: no stores)
+          if (nd == 0xFFFFFFFFu) dst[lane] = hbuf[lane];
+          else if (false) {
+#else
           if (out16 && nd >= 64) {
+#endif
             const uint32_t head = min(nd, (4u - ph) & 3u);
             if ((uint32_t)lane < head) dst[lane] = hbuf[ph + lane];
             const uint32_t nq = (nd - head) >> 2;
@@ -907,9 +932,11 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
             const uint32_t done = head + (nq << 2);
             if (done + (uint32_t)lane < nd) dst[done + lane] = hbuf[ph + done + lane];
           } else {
+#if !(AHA_EXPAND_LAB & 1)
             for (uint32_t j = lane; j < nd; j += 64) dst[j] = hbuf[ph + j];
+#endif
           }
-          __syncthreads();
+          expand_sync();
         }
       } else if (live) {  // a batch beyond the stage (and no expansion by hit index): hit by hit
         uint64_t idx = base + run + off;
@@ -930,6 +957,393 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
       run += tot;
     }
   }
+}
+
+// ---- the hit-dense expansion (cfg 5: 3.5 hits per byte, 11 GB of hits per step), software-pipelined.
+// k2d_expand<512> runs a window's steps one behind the other, and every wait of the wave for a load -- the chain gathers, the
+// next events' records -- is, on gfx950, also a wait for every store issued before it: vmcnt counts loads and stores in one
+// order, and the compiler, which cannot count the stores of a loop, waits for 0.  The stores of a window (6 KiB) are
+// acknowledged by memory after microseconds; a wave of k2d_expand<512> stands 9 400 of its 14 500 clocks per window in front of
+// such a wait (profiles/r06_expand_pipeline.txt).  Here a window's life is cut in three --
+//   A   events' marks, the lookups, the gathers issued           (reads s_excl / s_co / s_end, writes s_mark)
+//   B1  the gathers' results into the staged window              (writes hbuf)
+//   B2  the staged window out, 16 bytes a lane                   (reads hbuf)
+// -- the wave runs  A(w0) B1(w0);  { A(w + 1); B2(w); wait; B1(w + 1); }  and every load of the loop (the gathers, the next
+// batch's records) and every store of B2 is HAND-ISSUED, so that the one wait can name how many instructions younger than
+// the loads -- B2's stores, exactly -- may stay outstanding.  What that takes from the compiler, the code has to guarantee
+// itself:
+//   * a hand-issued load's register holds nothing until the wait: between the asm statement and the wait the VALUE must not
+//     be merged with another definition (hipcc resolves a phi with a copy of the register, then and there): the loads stand
+//     unconditionally in the loop body -- a window that does not exist gathers entry 0 and is not filled -- and are handed
+//     to ordinary variables only behind the wait;
+//   * the count must not be larger than the stores really issued: B2's counted form issues them with every lane in every
+//     instruction (no predicate the compiler could turn into a skipped instruction); a window it cannot take (under 64
+//     dwords, or beyond the capacity) goes out through ordinary stores and the wait is for 0.
+// The next window may be the first of the next batch of events (its scan and LDS tables are set up inside A); a batch takes
+// 64 events or, if those hold more hits than a window, as many as fill one.  A batch that is not expanded by hit index (few
+// hits per event, or no flattened chains) drains the pipeline and takes k2d_expand's per-event path.
+template <bool CHARS>
+__global__ __launch_bounds__(64) void k2d_expand_dense(DevAut A, V2Args M) {
+  constexpr uint32_t kStage = 512;
+  constexpr int kPer = (int)(kStage / 64);
+  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) uint32_t hbuf[kStage * 3 + 4];
+  __shared__ uint4 s_ev[64];  // per event of the batch: {hits of the batch before it, offset of its flattened chain, its end offset, -}
+  __shared__ __attribute__((aligned(16))) uint8_t s_mark[kStage];
+#ifdef AHA_EXPAND_CLK
+  const uint64_t k_start = clock64();
+  uint64_t k_chunks = 0;
+#endif
+  const bool out16 = (reinterpret_cast<uintptr_t>(M.out) & 15u) == 0;
+  if (M.cursor[1]) return;
+  const int lane = threadIdx.x;
+  const uint2 *chain = CHARS ? A.chain_chars : A.chain;
+  for (uint64_t c = blockIdx.x; c < M.n_chunks; c += gridDim.x) {
+    const uint32_t n = M.ev_cnt[c];
+    if (n == 0) continue;
+    const uint2 *reg = M.evd + c * M.ev_stride;
+    const uint64_t base = M.hit_base[c];
+    int32_t lead_adj = 0;
+    if (CHARS) {
+      const uint32_t d0 = M.chunk_doc0[c];
+      const uint64_t dchunk = M.doc_off[d0] / M.S;
+      lead_adj = (int32_t)(M.lead_base[c] - (M.lead_base[dchunk] + M.doc_lead_rank[d0]));
+    }
+#ifdef AHA_EXPAND_CLK
+    uint64_t c_a = 0, c_b2 = 0, c_wait = 0, c_fill = 0, c_other = 0, n_win = 0, t_last = clock64();
+    const uint64_t t_start = t_last, w_start = wall_clock64();
+#define CLK_MARK(acc) { const uint64_t t_ = clock64(); acc += t_ - t_last; t_last = t_; }
+#else
+#define CLK_MARK(acc)
+#endif
+    // the batch being prepared: events i0 .. i0 + n_ev - 1, `run` hits of the chunk before it, h0 = its next window
+    uint32_t i0 = 0, run = 0, h0 = 0, n_ev = 0;
+    bool have = false, by_hit = false, live = false;
+    uint2 rec = make_uint2(0, 0);
+    uint32_t cnt = 0, off = 0, tot = 0;
+    // the records of events ready_from .. ready_from + 63 (a lane beyond the chunk's events holds the last one's and ignores it)
+    uint2 rec_ready = make_uint2(0, 0);
+    uint32_t ready_from = ~0u;
+
+    // (rec_ready holds the records from i0.)  An event whose chain is longer than the record's count field says (255: look
+    // it up) needs a load the compiler counts -- and a load it counts anywhere in the pipeline's loop puts a wait for 0 on the
+    // loop's common path: inside the loop the batch is loaded WITHOUT the lookup, and one that needs it is left to the caller
+    // outside (returns false, nothing changed).
+    auto load_batch = [&](auto in_pipeline) -> bool {
+      const uint32_t i = i0 + lane;
+      const bool lv = i < n;
+      if (decltype(in_pipeline)::value && __ballot(lv && (rec_ready.x >> 24) == 255u)) return false;
+      live = lv;
+      rec = rec_ready;
+      cnt = 0;
+      if (live) {
+        cnt = rec.x >> 24;
+        rec.x &= 0xFFFFFFu;
+        if (!decltype(in_pipeline)::value) {
+          if (cnt == 255u) cnt = A.key_cnt[A.chain ? A.chain[rec.x].y : rec.x];
+        }
+        if (CHARS) rec.y = (rec.y >> 1) + ((rec.y & 1u) ? 0u : (uint32_t)lead_adj);
+      }
+      const uint32_t incl = wave_incl_scan(cnt);
+      tot = __shfl(incl, 63, 64);
+      off = incl - cnt;
+      n_ev = min(n - i0, 64u);
+      // 64 events of 9 hits are a window and a ninth of one: a batch that would spill takes only the events whose hits fill
+      // ONE window (at least 16 of them), the rest open the next batch
+      if (A.chain && tot > kStage) {
+        const uint32_t m = (uint32_t)__popcll(__ballot(live && incl <= kStage));
+        if (m >= 16u) {
+          n_ev = m;
+          tot = __shfl(incl, (int)m - 1, 64);
+          live = (uint32_t)lane < m;
+          cnt = live ? cnt : 0u;
+        }
+      }
+      by_hit = A.chain && (tot >= 2 * n_ev || tot > kStage);
+      h0 = 0;
+      have = true;
+      if (by_hit) s_ev[lane] = make_uint4(live ? off : tot, rec.x, rec.y, 0u);
+      return true;
+    };
+    auto batch_done = [&]() {
+      run += tot;
+      i0 += n_ev;
+      have = false;
+    };
+    // B2, uncounted: the staged window out through ordinary stores (k2d_expand's sequence)
+    auto stage_out = [&](uint64_t first, uint32_t nh, uint32_t ph) {
+      const uint64_t room = first < M.cap ? M.cap - first : 0;
+      const uint32_t nd = (uint32_t)(nh < room ? nh : room) * 3;
+      uint32_t *dst = reinterpret_cast<uint32_t *>(M.out + first);
+      if (out16 && nd >= 64) {
+        const uint32_t head = min(nd, (4u - ph) & 3u);
+        if ((uint32_t)lane < head) dst[lane] = hbuf[ph + lane];
+        const uint32_t nq = (nd - head) >> 2;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(hbuf + ph + head);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst + head);
+        for (uint32_t q = lane; q < nq; q += 64) d4[q] = s4[q];
+        const uint32_t done = head + (nq << 2);
+        if (done + (uint32_t)lane < nd) dst[done + lane] = hbuf[ph + done + lane];
+      } else {
+        for (uint32_t j = lane; j < nd; j += 64) dst[j] = hbuf[ph + j];
+      }
+      expand_sync();
+    };
+
+    for (;;) {
+      if (!have) {
+        if (i0 >= n) break;
+        if (ready_from != i0) {  // (the chunk's first batch, or the one behind a batch that went the per-event way)
+          v2u r;
+          const uint2 *ptr = reg + min(i0 + (uint32_t)lane, n - 1u);
+          asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(ptr) : "memory");
+          rec_ready = make_uint2(r.x, r.y);
+          ready_from = i0;
+        }
+        load_batch(std::false_type{});
+      }
+      if (!by_hit) {
+        // ---- not by hit index: one window filled event by event, or -- beyond the stage without flattened chains -- hit by hit
+        if (tot <= kStage) {
+          const uint64_t first = base + run;
+          const uint32_t ph = out16 ? (uint32_t)((first * 3) & 3u) : 0u;
+          if (live && A.chain) {
+            uint32_t w = ph + off * 3;
+            for (uint32_t j = 0; j < cnt; j++) {
+              const uint2 e = chain[rec.x + j];
+              hbuf[w] = rec.y - e.x;
+              hbuf[w + 1] = rec.y;
+              hbuf[w + 2] = e.y;
+              w += 3;
+            }
+          } else if (live) {
+            uint32_t w = ph + off * 3;
+            int32_t k = (int32_t)rec.x;
+            do {
+              const uint2 ln = A.key_ln[k];
+              hbuf[w] = CHARS ? rec.y - A.key_kc[k] - 1u : rec.y - ln.x;
+              hbuf[w + 1] = rec.y;
+              hbuf[w + 2] = (uint32_t)k;
+              w += 3;
+              k = (int32_t)ln.y;
+            } while (k >= 0);
+          }
+          expand_sync();
+          if (tot) stage_out(first, tot, ph);
+        } else if (live) {
+          uint64_t idx = base + run + off;
+          int32_t k = (int32_t)rec.x;  // (no flattened chains here: by_hit would have taken the batch)
+          do {
+            const uint2 ln = A.key_ln[k];
+            if (idx < M.cap) {
+              aha_hit h;
+              h.start = CHARS ? (int32_t)rec.y - (int32_t)A.key_kc[k] - 1 : (int32_t)rec.y - (int32_t)ln.x;
+              h.end = (int32_t)rec.y;
+              h.value = k;
+              M.out[idx] = h;
+            }
+            idx++;
+            k = (int32_t)ln.y;
+          } while (k >= 0);
+        }
+        batch_done();
+        continue;
+      }
+      // ---- by hit index, pipelined
+      uint32_t at[kPer], en[kPer];
+      uint64_t w_first = 0;
+      uint32_t w_nh = 0, w_ph = 0;
+      // A without the gathers: window h0 of the loaded batch -> at / en, its place and size -> w_*; moves on to the next window
+      auto lookups = [&]() {
+        const uint32_t nh = min(tot - h0, kStage);
+        w_first = base + run + h0;
+        w_nh = nh;
+        w_ph = out16 ? (uint32_t)((w_first * 3) & 3u) : 0u;
+        expand_sync();
+#pragma unroll
+        for (int k = 0; k < kPer / 4; k++) reinterpret_cast<uint32_t *>(s_mark)[lane + 64 * k] = 0u;
+        expand_sync();
+        if (live && off - h0 < nh) s_mark[off - h0] = 1;  // (off < h0 wraps around to a large number)
+        uint32_t before = (uint32_t)__popcll(__ballot(live && off < h0));
+        expand_sync();
+        // (no predicate on an LDS read: a read under a condition is a branch and a wait of its own, eight in a row -- the
+        // marks beyond the window are 0, every event index is one of the 64)
+        uint32_t mv[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++) mv[k] = s_mark[(uint32_t)lane + 64u * (uint32_t)k];
+        uint32_t ev[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+          const uint32_t j = (uint32_t)lane + 64u * (uint32_t)k;
+          const bool mk = j < nh && mv[k] != 0;
+          const uint64_t marks = __ballot(mk);
+          ev[k] = min(before + __builtin_amdgcn_mbcnt_hi((uint32_t)(marks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)marks, 0u)) +
+                          (mk ? 1u : 0u) - 1u, 63u);
+          before += (uint32_t)__popcll(marks);
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+          const uint32_t j = (uint32_t)lane + 64u * (uint32_t)k;
+          uint4 e = s_ev[ev[k]];
+          asm volatile("" : "+v"(e.x), "+v"(e.y));  // (read by every lane: hipcc would sink the read into a branch on j < nh)
+#ifdef AHA_EXPAND_NOGATHER  // (lab: every gather reads entry 0 -- wrong hits, the time without the gathers' misses)
+          at[k] = (j < nh && e.y == 0xFFFFFFFFu) ? e.y + (h0 + j - e.x) : 0u;
+#else
+          at[k] = j < nh ? e.y + (h0 + j - e.x) : 0u;  // (beyond the window: entry 0, gathered and ignored)
+#endif
+          en[k] = e.z;
+        }
+        h0 += kStage;
+        if (h0 >= tot) batch_done();
+      };
+      // B1: gathered entries into the staged window
+      auto fill = [&](const uint2 (&ce)[kPer], uint32_t nh, uint32_t ph) {
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+          // (no predicate: a place beyond the window's hits still lies inside hbuf, and nothing reads it)
+          const uint32_t w = ph + ((uint32_t)lane + 64u * (uint32_t)k) * 3;
+          hbuf[w] = en[k] - ce[k].x;  // Hit(idx-len+1, idx+1, value) ac.cr:271-273
+          hbuf[w + 1] = en[k];
+          hbuf[w + 2] = ce[k].y;
+        }
+        (void)nh;
+        expand_sync();
+      };
+      CLK_MARK(c_other)
+      bool prev = false;  // a staged window waits to go out (not in the pipeline's first round)
+      uint64_t p_first = 0;
+      uint32_t p_nh = 0, p_ph = 0;
+      for (;;) {
+        // A of the next window, if it is one of this pipeline's (in the first round: the window of the batch just loaded)
+        if (!have && i0 < n && ready_from == i0) (void)load_batch(std::true_type{});
+        const bool nx = have && by_hit;
+        if (nx) {
+          lookups();
+        } else {
+#pragma unroll
+          for (int k = 0; k < kPer; k++) at[k] = 0u;
+        }
+        // ... its gathers and the records of the batch behind the loaded one (or, while none is loaded, of the next): in flight
+        // until the wait below, their registers not to be looked at
+        const uint32_t want_from = have ? i0 + n_ev : i0;
+        v2u ce_raw[kPer], rec_raw;
+        {
+          const uint2 *ptr = reg + min(want_from + (uint32_t)lane, n - 1u);
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rec_raw) : "v"(ptr) : "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+          const uint32_t byte_off = at[k] << 3;  // (the table's base in scalar registers: no 64-bit address per lane)
+          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ce_raw[k]) : "v"(byte_off), "s"(chain) : "memory");
+        }
+        CLK_MARK(c_a)
+        // B2.  A window of 64 dwords or more that fits the output goes out as a COUNTED sequence of stores, every lane in every
+        // one of them: dwords 0 .. 63, the 16-byte quads from the first 128-byte line on in six rounds of 64 (a lane beyond the last
+        // quad stores the last quad again), dwords nd - 64 .. nd - 1.  What lanes store twice they store with the same value.
+        uint32_t counted = 0;  // stores issued that way (wave-uniform); 0: ordinary stores, uncounted
+        {
+          const uint64_t room = p_first < M.cap ? M.cap - p_first : 0;
+          const uint32_t nd = p_nh * 3;
+          if (!prev) {
+            // (nothing staged yet)
+          } else if (__builtin_amdgcn_readfirstlane((out16 && nd >= 64 && p_nh <= room) ? 1 : 0)) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(M.out + p_first);
+            const uint32_t head = (uint32_t)(((128u - ((uint32_t)reinterpret_cast<uintptr_t>(dst) & 127u)) & 127u) >> 2);  // < 32, = (4 - ph) mod 4
+            const uint32_t nq = (nd - head) >> 2;  // >= 8, <= 384
+            // (the window's address is the wave's: scalar registers, a 32-bit offset per lane)
+            const uint64_t dsta = reinterpret_cast<uint64_t>(dst);
+            const uint64_t sdst = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dsta >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dsta);
+            {
+              const uint32_t o0 = (uint32_t)lane * 4u;
+              const uint32_t d0 = hbuf[p_ph + lane];
+              // (s_nop: v_readfirstlane has just written the scalar pair, and a VMEM instruction may read an SGPR a VALU
+              // instruction wrote only five wait states later -- a hazard hipcc pads for its own instructions, not inside asm)
+              asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(o0), "v"(d0), "s"(sdst) : "memory");
+            }
+            // (always the six rounds of a full window -- a window of the cut batches is nearly one --, the six LDS reads in
+            // front of the six stores)
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(hbuf + p_ph + head);
+            // (three at a time: six quads in registers beside the gathers in flight would cost the fifth wave of a SIMD)
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+              uint4 tq[3];
+              uint32_t oq[3];
+#pragma unroll
+              for (int r = 0; r < 3; r++) {
+                const uint32_t q = min((uint32_t)(g * 3 + r) * 64u + (uint32_t)lane, nq - 1u);
+                tq[r] = s4[q];
+                oq[r] = head * 4u + q * 16u;
+              }
+#pragma unroll
+              for (int r = 0; r < 3; r++) {
+                const v4u dv = {tq[r].x, tq[r].y, tq[r].z, tq[r].w};
+                // (s_nop: the instruction behind a store of more than 8 bytes must not write the store's data registers --
+                // one wait state, which hipcc keeps for its own stores and cannot see to keep here)
+                asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(oq[r]), "v"(dv), "s"(sdst) : "memory");
+              }
+            }
+            {
+              const uint32_t o1 = ((nd - 64u) + (uint32_t)lane) * 4u;
+              const uint32_t d1 = hbuf[p_ph + (nd - 64u) + lane];
+              asm volatile("global_store_dword %0, %1, %2" ::"v"(o1), "v"(d1), "s"(sdst) : "memory");
+            }
+            counted = 2u + (uint32_t)(kPer - 2);
+            expand_sync();
+          } else {
+            stage_out(p_first, p_nh, p_ph);
+          }
+        }
+        CLK_MARK(c_b2)
+        if (counted == 8u)
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CLK_MARK(c_wait)
+        // (behind the wait: the loads' registers are values now)
+        rec_ready = make_uint2(rec_raw.x, rec_raw.y);
+        ready_from = want_from;
+        if (!nx) break;
+        {
+          uint2 ce[kPer];
+#pragma unroll
+          for (int k = 0; k < kPer; k++) ce[k] = make_uint2(ce_raw[k].x, ce_raw[k].y);
+          fill(ce, w_nh, w_ph);
+        }
+        p_first = w_first;
+        p_nh = w_nh;
+        p_ph = w_ph;
+        prev = true;
+        CLK_MARK(c_fill)
+#ifdef AHA_EXPAND_CLK
+        n_win++;
+#endif
+      }
+    }
+#ifdef AHA_EXPAND_CLK
+    if (lane == 0 && (c & 63) == 0) {  // (a sample: one chunk in 64)
+      c_other += clock64() - t_last;
+      atomicAdd(&M.cursor[8], (unsigned long long)c_a);
+      atomicAdd(&M.cursor[9], (unsigned long long)c_b2);
+      atomicAdd(&M.cursor[10], (unsigned long long)c_wait);
+      atomicAdd(&M.cursor[11], (unsigned long long)c_fill);
+      atomicAdd(&M.cursor[12], (unsigned long long)(wall_clock64() - w_start));  // (100 MHz)
+      atomicAdd(&M.cursor[13], (unsigned long long)n_win);
+      atomicAdd(&M.cursor[14], (unsigned long long)(clock64() - t_start));
+      atomicAdd(&M.cursor[15], 1ull);
+    }
+    k_chunks++;
+#endif
+  }
+#ifdef AHA_EXPAND_CLK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (what the wave's end waits for anyway)
+  if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) {
+    atomicAdd(&M.cursor[5], (unsigned long long)(clock64() - k_start));
+    atomicAdd(&M.cursor[6], (unsigned long long)k_chunks);
+    atomicAdd(&M.cursor[7], 1ull);
+  }
+#endif
 }
 
 // doc_hit_off[d] = hits before the document's first event: the chunk's hit base + the chain lengths (carried by the
@@ -1090,15 +1504,28 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
   launch_scan(M.chunk_hits, M.n_chunks, M.blk_a, M.hit_base, M.totals + 0, abortf, s);
   if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
   const dim3 ge(grid_for(M.n_chunks, 1, 1u << 20));
+  // the dense expansion: a wave's first loads and the acknowledgement of its last stores (a wave ends when they are in) cost
+  // ~35 000 clocks beside the ~90 000 of a chunk's windows -- its blocks take a few chunks each (AHA_EXPAND_BLOCKS, lab: 81 920 blocks 3.27 ms, one per chunk 3.48, 20 480 3.38, 5 120 3.78)
+  uint32_t dense_blocks = 256u * 20u * 16u;
+  if (const char *e = getenv("AHA_EXPAND_BLOCKS")) dense_blocks = (uint32_t)std::max(1, atoi(e));  // (lab)
+  const dim3 gd((uint32_t)std::min<uint64_t>(M.n_chunks ? M.n_chunks : 1, dense_blocks));
   if (M.chars) {
     // lead bytes before every chunk (the traversal counted them per chunk)
     launch_scan(M.lead_cnt, M.n_chunks, M.blk_b, M.lead_base, M.totals + 1, abortf, s);
     if (M.dense_hits)
+#ifdef AHA_EXPAND_OLD
       hipLaunchKernelGGL((k2d_expand<512, true>), ge, dim3(64), 0, s, A, M);
+#else
+      hipLaunchKernelGGL((k2d_expand_dense<true>), gd, dim3(64), 0, s, A, M);
+#endif
     else
       hipLaunchKernelGGL((k2d_expand<256, true>), ge, dim3(64), 0, s, A, M);
   } else if (M.dense_hits) {
+#ifdef AHA_EXPAND_OLD
     hipLaunchKernelGGL((k2d_expand<512, false>), ge, dim3(64), 0, s, A, M);
+#else
+    hipLaunchKernelGGL((k2d_expand_dense<false>), gd, dim3(64), 0, s, A, M);
+#endif
   } else {
     hipLaunchKernelGGL((k2d_expand<256, false>), ge, dim3(64), 0, s, A, M);
   }

@@ -180,4 +180,57 @@ __device__ __forceinline__ T block_excl_scan(T v, T *smem /*[kBlock/64]*/, T *to
 }
 
 
+// exclusive scan of in[0..n) into out, the sum into *total: one block of 1024 threads (sm: 16 words of its LDS).  k2_scan_small's
+// body, and the tail of kf_walk's last block (scan_filter.hip)
+__device__ __forceinline__ void scan_small_block(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out,
+                                                 uint64_t *total, uint64_t *sm) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint64_t carry = 0;
+  for (uint64_t r0 = 0; r0 < n; r0 += 16384) {
+    const uint64_t i0 = r0 + (uint64_t)threadIdx.x * 16;
+    uint32_t v[16];
+    if (i0 + 16 <= n) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint4 x = reinterpret_cast<const uint4 *>(in + i0)[q];
+        v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = i0 + j < n ? in[i0 + j] : 0u;
+    }
+    uint64_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) mine += v[j];
+    const uint64_t inc = wave_incl_scan(mine);
+    if (lane == 63) sm[w] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t x = sm[j];
+      if (j < w) base += x;
+      tot += x;
+    }
+    uint64_t run = carry + base + inc - mine;
+    if (i0 + 16 <= n) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint64_t a = run, b = run + v[2 * q];
+        run = b + v[2 * q + 1];
+        reinterpret_cast<ulonglong2 *>(out + i0)[q] = make_ulonglong2(a, b);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        if (i0 + j < n) out[i0 + j] = run;
+        run += v[j];
+      }
+    }
+    __syncthreads();
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
 }  // namespace aha

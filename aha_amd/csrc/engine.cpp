@@ -297,7 +297,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   const uint64_t cand_cap = pair ? std::max<uint64_t>(N / 48 + 4096, (uint64_t)ac->v2_grid * (kV2Threads / 64) * 256) : 0;
   size_t sizes[26] = {M.ev_cap * 16,      M.ev_cap * 16,      M.ev_cap * 4,     direct ? 0 : n_slabs * 4,
                       M.n_chunks * 4,     (M.n_docs + 1) * 4, M.n_chunks * 8,   n_blk * 8,
-                      n_blk * 8,          16 * 8,             M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
+                      n_blk * 8,          kCursorBytes,       M.chars ? M.ev_cap * 4 : 0, M.chars ? M.ev_cap * 4 : 0,
                       (M.chars || pair) ? M.n_chunks * 4 : 0, (M.chars || pair) ? M.n_chunks * 4 : 0, M.chars ? (M.n_docs + 1) * 4 : 0,
                       M.chars ? M.n_chunks * 8 : 0,
                       (unit && ac->unit_fused) ? 0 : n_reg * 8, 0 /* [17]: aligned copy of an unaligned corpus */,
@@ -326,8 +326,10 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   M.ev_base = (uint64_t *)sc->v2buf[6].p;
   M.blk_a = (uint64_t *)sc->v2buf[7].p;
   M.blk_b = (uint64_t *)sc->v2buf[8].p;
-  M.cursor = (unsigned long long *)sc->v2buf[9].p;
-  M.totals = (uint64_t *)sc->v2buf[9].p + 2;
+  if (sc->cursor_buf != sc->v2buf[9].p) {  // (a new buffer: nothing is known about its words)
+    sc->cursor_buf = sc->v2buf[9].p;
+    sc->cursor_dirty = true;
+  }
   M.ev_aux = (uint32_t *)sc->v2buf[10].p;
   M.sorted_aux = (uint32_t *)sc->v2buf[11].p;
   M.lead_cnt = (uint32_t *)sc->v2buf[12].p;
@@ -342,9 +344,18 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if ((rc = ensure_h_v2(ac, sc))) return rc;
   // the region pipelines' last kernel -- the per-document offsets -- leaves the host's five words itself
   M.publish = (direct && M.doc_hit_off && sc->h_v2_dev) ? sc->h_v2_dev : nullptr;
+  // the call's counter block; the kernel that publishes also clears the other block for the next call
+  static const bool always_clear = getenv("AHA_CURSOR_MEMSET") != nullptr;  // (lab: the memset in front of every call, as before round 6)
+  if (sc->cursor_dirty || always_clear) {
+    HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, kCursorBytes, s));
+    sc->cursor_phase = 0;
+  }
+  M.cursor = (unsigned long long *)sc->v2buf[9].p + 16 * sc->cursor_phase;
+  M.totals = (uint64_t *)M.cursor + 2;
+  M.clear_next = M.publish ? (unsigned long long *)sc->v2buf[9].p + 16 * (sc->cursor_phase ^ 1u) : nullptr;
+  sc->cursor_dirty = true;  // (until this call has run to its end)
 
   const bool prof = ac->profiling.load() && sc->ev_ready;
-  HIPCHK(ac, hipMemsetAsync(sc->v2buf[9].p, 0, 16 * 8, s));
   // device-resident offsets nobody has looked at yet: validated here, in front of the traversal; a bad verdict lands in
   // cursor[1], where the traversal and every post pass look first (no read-back before the launch: -30 us per call)
   if (M1.check_docs) launch_check_docs(M.doc_off, M.n_docs, N, nullptr, M.cursor + 1, s);
@@ -400,15 +411,19 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
   if (M.publish) {
     // (done by k2d_doc_offsets / ku_doc_offsets)
   } else if (sc->h_v2_dev) {
-    launch_publish_words((const unsigned long long *)sc->v2buf[9].p, sc->h_v2_dev, 5, s);
+    launch_publish_words((const unsigned long long *)M.cursor, sc->h_v2_dev, 5, s);
   } else {
-    HIPCHK(ac, hipMemcpyAsync(sc->h_v2, sc->v2buf[9].p, 5 * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ac, hipMemcpyAsync(sc->h_v2, M.cursor, 5 * 8, hipMemcpyDeviceToHost, s));
   }
   HIPCHK(ac, hipStreamSynchronize(s));
+  if (M.clear_next) {  // every kernel of the call has run: the other block is clear
+    sc->cursor_dirty = false;
+    sc->cursor_phase ^= 1u;
+  }
 #ifdef AHA_EXPAND_CLK
   {  // (lab: the dense expansion's phases, clock cycles summed over the sampled chunks' waves)
     unsigned long long w[16];
-    (void)hipMemcpy(w, sc->v2buf[9].p, sizeof(w), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(w, M.cursor, sizeof(w), hipMemcpyDeviceToHost);
     if (w[15])
       fprintf(stderr, "k2d_expand_dense, %llu sampled chunks, %.1f windows each; cycles per window: A %.0f  B2 %.0f  wait %.0f  fill %.0f  wall-clock ticks of 10 ns per chunk %.0f; clocks per chunk %.0f\n",
               w[15], (double)w[13] / w[15], (double)w[8] / w[13], (double)w[9] / w[13], (double)w[10] / w[13], (double)w[11] / w[13], (double)w[12] / w[15],
@@ -419,7 +434,7 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
 #ifdef AHA_SK_STATS
   if (skip) {
     unsigned long long w[16];
-    (void)hipMemcpy(w, sc->v2buf[9].p, sizeof(w), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(w, M.cursor, sizeof(w), hipMemcpyDeviceToHost);
     fprintf(stderr, "ks_traverse: %llu lane-trips (%.4f per byte), %llu jumps, %llu fresh, %llu wave-trips (%.1f %% of the lane slots used)\n", w[8],
             (double)w[8] / (double)N, w[9], w[11], w[10], 100.0 * (double)w[8] / (64.0 * (double)w[10]));
   }
@@ -495,9 +510,9 @@ int32_t device_match(aha_ac *ac, Scratch *sc, const uint8_t *d_corpus, const uin
   auto check_now = [&]() -> int32_t {
     // the offsets live in HBM: one small kernel and an 4-byte read-back before anything indexes with them
     int32_t rc2;
-    if ((rc2 = v2_reserve(ac, sc, 9, 16 * 8))) return rc2;
+    if ((rc2 = v2_reserve(ac, sc, 9, kCursorBytes))) return rc2;
     if ((rc2 = ensure_h_v2(ac, sc))) return rc2;
-    uint32_t *flag = (uint32_t *)sc->v2buf[9].p + 30;
+    uint32_t *flag = (uint32_t *)sc->v2buf[9].p + 64;  // (the third block: odd words)
     HIPCHK(ac, hipMemsetAsync(flag, 0, 4, s));
     launch_check_docs(d_doc_offsets, n_docs, n_bytes, flag, nullptr, s);
     HIPCHK(ac, hipMemcpyAsync(sc->h_v2, flag, 4, hipMemcpyDeviceToHost, s));

@@ -41,7 +41,14 @@ struct Scratch {
   hipStream_t hs[3] = {};  // host-buffer entry: private non-blocking streams for upload, match, download
   unsigned long long *h_v2 = nullptr;  // pinned: cursor[2] + totals[3]
   unsigned long long *h_v2_dev = nullptr;  // the same words as the device addresses them
+  // v2buf[9] holds TWO blocks of 16 counter words (and a third of odd words): a call counts in one of them, and its last kernel
+  // clears the other for the call behind it -- no memset in front of a call (5 us of a 64 MiB call).  Dirty: the blocks are
+  // not known to be clear (new buffer, a call that did not run to its end): the next call clears both itself.
+  const void *cursor_buf = nullptr;
+  bool cursor_dirty = true;
+  uint32_t cursor_phase = 0;
 };
+constexpr size_t kCursorBytes = 3 * 16 * 8;
 constexpr size_t kMaxScratch = 8;
 // last error text of the calling thread (aha_last_error): calls on one handle may run concurrently
 extern thread_local std::string tls_err;

@@ -130,6 +130,10 @@ struct V2Args {
   // region pipelines: where the call's last kernel -- the per-document offsets -- leaves the five words the host reads
   // (cursor[0..1], totals[0..2]: k_publish_words as a launch of its own costs ~5 us of a 64 MiB call); null: nobody publishes
   unsigned long long *publish;
+  // the 16 counter words of the NEXT call on this scratch, cleared by the same kernel (engine.cpp: Scratch::cursor_phase); null: nobody clears
+  unsigned long long *clear_next;
+  // the region pipeline's expansion launch: its blocks from doc_from on compute the documents' hit offsets (0: a launch of their own)
+  uint32_t doc_from, doc_lanes16;
 };
 
 // ---- character-level engine (scan_unit.hip, unit.hpp) ---------------------------

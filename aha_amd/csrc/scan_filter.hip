@@ -429,6 +429,8 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
       if (seq > M.ev_stride) M.cursor[1] = 2ull;  // region full: the host repeats the call with larger regions
     }
   }
+  // (The scan of the chunks' hit counts does NOT ride on this launch: the last block to finish would do it behind a
+  // device-scope fence per block -- on this chip an L2 write-back per XCD -- and the walks' 20 us became 89, profiles/r06_cfg2_fixed_costs.txt.)
 }
 
 }  // namespace

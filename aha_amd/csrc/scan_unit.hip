@@ -673,6 +673,7 @@ __global__ __launch_bounds__(256) void ku_chunk_adj(V2Args M) {
 __global__ __launch_bounds__(256) void ku_doc_offsets(V2Args M) {
   // (the call's last kernel: every word the host reads is final -- this kernel changes none of them)
   if (M.publish && blockIdx.x == 0 && threadIdx.x < 5) M.publish[threadIdx.x] = M.cursor[threadIdx.x];
+  if (M.clear_next && blockIdx.x == 0 && threadIdx.x < 16) M.clear_next[threadIdx.x] = 0ull;  // (the next call's counters)
   if (M.cursor[1] || !M.doc_hit_off) return;
   const uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (d > M.n_docs) return;

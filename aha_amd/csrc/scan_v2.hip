@@ -462,53 +462,7 @@ __global__ __launch_bounds__(1024) void k2_scan_small(const uint32_t *__restrict
                                                       uint64_t *total, const unsigned long long *abort_flag) {
   __shared__ uint64_t sm[16];
   if (abort_flag && *abort_flag) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint64_t carry = 0;
-  for (uint64_t r0 = 0; r0 < n; r0 += 16384) {
-    const uint64_t i0 = r0 + (uint64_t)threadIdx.x * 16;
-    uint32_t v[16];
-    if (i0 + 16 <= n) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const uint4 x = reinterpret_cast<const uint4 *>(in + i0)[q];
-        v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; j++) v[j] = i0 + j < n ? in[i0 + j] : 0u;
-    }
-    uint64_t mine = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) mine += v[j];
-    const uint64_t inc = wave_incl_scan(mine);
-    if (lane == 63) sm[w] = inc;
-    __syncthreads();
-    uint64_t base = 0, tot = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint64_t x = sm[j];
-      if (j < w) base += x;
-      tot += x;
-    }
-    uint64_t run = carry + base + inc - mine;
-    if (i0 + 16 <= n) {
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const uint64_t a = run, b = run + v[2 * q];
-        run = b + v[2 * q + 1];
-        reinterpret_cast<ulonglong2 *>(out + i0)[q] = make_ulonglong2(a, b);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        if (i0 + j < n) out[i0 + j] = run;
-        run += v[j];
-      }
-    }
-    __syncthreads();
-    carry += tot;
-  }
-  if (threadIdx.x == 0) *total = carry;
+  scan_small_block(in, n, out, total, sm);
 }
 
 // exclusive scan of in[0..n) into out, the sum into *total
@@ -770,6 +724,66 @@ __global__ __launch_bounds__(256) void k2d_count(DevAut A, V2Args M) {
 // workgroups per CU to hide the table gathers) otherwise; a batch with more hits takes the direct-store path.
 // CHARS (String overload, matcher.cr:34-39): the record's second word is the lead-byte count of the position
 // (<< 1 | "counted from the document start") instead of the byte offset; hits are char offsets.
+// doc_hit_off[d] = hits before the document's first event: the chunk's hit base + the chain lengths (carried by the
+// records since k2d_count) of the chunk's events before it.  One thread per document; a chunk holds few events.
+// LANES = 16: sixteen lanes (a DPP row) per document -- the events of the chunk before the document's first are summed sixteen
+// at a time (one thread per document walks them one by one: 19 us for cfg 2's 16 384 documents with 70 events per 32 KiB
+// chunk); LANES = 1: a thread per document, for batches of many small documents (few events before each).
+// A block of BLOCK threads, the blk-th of the documents' blocks: rides on the expansion's launch (blocks behind the expansion's
+// own: a launch of its own costs ~5 us of a 64 MiB call) or is k2d_doc_offsets' (batches the expansion's launch does not serve).
+template <int LANES, int BLOCK>
+__device__ __forceinline__ void doc_offsets_block(const DevAut &A, const V2Args &M, uint32_t blk) {
+  // (part of the call's last launch, and nothing in that launch changes a word the host reads)
+  if (M.publish && blk == 0 && threadIdx.x < 5) M.publish[threadIdx.x] = M.cursor[threadIdx.x];
+  if (M.clear_next && blk == 0 && threadIdx.x < 16) M.clear_next[threadIdx.x] = 0ull;  // (the next call's counters)
+  if (M.cursor[1] || !M.doc_hit_off) return;
+  const uint64_t d = ((uint64_t)blk * BLOCK + threadIdx.x) / LANES;
+  const uint32_t j = threadIdx.x & (uint32_t)(LANES - 1);
+  const bool in = d <= M.n_docs;
+  const uint64_t q = in ? M.doc_off[d] : M.n_bytes;
+  uint64_t r = M.totals[0];
+  uint32_t part = 0;
+  bool summed = false;
+  if (q < M.n_bytes) {
+    const uint64_t c = q / M.S;
+    const uint32_t rank = M.doc_ev_rank[d];
+    if (rank >= M.ev_cnt[c]) {
+      r = M.hit_base[c] + M.chunk_hits[c];
+    } else {
+      const uint2 *reg = M.evd + c * M.ev_stride;
+      for (uint32_t i = j; i < rank; i += LANES) {
+        const uint32_t x = reg[i].x;
+        const uint32_t cnt = x >> 24;
+        part += cnt == 255u ? A.key_cnt[A.chain ? A.chain[x & 0xFFFFFFu].y : (x & 0xFFFFFFu)] : cnt;
+      }
+      r = M.hit_base[c];
+      summed = true;
+    }
+  }
+  if (LANES == 16) {  // the row's sum in its last lane (row_shr 1, 2, 4, 8; lanes without a source add 0)
+    part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x111, 0xf, 0xf, false);
+    part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x112, 0xf, 0xf, false);
+    part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x114, 0xf, 0xf, false);
+    part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x118, 0xf, 0xf, false);
+  }
+  if (in && j == (uint32_t)(LANES - 1)) M.doc_hit_off[d] = r + (summed ? part : 0u);
+}
+
+template <int LANES>
+__global__ __launch_bounds__(256) void k2d_doc_offsets(DevAut A, V2Args M) {
+  doc_offsets_block<LANES, 256>(A, M, blockIdx.x);
+}
+
+// (the expansion kernels' first lines: blocks from M.doc_from on are the documents')
+__device__ __forceinline__ bool expand_block_is_docs(const DevAut &A, const V2Args &M) {
+  if (!M.doc_from || blockIdx.x < M.doc_from) return false;
+  if (M.doc_lanes16)
+    doc_offsets_block<16, 64>(A, M, blockIdx.x - M.doc_from);
+  else
+    doc_offsets_block<1, 64>(A, M, blockIdx.x - M.doc_from);
+  return true;
+}
+
 // The block is ONE wave: what its lanes hand one another through LDS needs the order of the wave's own LDS instructions
 // (which the hardware keeps) and a compiler fence -- not __syncthreads(), whose s_waitcnt vmcnt(0) would also wait for the
 // window's stores to be acknowledged by memory before the next window's first LDS write.
@@ -792,9 +806,11 @@ __global__ __launch_bounds__(64) void k2d_expand(DevAut A, V2Args M) {
   __shared__ uint32_t s_excl[64], s_co[64], s_end[64];
   __shared__ __attribute__((aligned(16))) uint8_t s_mark[kWaveStage];  // by hit index: 1 where an event's first hit stands
   const bool out16 = (reinterpret_cast<uintptr_t>(M.out) & 15u) == 0;
+  if (expand_block_is_docs(A, M)) return;
   if (M.cursor[1]) return;
   const int lane = threadIdx.x;
-  for (uint64_t c = blockIdx.x; c < M.n_chunks; c += gridDim.x) {
+  const uint32_t n_blocks = M.doc_from ? M.doc_from : gridDim.x;
+  for (uint64_t c = blockIdx.x; c < M.n_chunks; c += n_blocks) {
     const uint32_t n = M.ev_cnt[c];
     if (n == 0) continue;
     const uint2 *reg = M.evd + c * M.ev_stride;
@@ -996,10 +1012,12 @@ __global__ __launch_bounds__(64) void k2d_expand_dense(DevAut A, V2Args M) {
   uint64_t k_chunks = 0;
 #endif
   const bool out16 = (reinterpret_cast<uintptr_t>(M.out) & 15u) == 0;
+  if (expand_block_is_docs(A, M)) return;
   if (M.cursor[1]) return;
   const int lane = threadIdx.x;
   const uint2 *chain = CHARS ? A.chain_chars : A.chain;
-  for (uint64_t c = blockIdx.x; c < M.n_chunks; c += gridDim.x) {
+  const uint32_t n_blocks = M.doc_from ? M.doc_from : gridDim.x;
+  for (uint64_t c = blockIdx.x; c < M.n_chunks; c += n_blocks) {
     const uint32_t n = M.ev_cnt[c];
     if (n == 0) continue;
     const uint2 *reg = M.evd + c * M.ev_stride;
@@ -1346,48 +1364,6 @@ __global__ __launch_bounds__(64) void k2d_expand_dense(DevAut A, V2Args M) {
 #endif
 }
 
-// doc_hit_off[d] = hits before the document's first event: the chunk's hit base + the chain lengths (carried by the
-// records since k2d_count) of the chunk's events before it.  One thread per document; a chunk holds few events.
-// LANES = 16: sixteen lanes (a DPP row) per document -- the events of the chunk before the document's first are summed sixteen
-// at a time (one thread per document walks them one by one: 19 us for cfg 2's 16 384 documents with 70 events per 32 KiB
-// chunk); LANES = 1: a thread per document, for batches of many small documents (few events before each).
-template <int LANES>
-__global__ __launch_bounds__(256) void k2d_doc_offsets(DevAut A, V2Args M) {
-  // (the call's last kernel: every word the host reads is final -- this kernel changes none of them)
-  if (M.publish && blockIdx.x == 0 && threadIdx.x < 5) M.publish[threadIdx.x] = M.cursor[threadIdx.x];
-  if (M.cursor[1] || !M.doc_hit_off) return;
-  const uint64_t d = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / LANES;
-  const uint32_t j = threadIdx.x & (uint32_t)(LANES - 1);
-  const bool in = d <= M.n_docs;
-  const uint64_t q = in ? M.doc_off[d] : M.n_bytes;
-  uint64_t r = M.totals[0];
-  uint32_t part = 0;
-  bool summed = false;
-  if (q < M.n_bytes) {
-    const uint64_t c = q / M.S;
-    const uint32_t rank = M.doc_ev_rank[d];
-    if (rank >= M.ev_cnt[c]) {
-      r = M.hit_base[c] + M.chunk_hits[c];
-    } else {
-      const uint2 *reg = M.evd + c * M.ev_stride;
-      for (uint32_t i = j; i < rank; i += LANES) {
-        const uint32_t x = reg[i].x;
-        const uint32_t cnt = x >> 24;
-        part += cnt == 255u ? A.key_cnt[A.chain ? A.chain[x & 0xFFFFFFu].y : (x & 0xFFFFFFu)] : cnt;
-      }
-      r = M.hit_base[c];
-      summed = true;
-    }
-  }
-  if (LANES == 16) {  // the row's sum in its last lane (row_shr 1, 2, 4, 8; lanes without a source add 0)
-    part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x111, 0xf, 0xf, false);
-    part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x112, 0xf, 0xf, false);
-    part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x114, 0xf, 0xf, false);
-    part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x118, 0xf, 0xf, false);
-  }
-  if (in && j == (uint32_t)(LANES - 1)) M.doc_hit_off[d] = r + (summed ? part : 0u);
-}
-
 // ---------------------------------------------------------------- launchers
 size_t v2_lds_bytes(uint32_t lds_slots, bool compact) {
   return (size_t)lds_slots * (compact ? 4 : 8) + (size_t)(kV2Threads / 64) * kWaveIn2;
@@ -1490,7 +1466,8 @@ void v2_launch_lead_scan(const V2Args &M, void *stream) {  // lead_cnt -> lead_b
               (hipStream_t)stream);
 }
 
-void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void *ev_mid, bool counted) {
+void v2_launch_direct_post(const DevAut &A, const V2Args &M0, void *stream, void *ev_mid, bool counted) {
+  V2Args M = M0;
   hipStream_t s = (hipStream_t)stream;
   const uint32_t gw = grid_for(M.n_chunks, 4, 8192);  // 4 waves (chunks) per 256-thread block
   if (counted) {
@@ -1508,7 +1485,23 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
   // ~35 000 clocks beside the ~90 000 of a chunk's windows -- its blocks take a few chunks each (AHA_EXPAND_BLOCKS, lab: 81 920 blocks 3.27 ms, one per chunk 3.48, 20 480 3.38, 5 120 3.78)
   uint32_t dense_blocks = 256u * 20u * 16u;
   if (const char *e = getenv("AHA_EXPAND_BLOCKS")) dense_blocks = (uint32_t)std::max(1, atoi(e));  // (lab)
-  const dim3 gd((uint32_t)std::min<uint64_t>(M.n_chunks ? M.n_chunks : 1, dense_blocks));
+  dim3 gd((uint32_t)std::min<uint64_t>(M.n_chunks ? M.n_chunks : 1, dense_blocks));
+  dim3 gx = ge;
+  // the documents' hit offsets ride on the expansion's launch: blocks of 64 threads behind the expansion's own
+  const uint64_t nd = M.n_docs + 1;
+  const bool lanes16 = nd <= 4 * M.n_chunks;  // (few documents per chunk: many events can stand before a document's first)
+  const uint64_t doc_blocks = lanes16 ? (nd * 16 + 63) / 64 : (nd + 63) / 64;
+#ifdef AHA_EXPAND_OLD
+  const bool ride = false;
+#else
+  const bool ride = M.doc_hit_off && doc_blocks + gx.x < (1u << 22) && !getenv("AHA_DOC_OFFSETS_LAUNCH");  // (the variable: lab, a launch of their own)
+#endif
+  if (ride) {
+    M.doc_lanes16 = lanes16 ? 1 : 0;
+    M.doc_from = M.dense_hits ? gd.x : gx.x;
+    gd.x += (uint32_t)doc_blocks;
+    gx.x += (uint32_t)doc_blocks;
+  }
   if (M.chars) {
     // lead bytes before every chunk (the traversal counted them per chunk)
     launch_scan(M.lead_cnt, M.n_chunks, M.blk_b, M.lead_base, M.totals + 1, abortf, s);
@@ -1519,7 +1512,7 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
       hipLaunchKernelGGL((k2d_expand_dense<true>), gd, dim3(64), 0, s, A, M);
 #endif
     else
-      hipLaunchKernelGGL((k2d_expand<256, true>), ge, dim3(64), 0, s, A, M);
+      hipLaunchKernelGGL((k2d_expand<256, true>), gx, dim3(64), 0, s, A, M);
   } else if (M.dense_hits) {
 #ifdef AHA_EXPAND_OLD
     hipLaunchKernelGGL((k2d_expand<512, false>), ge, dim3(64), 0, s, A, M);
@@ -1527,11 +1520,10 @@ void v2_launch_direct_post(const DevAut &A, const V2Args &M, void *stream, void 
     hipLaunchKernelGGL((k2d_expand_dense<false>), gd, dim3(64), 0, s, A, M);
 #endif
   } else {
-    hipLaunchKernelGGL((k2d_expand<256, false>), ge, dim3(64), 0, s, A, M);
+    hipLaunchKernelGGL((k2d_expand<256, false>), gx, dim3(64), 0, s, A, M);
   }
-  if (M.doc_hit_off) {
-    const uint64_t nd = M.n_docs + 1;
-    if (nd <= 4 * M.n_chunks)  // (few documents per chunk: many events can stand before a document's first)
+  if (M.doc_hit_off && !ride) {
+    if (lanes16)
       hipLaunchKernelGGL(k2d_doc_offsets<16>, dim3((uint32_t)((nd * 16 + 255) / 256)), dim3(256), 0, s, A, M);
     else
       hipLaunchKernelGGL(k2d_doc_offsets<1>, dim3((uint32_t)((nd + 255) / 256)), dim3(256), 0, s, A, M);

@@ -434,12 +434,18 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
     const uint32_t *src = M.evg + g * 64 * stride * 3;
     uint2 *dst = M.evd + g * 64 * stride;
+    // the next block's records and their end_info entries are requested a block ahead and waited for IN FRONT of this
+    // block's stores: vmcnt counts loads and stores in one order, and a load waited for behind the stores waits for their
+    // acknowledgement too (profiles/r06_expand_pipeline.txt)
     uint2 nxt[kRgPer];
+    uint32_t xn[kRgPer];
 #pragma unroll
     for (int q = 0; q < kRgPer; q++) {
       const uint32_t i = q * kRgThreads + threadIdx.x;
       nxt[q] = i < total ? make_uint2(src[(size_t)i * 3], src[(size_t)i * 3 + 1]) : make_uint2(0, 0);
     }
+#pragma unroll
+    for (int q = 0; q < kRgPer; q++) xn[q] = (uint32_t)(q * kRgThreads) + threadIdx.x < total ? A.end_info[nxt[q].x & bmask] : 0u;
     for (uint32_t i0 = 0; i0 < total; i0 += kRgBlock) {
       uint2 rec[kRgPer];
       uint32_t x[kRgPer], rank[kRgPer], l[kRgPer];
@@ -449,10 +455,10 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
         const uint32_t i = i0 + q * kRgThreads + threadIdx.x;
         live[q] = i < total;
         rec[q] = nxt[q];
+        // key id, or (flattened chains) the offset of its chain, | min(chain length, 255) << 24
+        x[q] = xn[q];
         nxt[q] = i + kRgBlock < total ? make_uint2(src[(size_t)(i + kRgBlock) * 3], src[(size_t)(i + kRgBlock) * 3 + 1])
                                       : make_uint2(0, 0);
-        // key id, or (flattened chains) the offset of its chain, | min(chain length, 255) << 24
-        x[q] = live[q] ? A.end_info[rec[q].x & bmask] : 0u;
       }
 #pragma unroll
       for (int q = 0; q < kRgPer; q++) {
@@ -504,6 +510,11 @@ __global__ __launch_bounds__(kRgThreads) void ku_regroup(DevAut A, V2Args M) {
         }
       }
       __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kRgPer; q++)  // (the next block's records have arrived by now: their entries go out in front of the stores)
+        xn[q] = i0 + kRgBlock + (uint32_t)(q * kRgThreads) + threadIdx.x < total ? A.end_info[nxt[q].x & bmask] : 0u;
+#pragma unroll
+      for (int q = 0; q < kRgPer; q++) asm volatile("" : "+v"(xn[q]));  // (... and are waited for here)
       const uint32_t nb = min(total - i0, (uint32_t)kRgBlock);
 #pragma unroll
       for (int q = 0; q < kRgPer; q++) {

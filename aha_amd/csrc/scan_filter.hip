@@ -377,14 +377,24 @@ __global__ __launch_bounds__(IMG ? 1024 : 256) void kf_walk(DevAut A, V2Args M, 
       const uint32_t vincl = wave_incl_scan(nv);
       const uint32_t vtot = wave_last(vincl);
       uint32_t at = seq + vincl - nv;
+      // {key id or offset of its flattened chain | chain length << 24, end offset in the document}: what k2d_count makes of
+      // {END state, ..} -- one gather per event here saves its launch (4.4 us + the gap of a 64 MiB call) and its pass.
+      // All gathers (and the next batch's text, requested at the top) are waited for IN FRONT of the batch's stores: vmcnt
+      // counts loads and stores in one order, a load waited for behind a store waits for the store's acknowledgement too.
+      uint32_t xk[kfMaxEnds], ck[kfMaxEnds];
+#pragma unroll
+      for (int k = 0; k < kfMaxEnds; k++) xk[k] = val[k] ? A.end_info[eb[k]] : 0u;
+#pragma unroll
+      for (int k = 0; k < kfMaxEnds; k++) {
+        ck[k] = xk[k] >> 24;
+        if (val[k] && ck[k] == 255u) ck[k] = A.key_cnt[A.chain ? A.chain[xk[k] & 0xFFFFFFu].y : (xk[k] & 0xFFFFFFu)];
+      }
+      asm volatile("" : "+v"(tn));
 #pragma unroll
       for (int k = 0; k < kfMaxEnds; k++)
         if (val[k]) {
-          // {key id or offset of its flattened chain | chain length << 24, end offset in the document}: what k2d_count makes of
-          // {END state, ..} -- one gather per event here saves its launch (4.4 us + the gap of a 64 MiB call) and its pass
-          uint32_t x = A.end_info[eb[k]], cnt = x >> 24;
-          if (cnt == 255u) cnt = A.key_cnt[A.chain ? A.chain[x & 0xFFFFFFu].y : (x & 0xFFFFFFu)];
-          hsum += cnt;
+          const uint32_t x = xk[k];
+          hsum += ck[k];
           uint32_t y = (uint32_t)((int32_t)ej[k] - ds);
           if (CHARS) {  // the document starts inside the chunk: counted from there, exactly; else from the chunk start
             const bool exact = ds >= kfWarm;

@@ -350,6 +350,46 @@ def test_capacity_error_reports_required():
     assert gpu_list(out) == [(i, i + 1, 0) for i in range(10)]
 
 
+def test_dense_expansion_capacity_and_alignment(engine):
+    """The hit-dense expansion (k2d_expand_dense: windows of 512 hits, hand-issued counted stores) at its corners: an output
+    whose capacity ends inside a window / at a window's end / one hit short (AHA_E_CAPACITY with the count, nothing written behind
+    the capacity), an output address that is not 16-byte aligned (the uncounted store path), chains longer than the record's
+    count field beside short ones, many short documents.  Against the oracle (src/aha/ac.cr:265-278)."""
+    import torch
+
+    if engine not in ("v2", "u", "ur", "auto", "f"):
+        pytest.skip("one byte-level and the character-level variants")
+    for keys, text in ((["a" * k for k in range(1, 13)], "a" * 5000 + "b" + "a" * 3000),
+                       (["中" * k for k in range(1, 10)] + ["中国"], ("中" * 40 + "国") * 150),
+                       (["ab", "b", "abab", "bab", "abc"], "ababcab" * 3000)):
+        ac = AC.compile(keys)
+        o = orc.AC.compile(keys)
+        raw = text.encode()
+        corpus = np.frombuffer(raw, dtype=np.uint8)
+        for doc in (np.array([0, len(raw)], dtype=np.uint64),
+                    np.array(sorted(set(range(0, len(raw), 999)) | {len(raw)}), dtype=np.uint64)):
+            oh, od = o.match_batch(corpus, doc, cap=len(raw) * 16)
+            total = len(oh)
+            assert total > 4 * len(raw) // 4  # (hit-dense: the dense expansion's batch)
+            dc, dd = torch.from_numpy(corpus.copy()).cuda(), torch.from_numpy(doc.astype(np.int64)).cuda()
+            dho = torch.zeros(doc.size, dtype=torch.int64, device="cuda")
+            want = torch.from_numpy(np.ascontiguousarray(oh).view(np.int32).reshape(-1, 3))
+            big = torch.full((total + 64 + 4, 3), -7, dtype=torch.int32, device="cuda")
+            for shift in (0, 1):  # rows of 12 bytes: shift 1 = an output address that is 4- but not 16-byte aligned
+                for cap in (total, total + 5, total - 1, total - 300, 512, 513, 1000):
+                    big.fill_(-7)
+                    out = big[shift:shift + cap]
+                    if cap >= total:
+                        assert ac.match_batch_device(dc, dd, out, dho) == total
+                        assert torch.equal(out[:total].cpu(), want)
+                        assert np.array_equal(dho.cpu().numpy().astype(np.uint64), od)
+                    else:
+                        with pytest.raises(AhaError) as e:
+                            ac.match_batch_device(dc, dd, out, dho)
+                        assert e.value.code == N.AHA_E_CAPACITY and e.value.required == total
+                    assert bool((big[shift + cap:] == -7).all()) and bool((big[:shift] == -7).all())  # nothing behind / in front of the buffer
+
+
 def test_capacity_error_when_event_temp_overflows():
     # more events than the single-traversal engine's temp (sized from cap) can
     # hold: it must hand over to the two-pass engine and still report the count

@@ -340,6 +340,42 @@ def test_hand_issued_probe_is_not_touched_before_its_wait():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_the_isa_audit_fires_on_each_hazard_it_checks():
+    """tools/audit_probe.py on small ISA texts: the three faults that round 6's hand-issued kernel (k2d_expand_dense) met each
+    make it report -- a register of an in-flight asm load copied before the hand-written wait, a scalar base written by
+    v_readfirstlane right in front of an asm VMEM instruction, the data register of an asm 16-byte store rewritten by the next
+    instruction -- and their repaired forms do not; a block laid out between load and wait that only a branch from before
+    the load reaches is not taken for a use."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("audit_probe", os.path.join(root, "tools", "audit_probe.py"))
+    ap = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ap)
+    load = "\t;;#ASMSTART\n\tglobal_load_dwordx2 v[26:27], v[2:3], off\n\t;;#ASMEND\n"
+    wait = "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n"
+    # 1. a copy of the in-flight pair
+    n, bad = ap.audit(load + "\tv_add_u32_e32 v4, v5, v6\n\tv_mov_b64_e32 v[16:17], v[26:27]\n" + wait)
+    assert n == 1 and len(bad) == 1 and "v[26:27]" in bad[0][1]
+    assert ap.audit(load + "\tv_add_u32_e32 v4, v5, v6\n" + wait + "\tv_mov_b64_e32 v[16:17], v[26:27]\n") == (1, [])
+    # ... a block in between that only an earlier branch reaches
+    other = "\ts_branch .LBB0_9\n.LBB0_5:\n\tv_mov_b32_e32 v8, v26\n\ts_branch .LBB0_2\n.LBB0_9:\n"
+    assert ap.audit("\ts_cbranch_vccnz .LBB0_5\n" + load + other + wait) == (1, [])
+    n, bad = ap.audit(load + "\ts_cbranch_vccnz .LBB0_5\n" + other + wait)  # (reached from inside the stretch: a use)
+    assert n == 1 and len(bad) == 1
+    # ... load and wait in one asm statement
+    assert ap.audit("\t;;#ASMSTART\n\tglobal_load_dwordx2 v[26:27], v[2:3], off\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32_e32 v1, v26\n") == (1, [])
+    # 2. VALU-written SGPR -> VMEM
+    st = "\t;;#ASMSTART\n%s\tglobal_store_dword v52, v78, s[4:5]\n\t;;#ASMEND\n"
+    rfl = "\tv_readfirstlane_b32 s5, v50\n\tv_readfirstlane_b32 s4, v48\n\ts_waitcnt lgkmcnt(0)\n"
+    assert len(ap.sgpr_hazards(rfl + st % "")) == 1
+    assert ap.sgpr_hazards(rfl + st % "\ts_nop 4\n") == []
+    # 3. store data rewritten by the next instruction
+    st4 = "\t;;#ASMSTART\n\tglobal_store_dwordx4 v87, v[48:51], s[4:5]\n%s\t;;#ASMEND\n\tv_min_u32_e32 v48, v56, v86\n"
+    assert len(ap.store_data_hazards(st4 % "")) == 1
+    assert ap.store_data_hazards(st4 % "\ts_nop 1\n") == []
+
+
 def test_crystal_binding_declares_every_symbol_of_the_header():
     """bindings/crystal/aha_hip.cr cannot be compiled here (no Crystal): at least its `lib` block must bind every entry point
     the header declares (the round-3 review found 18 of 44 missing)."""

@@ -485,7 +485,12 @@ int32_t match_v2(aha_ac *ac, Scratch *sc, MatchArgs &M1, hipStream_t s, uint64_t
 // the events of a scratch set are created by the first profiled call that leases it
 int32_t ready_events(aha_ac *ac, Scratch *sc) {
   if (!ac->profiling.load() || sc->ev_ready) return AHA_OK;
-  for (auto &e : sc->ev) HIPCHK(ac, hipEventCreate(&e));
+  // (timing only -- nothing synchronizes with them, the call ends in hipStreamSynchronize --: created without the system-scope
+  // fence of a default event, i.e. without a cache write-back and invalidation between the kernels they stand between.  A
+  // 64 MiB call of cfg 2: 86 us against 89.5 with the fences (AHA_EVENT_FENCE=1) -- and 65 without any events: the five
+  // records themselves cost ~4 us each, profiles/r06_cfg2_fixed_costs.txt)
+  static const unsigned ev_flags = getenv("AHA_EVENT_FENCE") ? hipEventDefault : hipEventDisableSystemFence;
+  for (auto &e : sc->ev) HIPCHK(ac, hipEventCreateWithFlags(&e, ev_flags));
   sc->ev_ready = true;
   return AHA_OK;
 }

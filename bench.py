@@ -361,6 +361,26 @@ def main():
     gbs = float(tot_bytes.item()) * args.steps / elapsed / 1e9
     mhits = float(tot_hits.item()) * args.steps / elapsed / 1e6
 
+    # ---- the same K steps once more WITHOUT the library's timing events (the product's default; `value` above is measured with
+    # them, as the roofline needs their times from the timed region): five event records cost a call ~20 us of wall time,
+    # which shows on steps of a tenth of a millisecond (cfg 2 at 64 MiB) and nowhere else.  Reported beside, never as `value`.
+    no_events = None
+    if world == 1:
+        ac.set_profiling(False)
+        for _ in range(min(args.warmup, 2)):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        e1 = time.perf_counter() - t1
+        ac.set_profiling(True)
+        step()  # (last_timing() below is a profiled call's again)
+        no_events = {"ms_per_step": round(e1 / args.steps * 1e3, 4), "value": round(n_bytes * args.steps / e1 / 1e9, 3),
+                     "note": "the same steps with aha_ac_set_profiling off (no HIP event records inside the call)"}
+        log(f"without the library's timing events: {no_events['ms_per_step']} ms per step, {no_events['value']} GB/s")
+
     # ---- N > 1: the parts of a step on their own (SURVEY.md section 8 d: "gather time broken out"), untimed extras
     breakdown, strong = None, None
     if gather is not None:
@@ -617,6 +637,8 @@ def main():
                                       + (" (overlapped)" if overlap else "")},
             "roofline": roofline,
         }
+        if no_events is not None and ok:
+            line["without_timing_events"] = no_events
         if breakdown is not None:
             line["breakdown"] = breakdown
         if strong is not None:
